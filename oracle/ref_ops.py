@@ -1,0 +1,278 @@
+"""ORACLE — test infrastructure only (see oracle/__init__.py).
+
+torch-CPU fp32 restatement of the reference's head decode, target assignment, losses and post-processing.
+Every function cites the reference file:line it follows (paths relative to /root/reference).  Pinned against the
+reference itself by tests/golden/*.npz (tests/golden/make_golden.py imports the reference in the build container).
+
+Determinism contracts the reference leaves undefined and this build fixes:
+  * candidate order of build_targets = (offset, anchor, target) lexicographic  (what the reference's boolean-mask
+    indexing produces);  duplicate-cell tconf scatter = LAST writer in that order wins (CPU index_put_ behaviour);
+  * post_process sort = score descending, ties by ascending candidate index;
+  * CSL argmax = first maximal bin.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import nms_rotated as _c_nms_rotated
+
+PI = math.pi
+STRIDES = (8, 16, 32)                       # model/yolo.py:21
+OFFSETS = ((0.0, 0.0), (0.5, 0.0), (0.0, 0.5), (-0.5, 0.0), (0.0, -0.5))   # lib/loss.py:281-284 (off * g)
+
+
+# ---------------------------------------------------------------------------------------------- anchors
+def make_anchors(model_config, mode):
+    """model/yolo.py:54-72 — anchors in grid units; kfiou appends the anchor angle (rad), size-major."""
+    out = []
+    for stride, flat in zip(STRIDES, model_config["anchors"]):
+        row = []
+        for k in range(0, len(flat), 2):
+            w, h = flat[k] / stride, flat[k + 1] / stride
+            if mode == "csl":
+                row.append([w, h])
+            else:
+                for deg in model_config["angles"]:
+                    row.append([w, h, deg * np.pi / 180])
+        out.append(row)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- small utils
+def norm_angle(theta):
+    """lib/general.py:7-20 (assert dropped: it is a device sync, the clamp logic is the contract)."""
+    theta = torch.where(theta >= PI / 2, theta - PI, theta)
+    theta = torch.where(theta < -PI / 2, theta + PI, theta)
+    return theta
+
+
+def bbox_ciou(p, t):
+    """lib/loss.py:36-78.  p,t: [n,4] xywh.  alpha carries no gradient."""
+    px, py, pw, ph = p.unbind(-1)
+    tx, ty, tw, th = t.unbind(-1)
+    pl, pr, pt_, pb = px - pw / 2, px + pw / 2, py - ph / 2, py + ph / 2
+    tl, tr, tt, tb = tx - tw / 2, tx + tw / 2, ty - th / 2, ty + th / 2
+    iw = (torch.min(pr, tr) - torch.max(pl, tl)).clamp(min=0)
+    ih = (torch.min(pb, tb) - torch.max(pt_, tt)).clamp(min=0)
+    inter = iw * ih
+    ow = (torch.max(pr, tr) - torch.min(pl, tl)).clamp(min=0)
+    oh = (torch.max(pb, tb) - torch.min(pt_, tt)).clamp(min=0)
+    c2 = ow ** 2 + oh ** 2
+    d2 = (tx - px) ** 2 + (ty - py) ** 2
+    union = pw * ph + tw * th - inter
+    u = d2 / (c2 + 1e-15)
+    iou = inter / (union + 1e-15)
+    v = (4 / (PI ** 2)) * torch.pow(torch.atan(tw / th) - torch.atan(pw / ph), 2)
+    with torch.no_grad():
+        alpha = v / ((1 - iou) + v)
+    return torch.clamp(iou - (u + alpha * v), min=-1.0, max=1.0)
+
+
+def kf_loss(pred, target, alpha=3.0):
+    """lib/loss.py:100-150 with fun='exp' (+ lib/general.py:107-133 for Sigma).
+
+    Returns (loss scalar, KFIoU[n]).  The reference's [n,1]+[n] -> [n,n] broadcast mean equals
+    mean(xy_loss)+mean(kf_loss) (both terms >= 0 so clamp(0) is inert) — SURVEY.md §8a row L6; the closed form
+    of the 2x2 inverse replaces torch.inverse."""
+    wh_p = pred[:, 2:4].clamp(min=1e-4, max=1e4)
+    wh_t = target[:, 2:4].clamp(min=1e-4, max=1e4)
+    r_p, r_t = pred[:, 4], target[:, 4]
+    # Sigma_t = R diag((w/2)^2,(h/2)^2) R^T ; R = [[c,-s],[s,c]]
+    c, s = torch.cos(r_t), torch.sin(r_t)
+    a2, b2 = (0.5 * wh_t[:, 0]) ** 2, (0.5 * wh_t[:, 1]) ** 2
+    s00 = c * c * a2 + s * s * b2
+    s01 = c * s * (a2 - b2)
+    s11 = s * s * a2 + c * c * b2
+    det = s00 * s11 - s01 * s01
+    dx, dy = pred[:, 0] - target[:, 0], pred[:, 1] - target[:, 1]
+    maha = (dx * dx * s11 - 2 * dx * dy * s01 + dy * dy * s00) / det
+    xy_loss = torch.log(maha + 1)
+    wp2, hp2 = wh_p[:, 0] ** 2, wh_p[:, 1] ** 2
+    wt2, ht2 = wh_t[:, 0] ** 2, wh_t[:, 1] ** 2
+    cos2, sin2 = torch.cos(r_p - r_t) ** 2, torch.sin(r_p - r_t) ** 2
+    A = torch.sqrt(1 + (wp2 * hp2) / (wt2 * ht2) + (wp2 / wt2 + hp2 / ht2) * cos2 + (wp2 / ht2 + hp2 / wt2) * sin2)
+    B = torch.sqrt(1 + (wt2 * ht2) / (wp2 * hp2) + (wt2 / wp2 + ht2 / hp2) * cos2 + (wt2 / hp2 + ht2 / wp2) * sin2)
+    kfiou = (4 - alpha) / (A + B - alpha)
+    kf = torch.exp(1 - kfiou) - 1
+    return xy_loss.clamp(0).mean() + kf.clamp(0).mean(), kfiou
+
+
+# ---------------------------------------------------------------------------------------------- decode
+def decode(head_maps, anchors, nc, mode):
+    """model/yololayer.py:15-56 (csl) / :66-105 (kfiou).
+
+    head_maps: 3 x [B, na*attrs, gs, gs] (raw conv output, NCHW).  Returns (train_out list of [B,na,gs,gs,attrs],
+    infer_out [B, sum na*gs^2, nc+6])."""
+    outs, infer = [], []
+    for i, x in enumerate(head_maps):
+        B, _, gs, _ = x.shape
+        an = torch.tensor(anchors[i], dtype=torch.float32)
+        na = an.shape[0]
+        attrs = nc + (185 if mode == "csl" else 6)
+        t = x.reshape(B, na, attrs, gs, gs).permute(0, 1, 3, 4, 2).contiguous()
+        outs.append(t)
+        y = torch.sigmoid(t)
+        col = torch.arange(gs, dtype=torch.float32).view(1, 1, 1, gs)
+        row = torch.arange(gs, dtype=torch.float32).view(1, 1, gs, 1)
+        stride = STRIDES[i]
+        bx = (y[..., 0] * 2 - 0.5 + col) * stride
+        by = (y[..., 1] * 2 - 0.5 + row) * stride
+        bw = (y[..., 2] * 2) ** 2 * an[:, 0].view(1, na, 1, 1) * stride
+        bh = (y[..., 3] * 2) ** 2 * an[:, 1].view(1, na, 1, 1) * stride
+        if mode == "csl":
+            conf, cls = y[..., 4], y[..., 5:5 + nc]
+            bins = y[..., 5 + nc:]
+            first_max = torch.argmax((bins == bins.max(-1, keepdim=True)[0]).to(torch.uint8), dim=-1)
+            ang = (first_max.float() - 90) / 180 * np.pi
+        else:
+            ang = (y[..., 4] - 0.5) * 0.5236 + an[:, 2].view(1, na, 1, 1)
+            conf, cls = y[..., 5], y[..., 6:]
+        rows = torch.cat([torch.stack((bx, by, bw, bh, ang, conf), -1), cls], -1)
+        infer.append(rows.reshape(B, -1, nc + 6))
+    return outs, torch.cat(infer, 1)
+
+
+# ---------------------------------------------------------------------------------------------- targets
+def build_targets(shapes, targets, anchors, mode):
+    """lib/loss.py:270-331 (csl) / :427-492 (kfiou).
+
+    shapes: list of (gs_y, gs_x) per scale; targets [nt, 7|187] = (img, cls, x, y, w, h, theta[, csl x180]),
+    xywh normalised.  Returns per scale a dict with int64 b,a,gj,gi,c and float tbox ([n,4] csl / [n,5] kfiou),
+    tidx (row of `targets` each match came from) and anch [n,2|3]."""
+    nt = targets.shape[0]
+    res = []
+    for i, (gy, gx) in enumerate(shapes):
+        an = torch.tensor(anchors[i], dtype=torch.float32)
+        na = an.shape[0]
+        if nt == 0:
+            # lib/loss.py:311-313: t = targets[0] -> empty
+            z = torch.zeros(0, dtype=torch.int64)
+            res.append(dict(b=z, a=z, gj=z, gi=z, c=z, tidx=z, tbox=torch.zeros(0, 4 if mode == "csl" else 5),
+                            anch=an[z]))
+            continue
+        # long-typed gain: x,w scale by grid width, y,h by grid height (lib/loss.py:274,289)
+        gxy = targets[:, 2:4] * torch.tensor([gx, gy], dtype=torch.float32)
+        gwh = targets[:, 4:6] * torch.tensor([gx, gy], dtype=torch.float32)
+        r = gwh[None, :, :] / an[:, None, :2]                                  # [na, nt, 2]
+        ok = torch.max(r, 1.0 / r).max(2)[0] < 4.0                              # lib/loss.py:297-298
+        if mode == "kfiou":
+            d = torch.abs(torch.cos(targets[None, :, 6] - an[:, None, 2]))      # lib/loss.py:458-461
+            ok = ok & (d > 0.866)
+        a_idx, t_idx = ok.nonzero(as_tuple=True)                               # anchor-major, target-minor order
+        mxy = gxy[t_idx]
+        inv = torch.tensor([gx, gy], dtype=torch.float32) - mxy
+        near_lo = (torch.remainder(mxy, 1.0) < 0.5) & (mxy > 1.0)              # j,k   lib/loss.py:306
+        near_hi = (torch.remainder(inv, 1.0) < 0.5) & (inv > 1.0)              # l,m   lib/loss.py:307
+        sel = torch.stack((torch.ones_like(near_lo[:, 0]), near_lo[:, 0], near_lo[:, 1], near_hi[:, 0], near_hi[:, 1]))
+        o_idx, m_idx = sel.nonzero(as_tuple=True)                              # offset-major order
+        a_f, t_f = a_idx[m_idx], t_idx[m_idx]
+        off = torch.tensor(OFFSETS, dtype=torch.float32)[o_idx]
+        fxy = gxy[t_f]
+        gij = (fxy - off).long()                                               # trunc toward zero, lib/loss.py:319
+        gi = gij[:, 0].clamp(0, gx - 1)
+        gj = gij[:, 1].clamp(0, gy - 1)
+        # gi/gj are views of gij and clamp_ is in place (lib/loss.py:320,324) -> tbox sees the CLAMPED cell
+        box = [fxy - torch.stack((gi, gj), 1).float(), gwh[t_f]]               # lib/loss.py:325
+        if mode == "kfiou":
+            box.append(targets[t_f, 6:7])
+        res.append(dict(b=targets[t_f, 0].long(), a=a_f, gj=gj, gi=gi, c=targets[t_f, 1].long(), tidx=t_f,
+                        tbox=torch.cat(box, 1), anch=an[a_f]))
+    return res
+
+
+def _bce_mean(logits, target):
+    return F.binary_cross_entropy_with_logits(logits, target, reduction="mean")
+
+
+def compute_loss(outputs, targets, anchors, nc, mode, hyp):
+    """ComputeCSLLoss.__call__ lib/loss.py:191-268 / ComputeKFIoULoss.__call__ lib/loss.py:368-425.
+
+    outputs: list of 3 [B,na,gs,gs,attrs] (may require grad).  Returns (loss[1], dict of 0-d tensors)."""
+    reg = torch.zeros(1)
+    conf = torch.zeros(1)
+    cls = torch.zeros(1)
+    theta = torch.zeros(1)
+    tg = build_targets([(o.shape[2], o.shape[3]) for o in outputs], targets, anchors, mode)
+    obj_ch = 4 if mode == "csl" else 5
+    for i, pi in enumerate(outputs):
+        m = tg[i]
+        tconf = torch.zeros(pi.shape[:4])
+        n = m["b"].shape[0]
+        if targets.shape[0] > 0 and n > 0:
+            ps = pi[m["b"], m["a"], m["gj"], m["gi"]]
+            pxy = ps[:, 0:2].sigmoid() * 2 - 0.5
+            pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * m["anch"][:, :2]
+            if mode == "csl":
+                iou = bbox_ciou(torch.cat((pxy, pwh), -1), m["tbox"])
+                reg = reg + (1.0 - iou).mean()
+                score = iou.detach().clamp(0)
+                c0 = 5
+            else:
+                pa = norm_angle((ps[:, 4:5].sigmoid() - 0.5) * 1.1 + m["anch"][:, 2:])   # lib/loss.py:390
+                l, kfiou = kf_loss(torch.cat((pxy, pwh, pa), -1), m["tbox"])
+                reg = reg + l
+                score = kfiou.detach().clamp(0)
+                c0 = 6
+            # last writer wins on duplicate cells (sequential loop == CPU index_put_ order)
+            flat = ((m["b"] * pi.shape[1] + m["a"]) * pi.shape[2] + m["gj"]) * pi.shape[3] + m["gi"]
+            tc = tconf.view(-1)
+            for k in range(n):
+                tc[flat[k]] = score[k]
+            if nc > 1:
+                onehot = torch.zeros(n, nc)
+                onehot[torch.arange(n), m["c"]] = 1
+                cls = cls + _bce_mean(ps[:, c0:c0 + nc], onehot)
+            if mode == "csl":
+                theta = theta + _bce_mean(ps[:, 5 + nc:], targets[m["tidx"], 7:187])
+        conf = conf + _bce_mean(pi[..., obj_ch], tconf)
+    reg = hyp["box"] * reg
+    conf = hyp["obj"] * conf
+    cls = hyp["cls"] * cls
+    items = {"reg_loss": reg, "conf_loss": conf, "cls_loss": cls}
+    loss = reg + conf + cls
+    if mode == "csl":
+        theta = 0.5 * theta                                                        # lambda_theta lib/loss.py:160
+        items["theta_loss"] = theta
+        loss = loss + theta
+    items["total_loss"] = loss
+    return loss, items
+
+
+# ---------------------------------------------------------------------------------------------- post_process
+def post_process_pre_nms(image_pred, conf_thres, max_nms=5000, max_wh=4096):
+    """lib/general.py:153-175 for ONE image (mutates image_pred[:, 6:] in place like the reference).
+    Returns (dets[n,7], rboxes[n,5] deg with class offset, order = candidate indices) — score desc, ties by index."""
+    image_pred[:, 6:] *= image_pred[:, 5:6]
+    cconf, cpred = image_pred[:, 6:].max(1)
+    idx = (cconf > conf_thres).nonzero(as_tuple=True)[0]
+    sc = cconf[idx]
+    order = torch.sort(sc, descending=True, stable=True)[1][:max_nms]
+    idx = idx[order]
+    dets = torch.cat((image_pred[idx, :5], cconf[idx, None], cpred[idx, None].float()), 1)
+    rb = dets[:, :5].clone()
+    rb[:, :2] = rb[:, :2] + dets[:, 6:7] * max_wh
+    rb[:, 4] = rb[:, 4] / np.pi * 180
+    return dets, rb, idx
+
+
+def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True, max_det=1500):
+    """lib/general.py:136-183; nms_rotated = the C oracle (CUDA '>' semantics by default)."""
+    outs = []
+    for b in range(predictions.shape[0]):
+        dets, rb, _ = post_process_pre_nms(predictions[b], conf_thres)
+        if dets.shape[0] == 0:
+            outs.append(torch.zeros((0, 7)))
+            continue
+        keep = _c_nms_rotated(rb.numpy(), dets[:, 5].numpy(), iou_thres, gt_only)[:max_det]
+        outs.append(dets[torch.from_numpy(keep)])
+    return outs
+
+
+def gaussian_label(angle_deg_plus90, num_class=180, u=0, sig=6.0):
+    """datasets/base_dataset.py:13-31 (int() truncation toward zero kept)."""
+    x = np.arange(-num_class / 2, num_class / 2)
+    y = np.exp(-(x - u) ** 2 / (2 * sig ** 2))
+    k = int(num_class / 2 - angle_deg_plus90)
+    return np.concatenate([y[k:], y[:k]], axis=0)
