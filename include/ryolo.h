@@ -1,0 +1,92 @@
+/*
+ * ryolo.h — C ABI of libryolo_hip.so (MI355X / gfx950 hot path of yingkunwu/R-YOLOv4).
+ *
+ * The reference has no C ABI of its own: its boundary is three Python call surfaces plus one torch-op schema
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces (paths in /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - plain C, raw DEVICE pointers + explicit sizes, a hipStream_t; no torch types;
+ *   - returns 0 on success, RY_ERR_* otherwise; never throws, never allocates, never synchronises:
+ *     all outputs and workspaces are caller-allocated (query *_workspace_bytes first), so every call is
+ *     hipGraph-capturable;
+ *   - re-entrant across streams; the library keeps no mutable global state.
+ */
+#ifndef RYOLO_H
+#define RYOLO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ryolo_stream_t;   /* == hipStream_t */
+
+#define RYOLO_OK 0
+#define RYOLO_ERR_ARG 1
+#define RYOLO_ERR_WORKSPACE 2
+#define RYOLO_ERR_LAUNCH 3
+#define RYOLO_ERR_UNSUPPORTED 4
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Rotated NMS / SkewIoU — replaces torch.ops.detectron2.nms_rotated / box_iou_rotated
+ * (detectron2 is un-vendored; call sites lib/general.py:177, test.py:135, dead code lib/loss.py:241).
+ * Boxes are (xc, yc, w, h, angle_degrees), float32.
+ * ------------------------------------------------------------------------------------------------------------ */
+int ryolo_nms_workspace_bytes(int batch, int64_t nmax, size_t* bytes);
+
+/* boxes [batch, nmax, 5] already sorted by score descending (lib/general.py:166-168);
+ * counts [batch] (device, may be NULL = all nmax valid); gt_only=1: suppress iff IoU > thr (detectron2 CUDA kernel),
+ * 0: IoU >= thr (detectron2 CPU kernel); keep [batch, keep_stride] receives POSITIONS in the sorted order, ascending;
+ * at most max_keep (<=0: no cap) are produced (lib/general.py:178-179 keeps max_det=1500); num_keep [batch] (device). */
+int ryolo_nms_rotated_batched(const float* boxes, const int32_t* counts, int batch, int64_t nmax, float iou_thr,
+                              int gt_only, int64_t max_keep, void* workspace, size_t workspace_bytes, int64_t* keep,
+                              int64_t keep_stride, int32_t* num_keep, ryolo_stream_t stream);
+
+/* IoU[n, m] row-major = pairwise_iou_rotated(b1[n,5], b2[m,5]) (test.py:135).
+ * workspace >= align256(n*48) + m*48 bytes. */
+int ryolo_box_iou_rotated(const float* b1, int n, const float* b2, int m, void* workspace, size_t workspace_bytes,
+                          float* out, ryolo_stream_t stream);
+
+/* out[i] = IoU(b1[i], b2[i]) — the element-wise SkewIoU score of the commented-out block lib/loss.py:233-245. */
+int ryolo_diag_iou_rotated(const float* b1, const float* b2, int n, float* out, ryolo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * YoloLayer — replaces model/yololayer.py:15-56 (YoloCSLLayer.forward) and :66-105 (YoloKFIoULayer.forward).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* in [batch, na*attrs, gs, gs] (NCHW conv output) -> out [batch, na, gs, gs, attrs]
+ * == out[i].view(bs,na,attrs,gs,gs).permute(0,1,3,4,2).contiguous()  (model/yololayer.py:25, :76).
+ * (The conv stack of this library emits that layout directly from the head-conv epilogue.) */
+int ryolo_head_permute(const float* in, float* out, int batch, int na, int attrs, int gs, ryolo_stream_t stream);
+
+/* Eval-time decode of ONE scale into its row slice of infer_out [batch, rows_per_image, nc+6]:
+ * mode 0 = csl  (attrs = nc+185: x,y,w,h,obj,cls[nc],theta[180]; first-max argmax, model/yololayer.py:28-54),
+ * mode 1 = kfiou(attrs = nc+6  : x,y,w,h,a,obj,cls[nc]; angle scale 0.5236, no norm_angle, :79-103).
+ * head [batch, na, gs, gs, attrs]; anchors_host = HOST pointer to na*3 floats (w, h, angle_rad; csl ignores angle),
+ * grid units (model/yolo.py:54-72); rows of this scale start at row_offset (scale order 8 -> 16 -> 32). */
+int ryolo_decode(int mode, const float* head, float* infer_out, int batch, int na, int gs, int nc, float stride,
+                 const float* anchors_host, int64_t row_offset, int64_t rows_per_image, ryolo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * post_process stages — replace the per-image loop of lib/general.py:153-181.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* pred [batch, M, nc+6] is MUTATED: cls *= obj (lib/general.py:155).  key[b,i] = max_k cls (first max) if it is
+ * > conf_thres (strict, :161) else -inf; cls[b,i] = argmax as float; count[b] = number of passing candidates. */
+int ryolo_pp_score(float* pred, int batch, int64_t M, int nc, float conf_thres, float* key, float* cls,
+                   int32_t* count, ryolo_stream_t stream);
+
+/* sorted_key/order = stable descending sort of key along M.  Writes the top-K rows: dets [batch,K,7] =
+ * (x,y,w,h,theta_rad,score,cls) and rboxes [batch,K,5] = NMS boxes with class offset cls*max_wh on x,y and theta in
+ * degrees (lib/general.py:166-174); count[b] is clamped to K. */
+int ryolo_pp_gather(const float* pred, const float* sorted_key, const int64_t* order, const float* cls, int batch,
+                    int64_t M, int nc, int64_t K, float max_wh, float* dets, float* rboxes, int32_t* count,
+                    ryolo_stream_t stream);
+
+/* out [batch, keep_stride, 7]: out[b,j] = dets[b, keep[b,j]] for j < num_keep[b], zeros after (lib/general.py:181). */
+int ryolo_pp_emit(const float* dets, const int64_t* keep, const int32_t* num_keep, int batch, int64_t K,
+                  int64_t keep_stride, float* out, ryolo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RYOLO_H */

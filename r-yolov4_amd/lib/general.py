@@ -1,0 +1,143 @@
+"""Drop-in for the reference's lib/general.py hot-path functions, on MI355X HIP kernels.
+
+Same names / arguments / return types as /root/reference/lib/general.py:
+    post_process(predictions, conf_thres=0.5, iou_thres=0.4) -> list[Tensor[n_i, 7]]      (lib/general.py:136-183)
+    norm_angle(theta), xywh2xyxy(x), xywhr2xywhrsigma(xywhr)                               (lib/general.py:7-133)
+plus the two detectron2 ops the reference imports (lib/general.py:4, test.py:7):
+    nms_rotated(boxes[N,5] deg, scores[N], iou_threshold) -> int64 keep indices
+    pairwise_iou_rotated(boxes1[N,5], boxes2[M,5]) -> [N, M]
+Out of scope here (CPU/cv2 dataset-side helpers): xywha2xyxyxyxy, xyxyxyxy2xywha.
+"""
+import numpy as np
+import torch
+
+from .. import hip
+
+MAX_WH = 4096.0      # lib/general.py:147
+MAX_NMS = 5000       # lib/general.py:148
+MAX_DET = 1500       # lib/general.py:149
+
+
+# ------------------------------------------------------------------------------------------ small tensor helpers
+def norm_angle(theta):
+    """lib/general.py:7-20.  The reference's range assert is a device->host sync; the two selects below already
+    guarantee the post-condition for any |theta| < 3*pi/2, so it is dropped (SURVEY §8b 'sync points to remove')."""
+    theta = torch.where(theta >= np.pi / 2, theta - np.pi, theta)
+    theta = torch.where(theta < -np.pi / 2, theta + np.pi, theta)
+    return theta
+
+
+def xywh2xyxy(x):
+    """lib/general.py:23-38"""
+    assert isinstance(x, torch.Tensor), "Input should be torch.tensors."
+    half = x[..., 2:4] / 2
+    return torch.cat((x[..., 0:2] - half, x[..., 0:2] + half), -1)
+
+
+def xywhr2xywhrsigma(xywhr):
+    """lib/general.py:107-133 — (xy, wh clamped to [1e-4,1e4], r, Sigma = R diag((wh/2)^2) R^T).
+    API-surface helper only: the KFIoU loss kernel (csrc/loss.hip) computes the closed form in registers."""
+    shape = xywhr.size()
+    assert shape[-1] == 5
+    xy = xywhr[..., :2]
+    wh = xywhr[..., 2:4].clamp(min=1e-4, max=1e4)
+    r = xywhr[..., 4]
+    c, s = torch.cos(r), torch.sin(r)
+    a2, b2 = (0.5 * wh[..., 0]) ** 2, (0.5 * wh[..., 1]) ** 2
+    sigma = torch.stack((c * c * a2 + s * s * b2, c * s * (a2 - b2), c * s * (a2 - b2), s * s * a2 + c * c * b2), -1)
+    return xy, wh, r, sigma.reshape(shape[0], 2, 2)
+
+
+# ------------------------------------------------------------------------------------------ rotated NMS / IoU ops
+def _nms_sorted_batched(rboxes, counts, iou_thres, gt_only, max_keep):
+    """rboxes [B,K,5] score-sorted; counts int32[B] or None.  Returns (keep int64[B,max_keep], num_keep int32[B])."""
+    B, K = rboxes.shape[0], rboxes.shape[1]
+    dev = rboxes.device
+    need = hip._Z()
+    hip.call("ryolo_nms_workspace_bytes", B, K, need)
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    mk = K if max_keep is None else min(max_keep, K)
+    keep = torch.empty((B, max(mk, 1)), dtype=torch.int64, device=dev)
+    num = torch.empty(B, dtype=torch.int32, device=dev)
+    hip.call("ryolo_nms_rotated_batched", hip.ptr(rboxes), hip.ptr(counts), B, K, float(iou_thres), 1 if gt_only else 0, mk,
+             hip.ptr(ws), need.value, hip.ptr(keep), keep.shape[1], hip.ptr(num), hip.stream())
+    return keep, num
+
+
+def nms_rotated(boxes, scores, iou_threshold, gt_only=True):
+    """Drop-in for detectron2.layers.nms.nms_rotated (call site lib/general.py:177).
+    gt_only=True suppresses iff IoU > thr (detectron2's CUDA kernel, what the reference runs on GPU);
+    False gives the `>=` of detectron2's CPU kernel.  Ties in `scores` are broken by ascending index."""
+    hip.require_device(boxes, "nms_rotated")
+    if boxes.dim() != 2 or boxes.shape[1] != 5 or scores.shape[0] != boxes.shape[0]:
+        raise RuntimeError("nms_rotated: boxes must be [N,5] and scores [N]")
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    sb = boxes.float()[order].contiguous().unsqueeze(0)
+    keep, num = _nms_sorted_batched(sb, None, iou_threshold, gt_only, None)
+    k = int(num.item())
+    return order[keep[0, :k]]
+
+
+def pairwise_iou_rotated(boxes1, boxes2):
+    """Drop-in for detectron2.layers.rotated_boxes.pairwise_iou_rotated (call site test.py:135)."""
+    hip.require_device(boxes1, "pairwise_iou_rotated")
+    b1 = boxes1.float().contiguous()
+    b2 = boxes2.float().contiguous()
+    n, m = b1.shape[0], b2.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=b1.device)
+    if n and m:
+        wsz = ((n * 48 + 255) // 256) * 256 + m * 48
+        ws = torch.empty(wsz, dtype=torch.uint8, device=b1.device)
+        hip.call("ryolo_box_iou_rotated", hip.ptr(b1), n, hip.ptr(b2), m, hip.ptr(ws), wsz, hip.ptr(out), hip.stream())
+    return out
+
+
+def diag_iou_rotated(boxes1, boxes2):
+    """iou[i] = SkewIoU(boxes1[i], boxes2[i]) — element-wise variant for the loss-side score of lib/loss.py:233-245."""
+    hip.require_device(boxes1, "diag_iou_rotated")
+    b1, b2 = boxes1.float().contiguous(), boxes2.float().contiguous()
+    out = torch.empty(b1.shape[0], dtype=torch.float32, device=b1.device)
+    hip.call("ryolo_diag_iou_rotated", hip.ptr(b1), hip.ptr(b2), b1.shape[0], hip.ptr(out), hip.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ post_process
+def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
+    """lib/general.py:136-183.  predictions [B, M, nc+6] (x,y,w,h,theta_rad,obj,cls...) on the HIP device;
+    predictions[:, :, 6:] is multiplied by the objectness IN PLACE exactly like the reference (:155).
+    Returns a list of B tensors [n_i, 7] = (x, y, w, h, theta_rad, score, class)."""
+    hip.require_device(predictions, "post_process")
+    if predictions.dim() != 3 or predictions.shape[2] < 6:
+        raise RuntimeError("post_process: predictions must be [B, M, nc+6]")
+    if predictions.dtype != torch.float32 or not predictions.is_contiguous():
+        raise RuntimeError("post_process: predictions must be contiguous float32")
+    B, M, A = predictions.shape
+    nc = A - 6
+    dev = predictions.device
+    empty = torch.zeros((0, 7), device=dev)
+    if B == 0:
+        return []
+    if M == 0 or nc == 0:
+        return [empty] * B
+    st = hip.stream()
+    key = torch.empty((B, M), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, M), dtype=torch.float32, device=dev)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
+    hip.call("ryolo_pp_score", hip.ptr(predictions), B, M, nc, float(conf_thres), hip.ptr(key), hip.ptr(cls), hip.ptr(count), st)
+    # Stable descending sort of the candidate scores (ties: ascending candidate index — the reference's
+    # argsort(descending=True) at lib/general.py:166 leaves tie order undefined; SURVEY §7 fixes it).
+    skey, order = torch.sort(key, dim=1, descending=True, stable=True)
+    K = min(M, MAX_NMS)
+    dets = torch.empty((B, K, 7), dtype=torch.float32, device=dev)
+    rboxes = torch.empty((B, K, 5), dtype=torch.float32, device=dev)
+    hip.call("ryolo_pp_gather", hip.ptr(predictions), hip.ptr(skey), hip.ptr(order), hip.ptr(cls), B, M, nc, K, MAX_WH,
+             hip.ptr(dets), hip.ptr(rboxes), hip.ptr(count), st)
+    keep, num = _nms_sorted_batched(rboxes, count, iou_thres, gt_only, MAX_DET)
+    ks = keep.shape[1]
+    out = torch.empty((B, ks, 7), dtype=torch.float32, device=dev)
+    hip.call("ryolo_pp_emit", hip.ptr(dets), hip.ptr(keep), hip.ptr(num), B, K, ks, hip.ptr(out), st)
+    n_host = num.cpu().tolist()          # the single device->host read of the whole batch
+    return [out[b, :n] if n > 0 else empty for b, n in enumerate(n_host)]

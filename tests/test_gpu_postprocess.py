@@ -1,0 +1,122 @@
+"""GPU parity tests (through the C ABI): rotated NMS / pairwise IoU / decode / post_process vs the oracle and the
+golden fixtures.  Integer outputs (keep indices) are compared bit-exactly; floats to the tolerance written per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ref_ops
+from ryolov4_amd.synth import CFG, synth_nms_boxes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _general():
+    from ryolov4_amd.lib import general
+    return general
+
+
+@pytest.mark.parametrize("dist", ["U", "C"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 5000])
+@pytest.mark.parametrize("thr", [0.65, 0.2])
+def test_nms_keep_set_bit_exact(dist, n, thr):
+    g = _general()
+    b, s = synth_nms_boxes(n, dist, seed=n)
+    perm = np.random.RandomState(0).permutation(n)            # un-sorted input: the op sorts by score itself
+    bb, ss = b[perm], s[perm]
+    for gt in (True, False):
+        got = g.nms_rotated(torch.from_numpy(bb).to(DEV), torch.from_numpy(ss).to(DEV), thr, gt_only=gt).cpu().numpy()
+        exp = oracle.nms_rotated(bb, ss, thr, gt)
+        assert got.dtype == np.int64 and np.array_equal(got, exp), (dist, n, thr, gt, len(got), len(exp))
+
+
+def test_nms_10k_metric_size_and_ties_and_edges():
+    g = _general()
+    b, s = synth_nms_boxes(10000, "C", seed=0)
+    got = g.nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), 0.65).cpu().numpy()
+    assert np.array_equal(got, oracle.nms_rotated(b, s, 0.65))
+    # score ties -> ascending index; identical boxes; zero-area boxes; no-prune path (thr == 0)
+    b2 = b[:300].copy(); s2 = np.full(300, 0.5, np.float32); b2[10] = b2[3]; b2[20, 2] = 0.0
+    for thr, gt in ((0.5, True), (0.0, True), (0.0, False), (1e-7, True)):
+        got = g.nms_rotated(torch.from_numpy(b2).to(DEV), torch.from_numpy(s2).to(DEV), thr, gt_only=gt).cpu().numpy()
+        assert np.array_equal(got, oracle.nms_rotated(b2, s2, thr, gt)), (thr, gt)
+    assert g.nms_rotated(torch.zeros(0, 5, device=DEV), torch.zeros(0, device=DEV), 0.5).shape == (0,)
+
+
+def test_nms_full_size_properties_50k():
+    """size-independent properties at the C5 size (oracle too slow): keep is sorted by score, idempotent, and no two
+    kept boxes overlap above the threshold (checked on a sample through the pairwise kernel)."""
+    g = _general()
+    b, s = synth_nms_boxes(50000, "U", seed=9)
+    tb, ts = torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV)
+    keep = g.nms_rotated(tb, ts, 0.3)
+    ks = ts[keep]
+    assert torch.all(ks[:-1] >= ks[1:])
+    keep2 = g.nms_rotated(tb[keep], ts[keep], 0.3)
+    assert torch.equal(keep2, torch.arange(keep.numel(), device=DEV))                 # idempotent
+    sub = tb[keep[:3000]]
+    iou = g.pairwise_iou_rotated(sub, sub)
+    iou.fill_diagonal_(0)
+    assert float(iou.max()) <= 0.3
+
+
+def test_pairwise_and_diag_iou():
+    g = _general()
+    b, _ = synth_nms_boxes(700, "C", seed=4)
+    b1, b2 = b[:333], b[200:700]
+    got = g.pairwise_iou_rotated(torch.from_numpy(b1).to(DEV), torch.from_numpy(b2).to(DEV)).cpu().numpy()
+    exp = oracle.pairwise_iou_rotated(b1, b2)
+    np.testing.assert_allclose(got, exp, atol=1e-6, rtol=0)                             # tolerance: 1e-6 absolute
+    d = g.diag_iou_rotated(torch.from_numpy(b1).to(DEV), torch.from_numpy(b[100:433]).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(d, np.array([oracle.single_iou(x, y) for x, y in zip(b1, b[100:433])], np.float32), atol=1e-6)
+    assert g.pairwise_iou_rotated(torch.zeros(0, 5, device=DEV), torch.from_numpy(b2).to(DEV)).shape == (0, 500)
+
+
+@pytest.mark.parametrize("mode,nc", [("csl", 2), ("csl", 16), ("kfiou", 2), ("kfiou", 16)])
+def test_decode_golden(golden_dir, mode, nc):
+    from ryolov4_amd.model import yololayer
+    gd = np.load(os.path.join(golden_dir, "g3_decode.npz"))
+    tag = f"{mode}_nc{nc}"
+    logits = [torch.from_numpy(gd[f"{tag}_logits{k}"].astype(np.float32)).to(DEV) for k in range(3)]
+    layer = yololayer.make_layer(mode, nc, ref_ops.make_anchors(CFG, mode), [8, 16, 32])
+    outs, infer = layer([l.clone() for l in logits], False)
+    exp_outs, _ = ref_ops.decode([l.cpu() for l in logits], ref_ops.make_anchors(CFG, mode), nc, mode)
+    for a, b in zip(outs, exp_outs):
+        assert torch.equal(a.cpu(), b)                                                   # permute is exact
+    # tolerance 1e-3 on boxes (north_star); observed ~1e-6 relative (expf ulp differences)
+    np.testing.assert_allclose(infer.cpu().numpy(), gd[f"{tag}_infer"], rtol=2e-5, atol=2e-5)
+    train_only = layer([l.clone() for l in logits], True)
+    assert isinstance(train_only, list) and len(train_only) == 3
+
+
+def test_post_process_golden(golden_dir):
+    g = _general()
+    gd = np.load(os.path.join(golden_dir, "g7_postprocess.npz"))
+    for case in range(4):
+        nc, ct, it = gd[f"c{case}_cfg"]
+        pred = torch.from_numpy(gd[f"c{case}_pred"].copy()).to(DEV)
+        outs = g.post_process(pred, float(ct), float(it))
+        ref_sum = float(gd[f"c{case}_mutated_sum"])
+        assert abs(pred.double().sum().item() - ref_sum) < 1e-6 * abs(ref_sum)            # in-place cls *= obj kept
+        assert len(outs) == pred.shape[0]
+        for b, o in enumerate(outs):
+            exp = gd[f"c{case}_out{b}"]
+            assert tuple(o.shape) == exp.shape, (case, b, o.shape, exp.shape)
+            np.testing.assert_allclose(o.cpu().numpy(), exp, atol=1e-6)                   # same rows, same order
+
+
+def test_post_process_random_vs_oracle_and_empty():
+    g = _general()
+    gen = torch.Generator().manual_seed(5)
+    pred = torch.rand(3, 20000, 22, generator=gen)
+    pred[..., 0:2] *= 500; pred[..., 2] = pred[..., 2] * 40 + 4; pred[..., 3] = pred[..., 2] * 3; pred[..., 4] = (pred[..., 4] - 0.5) * 3.1
+    pred[1, :, 5] = 0.0                                                                    # image 1: nothing passes
+    exp = ref_ops.post_process(pred.clone(), 0.5, 0.3)
+    got = g.post_process(pred.clone().to(DEV), 0.5, 0.3)
+    assert got[1].shape == (0, 7)
+    for a, b in zip(exp, got):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(b.cpu().numpy(), a.numpy(), atol=1e-5)

@@ -1,0 +1,188 @@
+"""CPU tests: pin the C oracle of the un-vendored detectron2 ops (parity unpinned by the reference) with
+(1) the analytic known-answer cases of SURVEY.md §8(c), (2) an independent float64 Sutherland-Hodgman clip,
+(3) structural properties of NMS; and check the PRODUCT's restructured pair function (host build) bit-for-bit."""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from ryolov4_amd.synth import synth_nms_boxes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R2 = math.sqrt(2)
+KNOWN = [
+    ([0.5, 0.5, 1, 1, 0], [0.25, 0.5, 0.5, 1, 0], 0.5),
+    ([565, 565, 10, 10, 0], [565, 565, 10, 8.3, 0], 0.83),
+    ([1, 1, R2, R2, 45], [1, 1, 2, 2, 0], 0.5),
+    ([1, 1, 2 * R2, 2 * R2, -45], [1, 1, 2, 2, 0], 0.5),
+    ([5, 5, 10, 6, 55], [5, 5, 10, 6, -35], 36 / 84),
+    ([3, 3, 8, 2, -45], [6, 0, 8, 2, -45], 0.0),
+    ([160, 153, 230, 23, -37], [190, 127, 80, 21, -46], 0.0),
+    ([299.5, 417.370422, 600, 364.259186, 27.1828], [299.5, 417.370422, 600, 364.259155, 27.1828], 364.259155 / 364.259186),
+    ([0, 0, 1, 1, 0], [0, 0, 1, 1, 45], (2 * R2 - 2) / (4 - 2 * R2)),
+    ([2563.7446, 1436.7902, 2174.7034, 214.095, 115.1183], [2563.7446, 1436.7902, 2174.7034, 214.095, 115.1183], 1.0),
+    ([296.662, 458.7388, 23.5157, 47.677, 0.08795], [296.662, 458.7388, 23.5157, 47.677, 0.08795], 1.0),
+]
+
+
+def _corners(b):
+    x, y, w, h, a = [float(v) for v in b]
+    t = a * math.pi / 180
+    c, s = math.cos(t) / 2, math.sin(t) / 2
+    p0 = (x + s * h + c * w, y + c * h - s * w)
+    p1 = (x - s * h + c * w, y - c * h - s * w)
+    return [p0, p1, (2 * x - p0[0], 2 * y - p0[1]), (2 * x - p1[0], 2 * y - p1[1])]
+
+
+def _area(poly):
+    return 0.5 * abs(sum(poly[i][0] * poly[(i + 1) % len(poly)][1] - poly[(i + 1) % len(poly)][0] * poly[i][1] for i in range(len(poly))))
+
+
+def sh_iou(b1, b2):
+    """independent float64 Sutherland-Hodgman polygon clip"""
+    subj, clip = _corners(b1), _corners(b2)
+    def orient(p):
+        return sum(p[i][0] * p[(i + 1) % 4][1] - p[(i + 1) % 4][0] * p[i][1] for i in range(4))
+    if orient(clip) < 0:
+        clip = clip[::-1]
+    out = subj
+    for i in range(4):
+        a, b = clip[i], clip[(i + 1) % 4]
+        inp, out = out, []
+        if not inp:
+            break
+        def inside(p):
+            return (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]) >= 0
+        def inter(p, q):
+            d1 = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+            d2 = (b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0])
+            t = d1 / (d1 - d2)
+            return (p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1]))
+        for j in range(len(inp)):
+            p, q = inp[j], inp[(j + 1) % len(inp)]
+            if inside(q):
+                if not inside(p):
+                    out.append(inter(p, q))
+                out.append(q)
+            elif inside(p):
+                out.append(inter(p, q))
+    ia = _area(out) if len(out) >= 3 else 0.0
+    a1, a2 = b1[2] * b1[3], b2[2] * b2[3]
+    return ia / (a1 + a2 - ia)
+
+
+@pytest.mark.parametrize("b1,b2,expect", KNOWN)
+def test_known_answers(b1, b2, expect):
+    tol = 1e-3 if expect == 0.0 else 2e-6
+    assert abs(oracle.single_iou(b1, b2) - expect) < tol
+
+
+def test_extreme_magnitudes_finite():
+    v = oracle.single_iou([1e17, 1e17, 10, 10, 3], [1e17, 1e17, 10, 10, 30])
+    assert np.isfinite(v) and v >= 0
+    assert oracle.single_iou([0, 0, 0, 5, 0], [0, 0, 5, 5, 0]) == 0.0        # degenerate area -> 0
+
+
+def test_against_independent_clip():
+    rng = np.random.RandomState(7)
+    worst = 0.0
+    for _ in range(3000):
+        b1 = [rng.uniform(0, 60), rng.uniform(0, 60), rng.uniform(5, 40), rng.uniform(5, 40), rng.uniform(-90, 90)]
+        b2 = [b1[0] + rng.uniform(-25, 25), b1[1] + rng.uniform(-25, 25), rng.uniform(5, 40), rng.uniform(5, 40), rng.uniform(-180, 180)]
+        worst = max(worst, abs(oracle.single_iou(b1, b2) - sh_iou(b1, b2)))
+    assert worst < 2e-4, worst
+
+
+def test_pairwise_matches_single():
+    b, _ = synth_nms_boxes(40, "C", seed=3)
+    m = oracle.pairwise_iou_rotated(b[:17], b[10:40])
+    assert m.shape == (17, 30)
+    assert m[3, 5] == np.float32(oracle.single_iou(b[3], b[15]))
+    assert oracle.pairwise_iou_rotated(np.zeros((0, 5)), b).shape == (0, 40)
+
+
+@pytest.mark.parametrize("rot", [0.0, 180.0, -180.0])
+def test_axis_aligned_rotations_keep_same_set(rot):
+    rng = np.random.RandomState(11)
+    n = 300
+    xy = rng.uniform(0, 100, (n, 2)); wh = rng.uniform(5, 30, (n, 2))
+    sc = rng.permutation(np.linspace(0.01, 0.99, n)).astype(np.float32)
+    base = np.concatenate([xy, wh, np.zeros((n, 1))], 1).astype(np.float32)
+    k0 = oracle.nms_rotated(base, sc, 0.3)
+    rotd = base.copy(); rotd[:, 4] = rot
+    assert np.array_equal(k0, oracle.nms_rotated(rotd, sc, 0.3))
+    swapped = base.copy(); swapped[:, [2, 3]] = base[:, [3, 2]]; swapped[:, 4] = 90.0       # 90 deg with w<->h
+    assert np.array_equal(k0, oracle.nms_rotated(swapped, sc, 0.3))
+
+
+def test_lazy_greedy_equals_mask_reduce():
+    for dist in ("U", "C"):
+        b, s = synth_nms_boxes(500, dist, seed=5)
+        for thr in (0.65, 0.2):
+            for gt in (True, False):
+                keep = oracle.nms_rotated(b, s, thr, gt)
+                mask = oracle.nms_mask(b, thr, gt)
+                remv = np.zeros(mask.shape[1], dtype=np.uint64)
+                k2 = []
+                for i in range(len(b)):
+                    if not (int(remv[i >> 6]) >> (i & 63)) & 1:
+                        k2.append(i)
+                        remv |= mask[i]
+                assert np.array_equal(keep, np.array(k2))
+
+
+def test_empty_and_single():
+    assert oracle.nms_rotated(np.zeros((0, 5)), np.zeros(0), 0.5).shape == (0,)
+    assert list(oracle.nms_rotated([[1, 1, 2, 2, 10]], [0.3], 0.5)) == [0]
+    # identical boxes: thr below 1 suppresses with '>', thr == 1.0 keeps with '>' and suppresses with '>='
+    two = np.array([[5, 5, 4, 2, 30], [5, 5, 4, 2, 30]], np.float32)
+    assert list(oracle.nms_rotated(two, [0.9, 0.8], 0.5)) == [0]
+    v = oracle.single_iou(two[0], two[1])          # ~1.0 (float rounding may land a hair above)
+    assert abs(v - 1.0) < 1e-6
+    assert list(oracle.nms_rotated(two, [0.9, 0.8], v, gt_only=True)) == [0, 1]
+    assert list(oracle.nms_rotated(two, [0.9, 0.8], v, gt_only=False)) == [0]
+    # score ties: lower index first
+    assert list(oracle.nms_rotated(two + np.array([[0, 0, 0, 0, 0], [100, 0, 0, 0, 0]], np.float32), [0.5, 0.5], 0.5)) == [0, 1]
+
+
+@pytest.fixture(scope="module")
+def host_iou():
+    so = os.path.join(ROOT, "tests", "_build", "host_iou.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
+                           os.path.join(ROOT, "tests", "host_iou_shim.cpp")])
+    L = ctypes.CDLL(so)
+    L.host_pair_iou.restype = ctypes.c_float
+    L.host_pair_iou.argtypes = [ctypes.POINTER(ctypes.c_float)] * 2
+    L.host_far_apart.restype = ctypes.c_int
+    L.host_far_apart.argtypes = [ctypes.POINTER(ctypes.c_float)] * 2
+    return L
+
+
+def test_product_pair_function_bit_exact_on_host(host_iou):
+    """r-yolov4_amd/csrc/rotated_iou.h compiled for the host == oracle, bit for bit, incl. the prune predicate's safety."""
+    fp = ctypes.POINTER(ctypes.c_float)
+    for dist, seed in (("U", 1), ("C", 2)):
+        b, _ = synth_nms_boxes(400, dist, seed=seed)
+        rng = np.random.RandomState(seed)
+        for _ in range(20000):
+            i, j = rng.randint(0, 400, 2)
+            if dist == "U" and rng.rand() < 0.7:      # force near pairs
+                j = i
+                bj = b[i].copy(); bj[:2] += rng.uniform(-30, 30, 2); bj[4] += rng.uniform(-60, 60)
+            else:
+                bj = b[j].copy()
+            bi = np.ascontiguousarray(b[i]); bj = np.ascontiguousarray(bj.astype(np.float32))
+            ref = np.float32(oracle.single_iou(bi, bj))
+            got = np.float32(host_iou.host_pair_iou(bi.ctypes.data_as(fp), bj.ctypes.data_as(fp)))
+            assert ref.tobytes() == got.tobytes(), (bi, bj, ref, got)
+            if host_iou.host_far_apart(bi.ctypes.data_as(fp), bj.ctypes.data_as(fp)):
+                assert ref < 1e-6
+    for b1, b2, _ in KNOWN:
+        a1 = np.array(b1, np.float32); a2 = np.array(b2, np.float32)
+        assert np.float32(oracle.single_iou(a1, a2)).tobytes() == np.float32(
+            host_iou.host_pair_iou(a1.ctypes.data_as(fp), a2.ctypes.data_as(fp))).tobytes()
