@@ -15,6 +15,7 @@
 #define RYOLO_H
 #include <stddef.h>
 #include <stdint.h>
+#include "ryolo_params.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -85,6 +86,64 @@ int ryolo_pp_gather(const float* pred, const float* sorted_key, const int64_t* o
 /* out [batch, keep_stride, 7]: out[b,j] = dets[b, keep[b,j]] for j < num_keep[b], zeros after (lib/general.py:181). */
 int ryolo_pp_emit(const float* dets, const int64_t* keep, const int32_t* num_keep, int batch, int64_t K,
                   int64_t keep_stride, float* out, ryolo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Conv stack — replaces every nn.Conv2d / nn.BatchNorm2d / activation / MaxPool2d / Upsample / torch.cat of
+ * model/utils.py:6-282, model/backbone.py, model/neck.py (cuDNN/ATen under the reference).  Activations are NHWC
+ * bf16 with an explicit channel stride; parameter blocks are defined in ryolo_params.h.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* implicit-GEMM convolution: forward (taps = kernel window), data gradient (mirrored taps, stride-2 as 4 parity
+ * classes on grid.z).  Epilogues (p->epi): 0 raw bf16, 1 raw + per-tile BatchNorm partial sums, 2 folded-BN + activation,
+ * 3 fp32 + bias (detection heads), 4 bf16 accumulate (tensor with several consumers). */
+int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
+/* number of [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem */
+int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int* rows);
+/* weight gradient, split-K over output pixels, fp32 atomics into the torch-layout .grad [Cout][Cin][kh*kw] */
+int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
+
+/* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] -> coeffs [4][C] =
+ * mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean/var updated in place (unbiased var). */
+int ryolo_bn_finalize(const float* partial, int rows, int C, double count, float eps, float momentum, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float* coeffs, ryolo_stream_t stream);
+/* eval BatchNorm2d: coeffs from the running statistics */
+int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                         int C, float* coeffs, ryolo_stream_t stream);
+/* z = act(bn1(y1) [+ bn2(y2)]) [+ residual]   (Conv / RepConv / Bottleneck of model/utils.py) */
+int ryolo_bn_act_fwd(const BnActParams* p, ryolo_stream_t stream);
+int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_per_block);
+/* backward of the above: dy1 [, dy2] [, dres], dgamma/dbeta accumulated; p->partial needs nblk*K*C floats, bco 3*C */
+int ryolo_bn_act_bwd(const BnActParams* p, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
+                     ryolo_stream_t stream);
+
+int ryolo_maxpool_fwd(const PoolParams* p, ryolo_stream_t stream);      /* nn.MaxPool2d k2 s2 / k5,9,13 s1 (utils.py:152,231-233) */
+int ryolo_maxpool_bwd(const PoolParams* p, ryolo_stream_t stream);
+int ryolo_upsample2x_fwd(const UpParams* p, ryolo_stream_t stream);     /* nn.Upsample(scale_factor=2) nearest (neck.py) */
+int ryolo_upsample2x_bwd(const UpParams* p, ryolo_stream_t stream);
+/* first layer (Cin = 3): fp32 NCHW image -> bf16 [NB*OH*OW][Kpad] patches, k = (r*kw + s)*Cin + c */
+int ryolo_im2col(const float* img, int NB, int Cin, int H, int W, int kh, int kw, int stride, int pad, int OH, int OW, int Kpad,
+                 bf16_t* col, ryolo_stream_t stream);
+/* detection head tail: pre [M][ldp] fp32 (conv + bias) [* ImplicitM] -> [B, na, gs, gs, attrs] (yololayer.py:25 fused) */
+int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
+                          ryolo_stream_t stream);
+int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
+                          bf16_t* dpre, int ldd, float* dmul, float* scratch, ryolo_stream_t stream);
+int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
+int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, float* out, float* scratch, ryolo_stream_t stream);
+
+/* fp32 master weights (torch layout) -> bf16 GEMM images, all convolutions in one launch */
+int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t total, ryolo_stream_t stream);
+int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int CinP, float* grad, ryolo_stream_t stream);
+/* torch.optim.SGD(momentum, nesterov=True) of train.py:156 over flat buffers: buf = mu*buf + g; p -= lr*(g + mu*buf) */
+int ryolo_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, ryolo_stream_t stream);
+int ryolo_struct_sizes(int* sizes /* [8] */);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Loss — replaces ComputeCSLLoss.__call__/build_targets (lib/loss.py:191-331) and ComputeKFIoULoss (:368-492),
+ * bbox_ciou (:36-78), KFLoss (:100-150).  Forward + gradient w.r.t. the head maps in one call; items[5] =
+ * reg, conf, cls, theta, total (already scaled by the hyp gains).
+ * ------------------------------------------------------------------------------------------------------------ */
+int ryolo_loss_workspace_bytes(const LossParams* p, size_t* bytes);
+int ryolo_loss(const LossParams* p, ryolo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,83 @@
+/* ryolo_params.h — POD parameter blocks of the libryolo_hip.so C ABI (plain C; mirrored with ctypes in
+ * r-yolov4_amd/engine/structs.py and size-checked at load time through ryolo_struct_sizes()). */
+#ifndef RYOLO_PARAMS_H
+#define RYOLO_PARAMS_H
+#include <stddef.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;          /* raw bfloat16 bits */
+#define RY_MAX_TAPS 9
+#define LOSS_MAX_NA 18
+
+
+typedef struct TapClass {
+    int ntaps;
+    int oh_add, ow_add;                      // full-grid output pixel = (oh*oh_mul + oh_add, ow*ow_mul + ow_add)
+    signed char dh[RY_MAX_TAPS], dw[RY_MAX_TAPS], widx[RY_MAX_TAPS];
+} TapClass;
+
+typedef struct ConvGemmParams {
+    const bf16_t* A; int NB, IH, IW, Cin, ldA;      // gathered operand: [NB, IH, IW, Cin] with channel stride ldA
+    const bf16_t* W; int Nout, wtaps;               // packed weights [Nout][wtaps][Cin]
+    int OH, OW;                                     // iteration grid per image (per class); M = NB*OH*OW
+    int sh, sw;                                     // input coordinate = o*s + d[tap]
+    int oh_mul, ow_mul, OHf, OWf;                   // full output grid (differs from OH/OW only for strided dgrad)
+    int nclasses;
+    TapClass cls[4];
+    int epi;                                        // see EPI_*
+    void* out; int ldC;
+    float* stats;                                   // EPI_STATS: [gridM][2][Nout]
+    const float* scale; const float* shift; int act; // EPI_AFFINE_ACT
+    const float* bias;                              // EPI_F32_BIAS (may be null)
+} ConvGemmParams;
+
+typedef struct WgradParams {
+    const bf16_t* dY; int ldY, Cout, CoutPad;        // [M][CoutPad] readable (zero padded), Cout rows stored
+    const bf16_t* X; int NB, IH, IW, Cin, ldX;        // gathered by tap
+    int OH, OW, sh, sw;
+    int ntaps; signed char dh[RY_MAX_TAPS], dw[RY_MAX_TAPS];
+    float* dW;                                       // torch layout [Cout][Cin][ntaps] fp32, atomically accumulated
+    int splitk; int64_t kchunk;                      // pixels per split (multiple of BK)
+} WgradParams;
+
+typedef struct BnActParams {
+    const bf16_t* y1; int ld1; const float* co1;      // co = [4][C]: mean, invstd, scale, shift
+    const bf16_t* y2; int ld2; const float* co2;      // optional second branch (RepConv rbr_1x1), summed before the activation
+    const bf16_t* res; int ldr;                       // optional residual added AFTER the activation (Bottleneck)
+    bf16_t* z; int ldz;
+    int64_t M; int C; int act;
+    // backward only
+    const bf16_t* dz; int lddz;
+    bf16_t* dy1; int lddy1; bf16_t* dy2; int lddy2;
+    bf16_t* dres; int lddres; int dres_accum;
+    float* partial;                                   // [nblk][K][C], K = 2 (one branch) or 3
+    const float* bco;                                 // backward coefficients [K][C]: mean_g, mean_gx1, mean_gx2
+    int rows_per_block;
+} BnActParams;
+
+typedef struct PoolParams {
+    const bf16_t* x; int ldx; bf16_t* z; int ldz;
+    int NB, H, W, C, k, stride, pad, OH, OW;
+    unsigned char* idx;            // [NB,OH,OW,C] argmax window offset (k>2 only)
+    const bf16_t* dz; int lddz; bf16_t* dx; int lddx; int accum;
+} PoolParams;
+
+typedef struct UpParams { const bf16_t* x; int ldx; bf16_t* z; int ldz; int NB, H, W, C; int accum; } UpParams;
+
+typedef struct PackEntry { const float* src; bf16_t* wf; bf16_t* wd; int Cout, Cin, taps, CinP, CoutP, pad_; int64_t start; } PackEntry;
+
+typedef struct LossParams {
+    int mode;                 // 0 csl, 1 kfiou
+    int nc, na, batch, nt, tcols;
+    const float* targets;     // [nt, tcols]  (img, cls, x, y, w, h, theta[, csl x 180])
+    const float* head[3];     // [B, na, gs, gs, attrs]
+    float* grad[3];           // same shape, d(total_loss)/d(logit); may be null when compute_grad == 0
+    int gs[3];
+    float anchors[3][LOSS_MAX_NA][3];
+    float box, obj, cls, theta_gain, obj_pw, cls_pw;
+    void* ws; size_t ws_bytes;
+    float* items;             // [5] device: reg, conf, cls, theta, total
+    int compute_grad;
+} LossParams;
+
+#endif /* RYOLO_PARAMS_H */

@@ -18,7 +18,7 @@
 static inline int64_t ry_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- bf16 <-> f32 (round-to-nearest-even), device side -------------------------------------------------
-typedef unsigned short bf16_t;
+#include "ryolo_params.h"   // bf16_t + POD parameter blocks
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f)

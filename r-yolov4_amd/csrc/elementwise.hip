@@ -1,0 +1,730 @@
+// Memory-bound layers of the conv stack for gfx950: training/eval BatchNorm + activation
+// (+ RepConv's second branch, + Bottleneck's residual add), their backward, MaxPool (k2 s2; k5/9/13 s1), nearest 2x
+// upsample, the small-Cin im2col front end, head finish (ImplicitM + [B,na,gs,gs,attrs] layout), ImplicitA, the bf16
+// weight repack and the fused Nesterov SGD step.
+// Reference: model/utils.py:6-32 (Conv = conv -> BatchNorm2d(eps 1e-5, momentum .1) -> Mish | LeakyReLU(.1) | SiLU),
+// :35-46 (Bottleneck residual), :146-160 (MaxConv), :163-186 (ImplicitA/M), :189-215 (RepConv), :218-282 (SPP*),
+// model/neck.py (nn.Upsample(scale_factor=2)), train.py:153-158 (SGD momentum .937 nesterov).
+//
+// All activations are NHWC bf16 with a channel stride (`ld`) so outputs land directly in their torch.cat slice.
+// Every kernel moves 16 bytes (8 bf16) per lane per access; per-channel reductions are two-level and deterministic
+// (per-workgroup partial rows, then a finalize kernel accumulating in double) — no float atomics.
+#include "common.h"
+#include "params.h"
+
+enum { ACT_LINEAR = 0, ACT_MISH = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
+
+__device__ __forceinline__ float act_f(float u, int act)
+{
+    if (act == ACT_SILU) return u / (1.f + __expf(-u));
+    if (act == ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
+    if (act == ACT_MISH) {
+        const float sp = u > 20.f ? u : log1pf(__expf(u));
+        return u * tanhf(sp);
+    }
+    return u;
+}
+__device__ __forceinline__ float act_d(float u, int act)
+{
+    if (act == ACT_SILU) { const float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
+    if (act == ACT_LEAKY) return u > 0.f ? 1.f : 0.1f;
+    if (act == ACT_MISH) {
+        const float sp = u > 20.f ? u : log1pf(__expf(u));
+        const float t = tanhf(sp);
+        const float s = 1.f / (1.f + __expf(-u));
+        return t + u * (1.f - t * t) * s;
+    }
+    return 1.f;
+}
+
+struct V8 { float v[8]; };
+__device__ __forceinline__ V8 ld8(const bf16_t* p)
+{
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    V8 o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(r.z << 16); o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const V8& a)
+{
+    uint4 r;
+    r.x = pack_bf2(a.v[0], a.v[1]); r.y = pack_bf2(a.v[2], a.v[3]);
+    r.z = pack_bf2(a.v[4], a.v[5]); r.w = pack_bf2(a.v[6], a.v[7]);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+// partial [rows][2][C] (sum, sumsq of the stored bf16 conv output) -> mean/invstd/scale/shift; running stats update
+// (momentum 0.1, unbiased variance — nn.BatchNorm2d defaults used by model/utils.py:17)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count, float eps,
+                                                           float momentum, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ out /*[4][C]*/)
+{
+    __shared__ double red[2][1024];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;          // 32 channels x 32 row lanes
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = rl; r < rows; r += 32) {
+            s += (double)partial[((int64_t)r * 2 + 0) * C + c];
+            q += (double)partial[((int64_t)r * 2 + 1) * C + c];
+        }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; k++) { s += red[0][k * 32 + cl]; q += red[1][k * 32 + cl]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        out[0 * C + c] = (float)mean;
+        out[1 * C + c] = invstd;
+        out[2 * C + c] = sc;
+        out[3 * C + c] = beta[c] - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                      float* out /*[4][C]*/)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    out[0 * C + c] = rm[c]; out[1 * C + c] = invstd; out[2 * C + c] = sc; out[3 * C + c] = beta[c] - rm[c] * sc;
+}
+
+// ------------------------------------------------------------------------------------------------ BN + act forward
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActParams p)
+{
+    const int c8 = p.C >> 3;
+    const int64_t total = p.M * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / c8;
+        const int c = (int)(i - m * c8) << 3;
+        const V8 a = ld8(p.y1 + m * p.ld1 + c);
+        V8 b, r, o;
+        if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+        if (p.res) r = ld8(p.res + m * p.ldr + c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float u = a.v[k] * p.co1[2 * p.C + c + k] + p.co1[3 * p.C + c + k];
+            if (p.y2) u += b.v[k] * p.co2[2 * p.C + c + k] + p.co2[3 * p.C + c + k];
+            float zv = act_f(u, p.act);
+            if (p.res) zv += r.v[k];
+            o.v[k] = zv;
+        }
+        st8(p.z + m * p.ldz + c, o);
+    }
+}
+
+// backward pass 1: per-channel sums of g = dz*act'(u) and g*xhat (per branch); block = (C/8 or fewer) x row lanes
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParams p)
+{
+    __shared__ float red[3][256][8 + 1];
+    const int c8 = p.C >> 3;
+    const int cols = c8 < 256 ? c8 : 256;              // thread columns per pass
+    const int rl = threadIdx.x / cols, nrl = 256 / cols;
+    const int cl = threadIdx.x - rl * cols;
+    const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t r1 = min(p.M, r0 + p.rows_per_block);
+    const int K = p.y2 ? 3 : 2;
+    for (int cb = 0; cb < c8; cb += cols) {
+        const int cc = cb + cl;
+        float sg[8], sx1[8], sx2[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { sg[k] = 0.f; sx1[k] = 0.f; sx2[k] = 0.f; }
+        if (rl < nrl && cc < c8) {
+            const int c = cc << 3;
+            for (int64_t m = r0 + rl; m < r1; m += nrl) {
+                const V8 d = ld8(p.dz + m * p.lddz + c);
+                const V8 a = ld8(p.y1 + m * p.ld1 + c);
+                V8 b;
+                if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    float u = a.v[k] * p.co1[2 * p.C + c + k] + p.co1[3 * p.C + c + k];
+                    if (p.y2) u += b.v[k] * p.co2[2 * p.C + c + k] + p.co2[3 * p.C + c + k];
+                    const float g = d.v[k] * act_d(u, p.act);
+                    sg[k] += g;
+                    sx1[k] += g * (a.v[k] - p.co1[c + k]) * p.co1[p.C + c + k];
+                    if (p.y2) sx2[k] += g * (b.v[k] - p.co2[c + k]) * p.co2[p.C + c + k];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) { red[0][threadIdx.x][k] = sg[k]; red[1][threadIdx.x][k] = sx1[k]; red[2][threadIdx.x][k] = sx2[k]; }
+        __syncthreads();
+        if (rl == 0 && cc < c8) {
+            for (int q = 0; q < K; q++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    float s = 0.f;
+                    for (int j = 0; j < nrl; j++) s += red[q][j * cols + cl][k];
+                    p.partial[((int64_t)blockIdx.x * K + q) * p.C + (cc << 3) + k] = s;
+                }
+            }
+        }
+    }
+}
+
+// backward finalize: sums over blocks (double) -> coefficients + dgamma/dbeta accumulation
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int K, int C, double count,
+                                                               float* __restrict__ bco /*[K][C]*/, float* __restrict__ dgamma1,
+                                                               float* __restrict__ dbeta1, float* __restrict__ dgamma2,
+                                                               float* __restrict__ dbeta2)
+{
+    __shared__ double red[3][1024];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s[3] = {0.0, 0.0, 0.0};
+    if (c < C)
+        for (int r = rl; r < nblk; r += 32)
+            for (int q = 0; q < K; q++) s[q] += (double)partial[((int64_t)r * K + q) * C + c];
+    for (int q = 0; q < 3; q++) red[q][threadIdx.x] = s[q];
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; k++)
+            for (int q = 0; q < K; q++) s[q] += red[q][k * 32 + cl];
+        bco[0 * C + c] = (float)(s[0] / count);
+        bco[1 * C + c] = (float)(s[1] / count);
+        if (K == 3) bco[2 * C + c] = (float)(s[2] / count);
+        if (dgamma1) { dgamma1[c] += (float)s[1]; dbeta1[c] += (float)s[0]; }
+        if (K == 3 && dgamma2) { dgamma2[c] += (float)s[2]; dbeta2[c] += (float)s[0]; }
+    }
+}
+
+// backward pass 2: dy = scale * (g - mean_g - xhat * mean_gx); residual gradient = dz
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnActParams p)
+{
+    const int c8 = p.C >> 3;
+    const int64_t total = p.M * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / c8;
+        const int c = (int)(i - m * c8) << 3;
+        const V8 d = ld8(p.dz + m * p.lddz + c);
+        const V8 a = ld8(p.y1 + m * p.ld1 + c);
+        V8 b, o1, o2;
+        if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float u = a.v[k] * p.co1[2 * p.C + c + k] + p.co1[3 * p.C + c + k];
+            if (p.y2) u += b.v[k] * p.co2[2 * p.C + c + k] + p.co2[3 * p.C + c + k];
+            const float g = d.v[k] * act_d(u, p.act);
+            const float gm = g - p.bco[c + k];
+            o1.v[k] = p.co1[2 * p.C + c + k] * (gm - (a.v[k] - p.co1[c + k]) * p.co1[p.C + c + k] * p.bco[p.C + c + k]);
+            if (p.y2) o2.v[k] = p.co2[2 * p.C + c + k] * (gm - (b.v[k] - p.co2[c + k]) * p.co2[p.C + c + k] * p.bco[2 * p.C + c + k]);
+        }
+        st8(p.dy1 + m * p.lddy1 + c, o1);
+        if (p.y2) st8(p.dy2 + m * p.lddy2 + c, o2);
+        if (p.dres) {
+            V8 r = d;
+            if (p.dres_accum) {
+                const V8 e = ld8(p.dres + m * p.lddres + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++) r.v[k] += e.v[k];
+            }
+            st8(p.dres + m * p.lddres + c, r);
+        }
+    }
+}
+
+// eval-mode / frozen-statistics backward is not needed: the reference only back-propagates in train() mode.
+
+// ------------------------------------------------------------------------------------------------ pooling / upsample
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolParams p)
+{
+    const int c8 = p.C >> 3;
+    const int64_t total = (int64_t)p.NB * p.OH * p.OW * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / c8;
+        const int c = (int)(i - pix * c8) << 3;
+        const int ow = (int)(pix % p.OW);
+        const int oh = (int)((pix / p.OW) % p.OH);
+        const int n = (int)(pix / ((int64_t)p.OW * p.OH));
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { best[k] = -INFINITY; bi[k] = 0; }
+        for (int dy = 0; dy < p.k; dy++) {
+            const int ih = oh * p.stride - p.pad + dy;
+            if ((unsigned)ih >= (unsigned)p.H) continue;
+            for (int dx = 0; dx < p.k; dx++) {
+                const int iw = ow * p.stride - p.pad + dx;
+                if ((unsigned)iw >= (unsigned)p.W) continue;
+                const V8 v = ld8(p.x + (((int64_t)n * p.H + ih) * p.W + iw) * p.ldx + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (v.v[k] > best[k]) { best[k] = v.v[k]; bi[k] = dy * p.k + dx; }      // strict >: first max wins
+            }
+        }
+        V8 o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.v[k] = best[k];
+        st8(p.z + pix * p.ldz + c, o);
+        if (p.idx) {
+            unsigned long long packed = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) packed |= (unsigned long long)(bi[k] & 0xff) << (8 * k);
+            *reinterpret_cast<unsigned long long*>(p.idx + pix * p.C + c) = packed;
+        }
+    }
+}
+
+// gather-form backward (deterministic, no atomics): every input pixel scans the windows that contain it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p)
+{
+    const int c8 = p.C >> 3;
+    const int64_t total = (int64_t)p.NB * p.H * p.W * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / c8;
+        const int c = (int)(i - pix * c8) << 3;
+        const int w = (int)(pix % p.W);
+        const int h = (int)((pix / p.W) % p.H);
+        const int n = (int)(pix / ((int64_t)p.W * p.H));
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = 0.f;
+        // windows (oh, ow) with oh*stride - pad <= h < oh*stride - pad + k
+        const int oh_lo = max(0, (h + p.pad - p.k + p.stride) / p.stride), oh_hi = min(p.OH - 1, (h + p.pad) / p.stride);
+        const int ow_lo = max(0, (w + p.pad - p.k + p.stride) / p.stride), ow_hi = min(p.OW - 1, (w + p.pad) / p.stride);
+        for (int oh = oh_lo; oh <= oh_hi; oh++)
+            for (int ow = ow_lo; ow <= ow_hi; ow++) {
+                const int want = (h - (oh * p.stride - p.pad)) * p.k + (w - (ow * p.stride - p.pad));
+                const int64_t op = ((int64_t)n * p.OH + oh) * p.OW + ow;
+                const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.idx + op * p.C + c);
+                const V8 g = ld8(p.dz + op * p.lddz + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((int)((packed >> (8 * k)) & 0xff) == want) acc[k] += g.v[k];
+            }
+        V8 o;
+        if (p.accum) {
+            const V8 e = ld8(p.dx + pix * p.lddx + c);
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = e.v[k] + acc[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = acc[k];
+        }
+        st8(p.dx + pix * p.lddx + c, o);
+    }
+}
+
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const UpParams p)      // z[2H,2W] <- x[H,W]
+{
+    const int c8 = p.C >> 3;
+    const int64_t total = (int64_t)p.NB * (2 * p.H) * (2 * p.W) * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / c8;
+        const int c = (int)(i - pix * c8) << 3;
+        const int ow = (int)(pix % (2 * p.W));
+        const int oh = (int)((pix / (2 * p.W)) % (2 * p.H));
+        const int n = (int)(pix / ((int64_t)4 * p.W * p.H));
+        const uint4 v = *reinterpret_cast<const uint4*>(p.x + (((int64_t)n * p.H + (oh >> 1)) * p.W + (ow >> 1)) * p.ldx + c);
+        *reinterpret_cast<uint4*>(p.z + pix * p.ldz + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const UpParams p)      // x-grad[H,W] (=|+=) sum of 4 z-grads; here x=dz(2H,2W) z=dx(H,W)
+{
+    const int c8 = p.C >> 3;
+    const int64_t total = (int64_t)p.NB * p.H * p.W * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / c8;
+        const int c = (int)(i - pix * c8) << 3;
+        const int w = (int)(pix % p.W);
+        const int h = (int)((pix / p.W) % p.H);
+        const int n = (int)(pix / ((int64_t)p.W * p.H));
+        V8 o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.v[k] = 0.f;
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                const V8 g = ld8(p.x + (((int64_t)n * 2 * p.H + 2 * h + a) * (2 * p.W) + 2 * w + b) * p.ldx + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++) o.v[k] += g.v[k];
+            }
+        if (p.accum) {
+            const V8 e = ld8(p.z + pix * p.ldz + c);
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] += e.v[k];
+        }
+        st8(p.z + pix * p.ldz + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small-Cin im2col
+// img fp32 NCHW [NB,3,H,W] (what train.py:186 hands over) -> col [NB*OH*OW][Kpad] bf16, k = (r*kw + s)*Cin + c
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, int NB, int Cin, int H, int W, int kh, int kw,
+                                                     int stride, int pad, int OH, int OW, int Kpad, bf16_t* __restrict__ col)
+{
+    const int64_t total = (int64_t)NB * OH * OW * (Kpad >> 3);
+    const int k8 = Kpad >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / k8;
+        const int kk = (int)(i - pix * k8) << 3;
+        const int ow = (int)(pix % OW);
+        const int oh = (int)((pix / OW) % OH);
+        const int n = (int)(pix / ((int64_t)OW * OH));
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = kk + e;
+            float v = 0.f;
+            if (k < kh * kw * Cin) {
+                const int tap = k / Cin, c = k - tap * Cin;
+                const int r = tap / kw, s = tap - r * kw;
+                const int ih = oh * stride - pad + r, iw = ow * stride - pad + s;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = img[(((int64_t)n * Cin + c) * H + ih) * W + iw];
+            }
+            o.v[e] = v;
+        }
+        st8(col + pix * Kpad + kk, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head finish / implicit
+// pre [M][ldp] fp32 (head conv + bias) -> out [B, na, gs, gs, attrs] fp32, times ImplicitM (mul may be null)
+__global__ void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs, int na,
+                                       int attrs, float* __restrict__ out)
+{
+    const int64_t total = (int64_t)B * na * gs * gs * attrs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int at = (int)(i % attrs);
+    const int64_t r = i / attrs;
+    const int cell = (int)(r % (gs * gs));
+    const int a = (int)((r / (gs * gs)) % na);
+    const int b = (int)(r / ((int64_t)gs * gs * na));
+    const int ch = a * attrs + at;
+    float v = pre[((int64_t)b * gs * gs + cell) * ldp + ch];
+    if (mul) v *= mul[ch];
+    out[i] = v;
+}
+
+// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand, zero padded to ldd) and per-block
+// partial sums of dout*pre for dImplicitM
+__global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, int ldp,
+                                                              const float* __restrict__ mul, int B, int gs, int na, int attrs,
+                                                              bf16_t* __restrict__ dpre, int ldd, float* __restrict__ dmul_partial,
+                                                              int rows_per_block)
+{
+    const int nch = na * attrs;
+    const int64_t M = (int64_t)B * gs * gs;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int ch = threadIdx.x; ch < ldd; ch += 256) {
+        float acc = 0.f;
+        const int a = ch / attrs, at = ch - a * attrs;
+        for (int64_t m = r0; m < r1; m++) {
+            float g = 0.f;
+            if (ch < nch) {
+                const int b = (int)(m / (gs * gs));
+                const int cell = (int)(m - (int64_t)b * gs * gs);
+                const float d = dout[((((int64_t)b * na + a) * gs * gs) + cell) * attrs + at];
+                if (mul) { acc += d * pre[m * ldp + ch]; g = d * mul[ch]; } else g = d;
+            }
+            dpre[m * ldd + ch] = f2bf(g);
+        }
+        if (dmul_partial && ch < nch) dmul_partial[(int64_t)blockIdx.x * nch + ch] = acc;
+    }
+}
+
+// out[c] += sum_r partial[r][c]
+__global__ void colsum_rows_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; r++) s += (double)partial[(int64_t)r * C + c];
+    out[c] += (float)s;
+}
+
+// ImplicitA: z = x + a[c]  (model/utils.py:172-173); backward of `a` = column sums of dz
+__global__ __launch_bounds__(256) void chan_add_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ a, int64_t M, int C,
+                                                       bf16_t* __restrict__ z, int ldz)
+{
+    const int c8 = C >> 3;
+    const int64_t total = M * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / c8;
+        const int c = (int)(i - m * c8) << 3;
+        V8 v = ld8(x + m * ldx + c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.v[k] += a[c + k];
+        st8(z + m * ldz + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int ldx, int64_t M, int C, int rows_per_block,
+                                                          float* __restrict__ partial)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t m = r0; m < r1; m++) s += bf2f(x[m * ldx + c]);
+        partial[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weights / optimizer
+// fp32 master [Cout][Cin][taps] (torch layout) -> Wf bf16 [Cout][taps][CinP] and Wd bf16 [Cin][taps][Cout] (Wd may be null).
+// CinP >= Cin: small-Cin first layers are packed as a single tap with k = tap*Cin + c zero-padded to CinP.
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __restrict__ table, int n, int64_t total)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].start <= i) lo = mid; else hi = mid - 1; }
+        const PackEntry e = table[lo];
+        const int64_t j = i - e.start;                      // index into the Wf image [Cout][taps or 1][CinP]
+        if (e.CinP == e.Cin) {
+            const int c = (int)(j % e.Cin);
+            const int t = (int)((j / e.Cin) % e.taps);
+            const int co = (int)(j / ((int64_t)e.Cin * e.taps));
+            const bf16_t v = f2bf(e.src[((int64_t)co * e.Cin + c) * e.taps + t]);
+            e.wf[j] = v;
+            if (e.wd) e.wd[((int64_t)c * e.taps + t) * e.CoutP + co] = v;
+        } else {
+            const int k = (int)(j % e.CinP);
+            const int co = (int)(j / e.CinP);
+            float v = 0.f;
+            if (k < e.taps * e.Cin) { const int t = k / e.Cin, c = k - t * e.Cin; v = e.src[((int64_t)co * e.Cin + c) * e.taps + t]; }
+            e.wf[j] = f2bf(v);
+        }
+    }
+}
+
+// dW scratch [Cout][CinP] (single-tap layout of a small-Cin layer) -> += into torch layout [Cout][Cin][taps]
+__global__ void unpack_wgrad_kernel(const float* __restrict__ scratch, int Cout, int Cin, int taps, int CinP, float* __restrict__ grad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * Cin * taps) return;
+    const int t = i % taps;
+    const int c = (i / taps) % Cin;
+    const int co = i / (taps * Cin);
+    grad[i] += scratch[(int64_t)co * CinP + t * Cin + c];
+}
+
+// SGD with Nesterov momentum, dampening 0, no weight decay (train.py:156): buf = mu*buf + g; p -= lr*(g + mu*buf)
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                           int64_t n, float lr, float mu, float gscale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float b = mu * buf[i] + gi;
+        buf[i] = b;
+        p[i] -= lr * (gi + mu * b);
+    }
+}
+
+// fp32 NCHW image -> is consumed directly by im2col_kernel; nothing else needed for the input side.
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static inline unsigned grid_for(int64_t work_items) { int64_t g = ry_cdiv(work_items, 256); if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g; }
+
+extern "C" int ryolo_bn_finalize(const float* partial, int rows, int C, double count, float eps, float momentum, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float* coeffs, hipStream_t stream)
+{
+    if (!partial || !gamma || !beta || !coeffs || C <= 0 || rows <= 0) return RY_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ry_cdiv(C, 32)), dim3(1024), 0, stream, partial, rows, C, count, eps, momentum,
+                       gamma, beta, running_mean, running_var, coeffs);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                    float* coeffs, hipStream_t stream)
+{
+    if (!gamma || !beta || !rm || !rv || !coeffs || C <= 0) return RY_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, rm, rv, eps, C, coeffs);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+static int check_bnact(const BnActParams& p) { return (!p.y1 || !p.co1 || p.C <= 0 || (p.C & 7) || (p.ld1 & 7) || p.M < 0) ? RY_ERR_ARG : RY_OK; }
+
+extern "C" int ryolo_bn_act_fwd(const BnActParams* pp, hipStream_t stream)
+{
+    if (!pp || check_bnact(*pp) || !pp->z) return RY_ERR_ARG;
+    if (pp->M == 0) return RY_OK;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(pp->M * (pp->C >> 3))), dim3(256), 0, stream, *pp);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_per_block)
+{
+    if (!nblk || !rows_per_block || M <= 0 || C <= 0) return RY_ERR_ARG;
+    const int c8 = C >> 3;
+    const int cols = c8 < 256 ? c8 : 256;
+    const int nrl = 256 / cols;
+    int64_t blocks = ry_cdiv(M, (int64_t)nrl * 16);                 // >= 16 rows per row lane
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    *rows_per_block = (int)ry_cdiv(M, blocks);
+    *nblk = (int)ry_cdiv(M, *rows_per_block);
+    return RY_OK;
+}
+
+// reduce -> finalize -> apply; `partial` needs nblk*K*C floats, bco needs 3*C floats
+extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
+                                hipStream_t stream)
+{
+    if (!pp || check_bnact(*pp) || !pp->dz || !pp->dy1 || !pp->partial || !bco) return RY_ERR_ARG;
+    BnActParams p = *pp;
+    if (p.M == 0) return RY_OK;
+    int nblk, rpb;
+    ryolo_bn_act_bwd_blocks(p.M, p.C, &nblk, &rpb);
+    p.rows_per_block = rpb;
+    p.bco = bco;
+    const int K = p.y2 ? 3 : 2;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, p.partial, nblk, K, p.C,
+                       (double)p.M, bco, dgamma1, dbeta1, dgamma2, dbeta2);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(p.M * (p.C >> 3))), dim3(256), 0, stream, p);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_maxpool_fwd(const PoolParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->x || !pp->z || (pp->C & 7) || pp->k < 1 || pp->k > 15) return RY_ERR_ARG;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)pp->NB * pp->OH * pp->OW * (pp->C >> 3))), dim3(256), 0, stream, *pp);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_maxpool_bwd(const PoolParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->dz || !pp->dx || !pp->idx || (pp->C & 7)) return RY_ERR_ARG;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)pp->NB * pp->H * pp->W * (pp->C >> 3))), dim3(256), 0, stream, *pp);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_upsample2x_fwd(const UpParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->x || !pp->z || (pp->C & 7)) return RY_ERR_ARG;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((int64_t)pp->NB * pp->H * pp->W * 4 * (pp->C >> 3))), dim3(256), 0, stream, *pp);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_upsample2x_bwd(const UpParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->x || !pp->z || (pp->C & 7)) return RY_ERR_ARG;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((int64_t)pp->NB * pp->H * pp->W * (pp->C >> 3))), dim3(256), 0, stream, *pp);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_im2col(const float* img, int NB, int Cin, int H, int W, int kh, int kw, int stride, int pad, int OH, int OW, int Kpad,
+                            bf16_t* col, hipStream_t stream)
+{
+    if (!img || !col || (Kpad & 31) || Kpad < kh * kw * Cin) return RY_ERR_ARG;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((int64_t)NB * OH * OW * (Kpad >> 3))), dim3(256), 0, stream, img, NB, Cin, H, W, kh, kw,
+                       stride, pad, OH, OW, Kpad, col);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
+                                     hipStream_t stream)
+{
+    if (!pre || !out) return RY_ERR_ARG;
+    const int64_t total = (int64_t)B * na * gs * gs * attrs;
+    if (total == 0) return RY_OK;
+    hipLaunchKernelGGL(head_finish_fwd_kernel, dim3((unsigned)ry_cdiv(total, 256)), dim3(256), 0, stream, pre, ldp, mul, B, gs, na, attrs, out);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+// dmul (ImplicitM grad, may be null) is accumulated; scratch needs nblk*na*attrs floats where nblk = ceil(M/64)
+extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
+                                     bf16_t* dpre, int ldd, float* dmul, float* scratch, hipStream_t stream)
+{
+    if (!dout || !pre || !dpre || (mul && (!dmul || !scratch))) return RY_ERR_ARG;
+    const int64_t M = (int64_t)B * gs * gs;
+    if (M == 0) return RY_OK;
+    const int rpb = 64;
+    const int nblk = (int)ry_cdiv(M, rpb);
+    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd,
+                       mul ? scratch : nullptr, rpb);
+    if (mul)
+        hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(na * attrs, 256)), dim3(256), 0, stream, scratch, nblk, na * attrs, dmul);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, hipStream_t stream)
+{
+    if (!x || !a || !z || (C & 7)) return RY_ERR_ARG;
+    if (M == 0) return RY_OK;
+    hipLaunchKernelGGL(chan_add_kernel, dim3(grid_for(M * (C >> 3))), dim3(256), 0, stream, x, ldx, a, M, C, z, ldz);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+// out[c] += sum_m x[m][c]; scratch needs ceil(M/256)*C floats
+extern "C" int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, float* out, float* scratch, hipStream_t stream)
+{
+    if (!x || !out || !scratch) return RY_ERR_ARG;
+    if (M == 0) return RY_OK;
+    const int rpb = 256;
+    const int nblk = (int)ry_cdiv(M, rpb);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, M, C, rpb, scratch);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, scratch, nblk, C, out);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t total, hipStream_t stream)
+{
+    if (!table_dev || n <= 0 || total <= 0) return RY_ERR_ARG;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, stream, table_dev, n, total);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int CinP, float* grad, hipStream_t stream)
+{
+    if (!scratch || !grad) return RY_ERR_ARG;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ry_cdiv((int64_t)Cout * Cin * taps, 256)), dim3(256), 0, stream, scratch, Cout, Cin,
+                       taps, CinP, grad);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, hipStream_t stream)
+{
+    if (!p || !g || !buf || n < 0) return RY_ERR_ARG;
+    if (n == 0) return RY_OK;
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, buf, n, lr, mu, gscale);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_struct_sizes(int* sizes /*[8]*/)
+{
+    if (!sizes) return RY_ERR_ARG;
+    sizes[0] = (int)sizeof(BnActParams); sizes[1] = (int)sizeof(PoolParams); sizes[2] = (int)sizeof(UpParams); sizes[3] = (int)sizeof(PackEntry);
+    sizes[4] = (int)sizeof(ConvGemmParams); sizes[5] = (int)sizeof(WgradParams); sizes[6] = (int)sizeof(LossParams); sizes[7] = (int)sizeof(TapClass);
+    return RY_OK;
+}

@@ -1,0 +1,441 @@
+// Fused loss (forward + gradient) for gfx950 — SURVEY.md §8a rows L1-L6.
+// Replaces ComputeCSLLoss (lib/loss.py:153-331) and ComputeKFIoULoss (:334-492) of the reference, including
+// build_targets (:270-331 / :427-492), bbox_ciou (:36-78), KFLoss (:81-150) with xywhr2xywhrsigma (lib/general.py:107-133)
+// and norm_angle (lib/general.py:7-20).
+//
+// The reference spends ~100 tiny launches, 4-5 device->host syncs (.cpu().item(), boolean-mask indexing) and an
+// O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 5 launches with no host round trip:
+//   K1 loss_targets_kernel   one 1024-thread workgroup per scale: candidate (offset, anchor, target) triples are tested
+//                            and compacted IN THE REFERENCE'S ORDER with ballot/popcount prefix sums (bit-exact indices);
+//   K2 loss_match_kernel     one wavefront per match: lane 0 differentiates the box term with forward-mode dual numbers
+//                            (CIoU with constant alpha / KFIoU closed form), all 64 lanes run the class / 180-bin CSL
+//                            BCE with wave64 shuffle reductions; gradients are emitted directly (fused fwd+bwd);
+//                            duplicate cells are resolved last-writer-wins via an atomicMax owner grid;
+//   K3 loss_tconf_kernel     owners scatter their IoU score into the objectness target grid;
+//   K4 loss_obj_kernel       objectness BCE over every cell (the only HBM-heavy pass: one strided logit per cell);
+//   K5 loss_finalize_kernel  fixed-order sums -> the five loss items, already scaled (lib/loss.py:251-255, :410-413).
+// Compiled with -ffp-contract=off so the float comparisons of target assignment match torch-CPU bit for bit.
+#include "common.h"
+#include "params.h"
+
+#define PI_F 3.14159265358979323846f
+
+
+// ------------------------------------------------------------------------------------------------ workspace carving
+struct ScaleWs {
+    int* count;               // [1]
+    int* rec;                 // [cap][8]: b, a, gj, gi, cls, tidx, cell, pad
+    float* frec;              // [cap][8]: tbox[0..4], score, pad, pad
+    int* owner;               // [cells]
+    float* tconf;             // [cells]
+    float* part_match;        // [nblk_match][4]: reg_a, reg_b, cls, theta
+    float* part_obj;          // [nblk_obj]
+    int cap, cells, nblk_match, nblk_obj;
+};
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+__host__ __device__ static inline void carve(const LossParams& p, ScaleWs* s, size_t* total)
+{
+    size_t off = 0;
+    char* base = reinterpret_cast<char*>(p.ws);
+    for (int i = 0; i < 3; i++) {
+        const int cap = 5 * p.na * p.nt;
+        const int cells = p.batch * p.na * p.gs[i] * p.gs[i];
+        s[i].cap = cap; s[i].cells = cells;
+        s[i].nblk_match = (cap + 3) / 4;
+        s[i].nblk_obj = (cells + 1023) / 1024 > 2048 ? 2048 : (cells + 1023) / 1024;
+        if (s[i].nblk_obj < 1) s[i].nblk_obj = 1;
+        s[i].count = reinterpret_cast<int*>(base + off); off += 256;
+        s[i].rec = reinterpret_cast<int*>(base + off); off += al256((size_t)cap * 8 * 4);
+        s[i].frec = reinterpret_cast<float*>(base + off); off += al256((size_t)cap * 8 * 4);
+        s[i].owner = reinterpret_cast<int*>(base + off); off += al256((size_t)cells * 4);
+        s[i].tconf = reinterpret_cast<float*>(base + off); off += al256((size_t)cells * 4);
+        s[i].part_match = reinterpret_cast<float*>(base + off); off += al256((size_t)(s[i].nblk_match > 0 ? s[i].nblk_match : 1) * 4 * 4);
+        s[i].part_obj = reinterpret_cast<float*>(base + off); off += al256((size_t)s[i].nblk_obj * 4);
+    }
+    *total = off;
+}
+
+// ------------------------------------------------------------------------------------------------ K1 targets
+__global__ __launch_bounds__(1024) void loss_targets_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
+{
+    const int i = blockIdx.x;
+    const ScaleWs s = i == 0 ? s0 : (i == 1 ? s1 : s2);
+    const int gs = p.gs[i];
+    const int na = p.na, nt = p.nt;
+    const int total = 5 * na * nt;
+    __shared__ int wave_cnt[16];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float fg = (float)gs;
+    for (int base = 0; base < total; base += 1024) {
+        const int cnd = base + threadIdx.x;
+        bool ok = false;
+        int o = 0, a = 0, t = 0;
+        float gx = 0.f, gy = 0.f, gw = 0.f, gh = 0.f;
+        if (cnd < total) {
+            o = cnd / (na * nt);
+            const int r = cnd - o * na * nt;
+            a = r / nt;
+            t = r - a * nt;
+            const float* tg = p.targets + (int64_t)t * p.tcols;
+            gx = tg[2] * fg; gy = tg[3] * fg; gw = tg[4] * fg; gh = tg[5] * fg;
+            const float aw = p.anchors[i][a][0], ah = p.anchors[i][a][1];
+            const float rw = gw / aw, rh = gh / ah;
+            const float mw = fmaxf(rw, 1.0f / rw), mh = fmaxf(rh, 1.0f / rh);
+            ok = fmaxf(mw, mh) < 4.0f;                                                     // lib/loss.py:297-298 / :454-455
+            if (p.mode == 1) ok = ok && (fabsf(cosf(tg[6] - p.anchors[i][a][2])) > 0.866f);   // lib/loss.py:458-461
+            if (ok && o > 0) {
+                const float ix = fg - gx, iy = fg - gy;                                    // gxi = gain - gxy
+                if (o == 1) ok = (gx - floorf(gx) < 0.5f) && (gx > 1.0f);
+                else if (o == 2) ok = (gy - floorf(gy) < 0.5f) && (gy > 1.0f);
+                else if (o == 3) ok = (ix - floorf(ix) < 0.5f) && (ix > 1.0f);
+                else ok = (iy - floorf(iy) < 0.5f) && (iy > 1.0f);
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = running;
+        for (int w = 0; w < wave; w++) before += wave_cnt[w];
+        if (ok) {
+            const int e = before + __popcll(m & ((1ull << lane) - 1ull));
+            const float offx = o == 1 ? 0.5f : (o == 3 ? -0.5f : 0.f);
+            const float offy = o == 2 ? 0.5f : (o == 4 ? -0.5f : 0.f);
+            int gi = (int)(gx - offx), gj = (int)(gy - offy);                              // .long(): trunc toward zero
+            gi = min(max(gi, 0), gs - 1);                                                  // clamp_ in place (lib/loss.py:324)
+            gj = min(max(gj, 0), gs - 1);
+            const float* tg = p.targets + (int64_t)t * p.tcols;
+            const int b = (int)tg[0];
+            int* r = s.rec + (int64_t)e * 8;
+            r[0] = b; r[1] = a; r[2] = gj; r[3] = gi; r[4] = (int)tg[1]; r[5] = t;
+            r[6] = ((b * na + a) * gs + gj) * gs + gi;
+            r[7] = 0;
+            float* f = s.frec + (int64_t)e * 8;
+            f[0] = gx - (float)gi; f[1] = gy - (float)gj; f[2] = gw; f[3] = gh;              // tbox (lib/loss.py:325 / :488)
+            f[4] = p.mode == 1 ? tg[6] : 0.f;
+            f[5] = 0.f; f[6] = 0.f; f[7] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < 16; w++) tot += wave_cnt[w]; running += tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *s.count = running;
+}
+
+// ------------------------------------------------------------------------------------------------ dual numbers
+template <int N>
+struct Dual {
+    float v;
+    float d[N];
+};
+template <int N> __device__ __forceinline__ Dual<N> dconst(float c) { Dual<N> r; r.v = c; for (int k = 0; k < N; k++) r.d[k] = 0.f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dvar(float c, int idx) { Dual<N> r = dconst<N>(c); r.d[idx] = 1.f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(Dual<N> a, Dual<N> b) { for (int k = 0; k < N; k++) a.d[k] += b.d[k]; a.v += b.v; return a; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(Dual<N> a, Dual<N> b) { for (int k = 0; k < N; k++) a.d[k] -= b.d[k]; a.v -= b.v; return a; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v * b.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * b.v + a.v * b.d[k]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator/(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v / b.v; for (int k = 0; k < N; k++) r.d[k] = (a.d[k] - r.v * b.d[k]) / b.v; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(Dual<N> a, float c) { a.v *= c; for (int k = 0; k < N; k++) a.d[k] *= c; return a; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(Dual<N> a, float c) { a.v += c; return a; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(Dual<N> a, float c) { a.v -= c; return a; }
+template <int N> __device__ __forceinline__ Dual<N> dscale(Dual<N> a, float dv, float v) { for (int k = 0; k < N; k++) a.d[k] *= dv; a.v = v; return a; }   // f(a): value v, f'(a)=dv
+// torch.max / torch.min (binary): ties split the gradient evenly
+template <int N> __device__ __forceinline__ Dual<N> dmax(Dual<N> a, Dual<N> b)
+{
+    if (a.v > b.v) return a;
+    if (a.v < b.v) return b;
+    Dual<N> r; r.v = a.v; for (int k = 0; k < N; k++) r.d[k] = 0.5f * (a.d[k] + b.d[k]); return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dmin(Dual<N> a, Dual<N> b)
+{
+    if (a.v < b.v) return a;
+    if (a.v > b.v) return b;
+    Dual<N> r; r.v = a.v; for (int k = 0; k < N; k++) r.d[k] = 0.5f * (a.d[k] + b.d[k]); return r;
+}
+// clamp: gradient passes where min <= x <= max (torch clamp backward)
+template <int N> __device__ __forceinline__ Dual<N> dclamp(Dual<N> a, float lo, float hi)
+{
+    if (a.v < lo) return dconst<N>(lo);
+    if (a.v > hi) return dconst<N>(hi);
+    return a;
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplus_neg_abs(float x) { return log1pf(expf(-fabsf(x))); }
+// BCEWithLogits element, pos_weight pw: value and d/dx
+__device__ __forceinline__ float bce_val(float x, float t, float pw)
+{
+    const float w = 1.f + (pw - 1.f) * t;
+    return (1.f - t) * x + w * (softplus_neg_abs(x) + fmaxf(-x, 0.f));
+}
+__device__ __forceinline__ float bce_grad(float x, float t, float pw)
+{
+    const float w = 1.f + (pw - 1.f) * t;
+    return (1.f - t) - w * (1.f - sigm(x));
+}
+
+// CIoU (lib/loss.py:36-78) with alpha constant; inputs 4 duals (x,y,w,h), target floats
+__device__ Dual<4> ciou_dual(Dual<4> x1, Dual<4> y1, Dual<4> w1, Dual<4> h1, float x2, float y2, float w2, float h2)
+{
+    typedef Dual<4> D;
+    const D pl = x1 - w1 * 0.5f, pr = x1 + w1 * 0.5f, pt = y1 - h1 * 0.5f, pb = y1 + h1 * 0.5f;
+    const D tl = dconst<4>(x2 - w2 / 2), tr = dconst<4>(x2 + w2 / 2), tt = dconst<4>(y2 - h2 / 2), tb = dconst<4>(y2 + h2 / 2);
+    const D iw = dclamp(dmin(pr, tr) - dmax(pl, tl), 0.f, INFINITY);
+    const D ih = dclamp(dmin(pb, tb) - dmax(pt, tt), 0.f, INFINITY);
+    const D inter = iw * ih;
+    const D dx = dconst<4>(x2) - x1, dy = dconst<4>(y2) - y1;
+    const D d2 = dx * dx + dy * dy;
+    const D ow = dclamp(dmax(pr, tr) - dmin(pl, tl), 0.f, INFINITY);
+    const D oh = dclamp(dmax(pb, tb) - dmin(pt, tt), 0.f, INFINITY);
+    const D c2 = ow * ow + oh * oh;
+    const D uni = w1 * h1 + (w2 * h2) - inter;
+    const D u = d2 / (c2 + 1e-15f);
+    const D iou = inter / (uni + 1e-15f);
+    const D ratio = w1 / h1;
+    const float at2 = atanf(w2 / h2);
+    const D at1 = dscale(ratio, 1.f / (1.f + ratio.v * ratio.v), atanf(ratio.v));
+    const D diff = dconst<4>(at2) - at1;
+    const D v = diff * diff * 0.4052847345693511f;            // (float)(4 / pi^2)
+    const float alpha = v.v / ((1.f - iou.v) + v.v);
+    D c = iou - (u + v * alpha);
+    if (c.v < -1.f) c = dconst<4>(-1.f);
+    if (c.v > 1.f) c = dconst<4>(1.f);
+    return c;
+}
+
+// KFLoss pieces (lib/loss.py:100-150, fun='exp', alpha=3): returns xy_loss and kf_loss as duals of (x,y,w,h,r), plus KFIoU
+__device__ void kf_dual(Dual<5> x, Dual<5> y, Dual<5> w, Dual<5> h, Dual<5> r, const float* t, Dual<5>& xy_loss, Dual<5>& kf_loss,
+                        float& kfiou)
+{
+    typedef Dual<5> D;
+    const D wp = dclamp(w, 1e-4f, 1e4f), hp = dclamp(h, 1e-4f, 1e4f);
+    const float wt = fminf(fmaxf(t[2], 1e-4f), 1e4f), ht = fminf(fmaxf(t[3], 1e-4f), 1e4f), rt = t[4];
+    // Sigma_t = R diag((wt/2)^2, (ht/2)^2) R^T, R = [[c,-s],[s,c]]; inverse in closed form
+    const float c = cosf(rt), s = sinf(rt);
+    const float a2 = (0.5f * wt) * (0.5f * wt), b2 = (0.5f * ht) * (0.5f * ht);
+    const float s00 = c * c * a2 + s * s * b2, s01 = c * s * (a2 - b2), s11 = s * s * a2 + c * c * b2;
+    const float det = s00 * s11 - s01 * s01;
+    const D dx = x - t[0], dy = y - t[1];
+    const D maha = (dx * dx * s11 - dx * dy * (2.f * s01) + dy * dy * s00) * (1.f / det);
+    const D m1 = maha + 1.f;
+    xy_loss = dscale(m1, 1.f / m1.v, logf(m1.v));
+    const D wp2 = wp * wp, hp2 = hp * hp;
+    const float wt2 = wt * wt, ht2 = ht * ht;
+    const D dr = r - rt;
+    const float cd = cosf(dr.v), sd = sinf(dr.v);
+    const D cos2 = dscale(dr, -2.f * cd * sd, cd * cd);
+    const D sin2 = dscale(dr, 2.f * sd * cd, sd * sd);
+    const D A2 = (wp2 * hp2) * (1.f / (wt2 * ht2)) + (wp2 * (1.f / wt2) + hp2 * (1.f / ht2)) * cos2 + (wp2 * (1.f / ht2) + hp2 * (1.f / wt2)) * sin2 + 1.f;
+    const D inv_wh = dconst<5>(wt2 * ht2) / (wp2 * hp2);
+    const D B2 = inv_wh + (dconst<5>(wt2) / wp2 + dconst<5>(ht2) / hp2) * cos2 + (dconst<5>(wt2) / hp2 + dconst<5>(ht2) / wp2) * sin2 + 1.f;
+    const D A = dscale(A2, 0.5f / sqrtf(A2.v), sqrtf(A2.v));
+    const D B = dscale(B2, 0.5f / sqrtf(B2.v), sqrtf(B2.v));
+    const D den = A + B - 3.f;
+    const D k = dconst<5>(1.f) / den;                      // (4 - alpha) / (A + B - alpha), alpha = 3
+    kfiou = k.v;
+    const float ex = expf(1.f - k.v);
+    kf_loss = dscale(k, -ex, ex - 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------ K2 per-match
+__global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, ScaleWs s, int scale)
+{
+    __shared__ float blk[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    const int n = *s.count;
+    const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
+    float reg_a = 0.f, reg_b = 0.f, clsl = 0.f, thl = 0.f;
+    if (e < n) {
+        const int* r = s.rec + (int64_t)e * 8;
+        float* f = s.frec + (int64_t)e * 8;
+        const int a = r[1], cell = r[6];
+        const float* ps = p.head[scale] + (int64_t)cell * attrs;
+        float* gp = p.compute_grad ? p.grad[scale] + (int64_t)cell * attrs : nullptr;
+        const float inv_n = 1.0f / (float)n;
+        if (lane == 0) {
+            const float aw = p.anchors[scale][a][0], ah = p.anchors[scale][a][1];
+            const float sx = sigm(ps[0]), sy = sigm(ps[1]), sw = sigm(ps[2]), sh = sigm(ps[3]);
+            float score, g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.mode == 0) {
+                const Dual<4> c = ciou_dual(dvar<4>(sx * 2.f - 0.5f, 0), dvar<4>(sy * 2.f - 0.5f, 1),
+                                            dvar<4>((sw * 2.f) * (sw * 2.f) * aw, 2), dvar<4>((sh * 2.f) * (sh * 2.f) * ah, 3),
+                                            f[0], f[1], f[2], f[3]);
+                reg_a = 1.0f - c.v;                                              // (1 - ciou).mean()  lib/loss.py:218
+                score = fmaxf(c.v, 0.f);
+                const float k = -p.box * inv_n;
+                g[0] = k * c.d[0] * 2.f * sx * (1.f - sx);
+                g[1] = k * c.d[1] * 2.f * sy * (1.f - sy);
+                g[2] = k * c.d[2] * 8.f * sw * sw * (1.f - sw) * aw;
+                g[3] = k * c.d[3] * 8.f * sh * sh * (1.f - sh) * ah;
+            } else {
+                const float sa = sigm(ps[4]);
+                float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];          // lib/loss.py:390
+                const float hp = (float)(3.14159265358979323846 / 2);
+                if (pa >= hp) pa = pa - PI_F;                                    // norm_angle, lib/general.py:14-15
+                if (pa < -hp) pa = pa + PI_F;
+                Dual<5> xy, kf;
+                float kfiou;
+                kf_dual(dvar<5>(sx * 2.f - 0.5f, 0), dvar<5>(sy * 2.f - 0.5f, 1), dvar<5>((sw * 2.f) * (sw * 2.f) * aw, 2),
+                        dvar<5>((sh * 2.f) * (sh * 2.f) * ah, 3), dvar<5>(pa, 4), f, xy, kf, kfiou);
+                reg_a = fmaxf(xy.v, 0.f);
+                reg_b = fmaxf(kf.v, 0.f);
+                score = fmaxf(kfiou, 0.f);
+                const float k = p.box * inv_n;
+                const float d0 = xy.d[0] + kf.d[0], d1 = xy.d[1] + kf.d[1], d2 = xy.d[2] + kf.d[2], d3 = xy.d[3] + kf.d[3],
+                            d4 = xy.d[4] + kf.d[4];
+                g[0] = k * d0 * 2.f * sx * (1.f - sx);
+                g[1] = k * d1 * 2.f * sy * (1.f - sy);
+                g[2] = k * d2 * 8.f * sw * sw * (1.f - sw) * aw;
+                g[3] = k * d3 * 8.f * sh * sh * (1.f - sh) * ah;
+                g[4] = k * d4 * 1.1f * sa * (1.f - sa);
+            }
+            f[5] = score;
+            atomicMax(&s.owner[cell], e);                                        // last writer (largest e) wins
+            if (gp) {
+                for (int k = 0; k < 4; k++) atomicAdd(gp + k, g[k]);
+                if (p.mode == 1) atomicAdd(gp + 4, g[4]);
+            }
+        }
+        // class BCE (nc > 1 only, lib/loss.py:223 / :399)
+        const int c0 = p.mode == 0 ? 5 : 6;
+        if (p.nc > 1) {
+            const int tc = r[4];
+            const float kc = p.cls * inv_n / (float)p.nc;
+            for (int k = lane; k < p.nc; k += 64) {
+                const float x = ps[c0 + k], t = (k == tc) ? 1.f : 0.f;
+                clsl += bce_val(x, t, p.cls_pw);
+                if (gp) atomicAdd(gp + c0 + k, kc * bce_grad(x, t, p.cls_pw));
+            }
+        }
+        if (p.mode == 0) {                                                       // CSL theta BCE, lib/loss.py:231
+            const float* tg = p.targets + (int64_t)r[5] * p.tcols + 7;
+            const float kt = p.theta_gain * inv_n / 180.f;
+            for (int k = lane; k < 180; k += 64) {
+                const float x = ps[5 + p.nc + k], t = tg[k];
+                thl += bce_val(x, t, 1.0f);
+                if (gp) atomicAdd(gp + 5 + p.nc + k, kt * bce_grad(x, t, 1.0f));
+            }
+        }
+    }
+    clsl = wave_sum(clsl);
+    thl = wave_sum(thl);
+    if (lane == 0) { blk[wave][0] = reg_a; blk[wave][1] = reg_b; blk[wave][2] = clsl; blk[wave][3] = thl; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float v = blk[0][threadIdx.x] + blk[1][threadIdx.x] + blk[2][threadIdx.x] + blk[3][threadIdx.x];
+        s.part_match[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3 / K4
+__global__ void loss_tconf_kernel(ScaleWs s)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *s.count) return;
+    const int cell = s.rec[(int64_t)e * 8 + 6];
+    if (s.owner[cell] == e) s.tconf[cell] = s.frec[(int64_t)e * 8 + 5];          // gr = 1.0: tconf = score (lib/loss.py:221)
+}
+
+__global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, ScaleWs s, int scale)
+{
+    __shared__ float red[4];
+    const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
+    const int och = p.mode == 0 ? 4 : 5;
+    const float kg = p.obj / (float)s.cells;
+    float acc = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < s.cells; i += gridDim.x * 256) {
+        const float x = p.head[scale][(int64_t)i * attrs + och];
+        const float t = s.tconf[i];
+        acc += bce_val(x, t, p.obj_pw);
+        if (p.compute_grad) p.grad[scale][(int64_t)i * attrs + och] = kg * bce_grad(x, t, p.obj_pw);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) s.part_obj[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------ K5 finalize
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
+{
+    __shared__ double red[256];
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};       // reg, conf, cls, theta (unscaled, summed over scales)
+    for (int i = 0; i < 3; i++) {
+        const ScaleWs s = i == 0 ? s0 : (i == 1 ? s1 : s2);
+        const int n = *s.count;
+        const int nb = (n + 3) / 4;
+        double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int b = threadIdx.x; b < nb; b += 256)
+            for (int q = 0; q < 4; q++) part[q] += (double)s.part_match[(int64_t)b * 4 + q];
+        for (int b = threadIdx.x; b < s.nblk_obj; b += 256) part[4] += (double)s.part_obj[b];
+        for (int q = 0; q < 5; q++) {
+            red[threadIdx.x] = part[q];
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+                __syncthreads();
+            }
+            part[q] = red[0];
+            __syncthreads();
+        }
+        if (n > 0) {
+            tot[0] += (part[0] + part[1]) / (double)n;
+            if (p.nc > 1) tot[2] += part[2] / ((double)n * p.nc);
+            if (p.mode == 0) tot[3] += part[3] / ((double)n * 180.0);
+        }
+        tot[1] += part[4] / (double)s.cells;
+    }
+    if (threadIdx.x == 0) {
+        const float reg = p.box * (float)tot[0], conf = p.obj * (float)tot[1], cls = p.cls * (float)tot[2],
+                    th = p.theta_gain * (float)tot[3];
+        p.items[0] = reg; p.items[1] = conf; p.items[2] = cls; p.items[3] = th;
+        p.items[4] = reg + conf + cls + th;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int ryolo_loss_workspace_bytes(const LossParams* pp, size_t* bytes)
+{
+    if (!pp || !bytes) return RY_ERR_ARG;
+    LossParams p = *pp;
+    p.ws = nullptr;
+    ScaleWs s[3];
+    carve(p, s, bytes);
+    return RY_OK;
+}
+
+extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
+{
+    if (!pp) return RY_ERR_ARG;
+    const LossParams& p = *pp;
+    if (p.na < 1 || p.na > LOSS_MAX_NA || p.nt < 0 || p.batch < 1 || p.nc < 0 || !p.items || !p.ws) return RY_ERR_ARG;
+    if (p.nt > 0 && !p.targets) return RY_ERR_ARG;
+    if (p.tcols < (p.mode == 0 ? 187 : 7) && p.nt > 0) return RY_ERR_ARG;
+    ScaleWs s[3];
+    size_t need;
+    carve(p, s, &need);
+    if (p.ws_bytes < need) return RY_ERR_WORKSPACE;
+    const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
+    if (hipMemsetAsync(p.ws, 0, need, stream) != hipSuccess) return RY_ERR_LAUNCH;
+    for (int i = 0; i < 3; i++) {
+        if (!p.head[i] || (p.compute_grad && !p.grad[i])) return RY_ERR_ARG;
+        if (hipMemsetAsync(s[i].owner, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
+        if (p.compute_grad && hipMemsetAsync(p.grad[i], 0, (size_t)s[i].cells * attrs * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
+    }
+    if (p.nt > 0) {
+        hipLaunchKernelGGL(loss_targets_kernel, dim3(3), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
+        for (int i = 0; i < 3; i++) {
+            hipLaunchKernelGGL(loss_match_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
+            hipLaunchKernelGGL(loss_tconf_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, s[i]);
+        }
+    }
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL(loss_obj_kernel, dim3(s[i].nblk_obj), dim3(256), 0, stream, p, s[i], i);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, p, s[0], s[1], s[2]);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+

@@ -1,0 +1,435 @@
+"""Static-graph executor for the conv stack — the MI355X-first replacement for running the
+reference's nn.Module.forward + autograd op by op.
+
+For a fixed (batch, image size, train/eval) the whole backbone + neck is planned ONCE into two flat tapes of C-ABI kernel
+launches (forward, backward) over pre-allocated NHWC bf16 buffers:
+  * no allocation, no host sync and no Python tensor ops inside a step -> both tapes are hipGraph-capturable;
+  * torch.cat never happens: producers are planned to write straight into their channel slice of the concat buffer;
+  * gradients: "first writer stores, later writers accumulate" is resolved at plan time per channel range, so there is
+    no zero-fill of activation gradients and no autograd bookkeeping;
+  * parameter gradients accumulate into one flat fp32 buffer (the unit of the RCCL all-reduce and of the fused SGD step).
+PyTorch only owns the memory (torch.empty) and the stream.
+"""
+import ctypes as C
+
+import torch
+
+from .. import hip
+from . import structs as S
+
+BF16 = torch.bfloat16
+
+
+class Buf:
+    """[N*H*W, C] bf16 activation buffer (NHWC, channel stride = C) and, lazily, its gradient twin."""
+
+    def __init__(self, N, H, W, Cc, device):
+        self.N, self.H, self.W, self.C = N, H, W, Cc
+        self.t = torch.empty((N * H * W, Cc), dtype=BF16, device=device)
+        self.g = None
+        self.g_written = []          # channel ranges already written during the planned backward
+
+    def grad_tensor(self):
+        if self.g is None:
+            self.g = torch.empty_like(self.t)
+        return self.g
+
+
+class TRef:
+    """Channel slice [c0, c0+C) of a Buf."""
+
+    def __init__(self, buf, c0=0, Cc=None):
+        self.buf, self.c0, self.C = buf, c0, buf.C - c0 if Cc is None else Cc
+        assert self.c0 % 8 == 0 and self.C % 8 == 0 and self.c0 + self.C <= buf.C
+
+    N = property(lambda s: s.buf.N)
+    H = property(lambda s: s.buf.H)
+    W = property(lambda s: s.buf.W)
+    ld = property(lambda s: s.buf.C)
+    M = property(lambda s: s.buf.N * s.buf.H * s.buf.W)
+
+    def ptr(self):
+        return self.buf.t.data_ptr() + 2 * self.c0
+
+    def gptr(self):
+        return self.buf.grad_tensor().data_ptr() + 2 * self.c0
+
+    def slice(self, c0, Cc):
+        return TRef(self.buf, self.c0 + c0, Cc)
+
+    def grad_write_mode(self):
+        """Plan-time: returns 1 (accumulate) if [c0,c0+C) of the grad buffer was already written, else 0 (store)."""
+        lo, hi = self.c0, self.c0 + self.C
+        covered = any(a <= lo and hi <= b for a, b in self.buf.g_written)
+        if not covered:
+            for a, b in self.buf.g_written:
+                if not (hi <= a or b <= lo):
+                    raise RuntimeError("engine: partially overlapping gradient writes (unsupported plan)")
+            self.buf.g_written.append((lo, hi))
+        return 1 if covered else 0
+
+    def to_nchw(self, grad=False):
+        t = self.buf.g if grad else self.buf.t
+        return t.view(self.N, self.H, self.W, self.ld)[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2).float().contiguous()
+
+
+def _taps_fwd(k, pad):
+    return [(r - pad, s - pad, r * k + s) for r in range(k) for s in range(k)]
+
+
+def _fill_class(tc, taps, oh_add=0, ow_add=0):
+    tc.ntaps = len(taps)
+    tc.oh_add, tc.ow_add = oh_add, ow_add
+    for i, (dh, dw, wi) in enumerate(taps):
+        tc.dh[i], tc.dw[i], tc.widx[i] = dh, dw, wi
+
+
+class Graph:
+    def __init__(self, rt, B, Hin, Win, training):
+        self.rt, self.B, self.Hin, self.Win, self.training = rt, B, Hin, Win, training
+        self.dev = rt.device
+        self.fwd, self.bwd = [], []            # tapes: lists of (fn_name, args...) closures
+        self.keep = []                         # tensors/structs kept alive
+        self.stream = None
+        self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
+        self.heads = []                        # per scale: dict(out=fp32 tensor, dout=fp32 tensor)
+        self.debug = {}
+
+    # ------------------------------------------------------------------ helpers
+    def new(self, N, H, W, Cc):
+        b = Buf(N, H, W, Cc, self.dev)
+        self.keep.append(b)
+        return TRef(b)
+
+    def f32(self, *shape, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def _call(self, tape, name, *args):
+        """args may contain ctypes structs (passed by reference); the stream is appended at run time."""
+        conv = tuple(C.byref(a) if isinstance(a, C.Structure) else a for a in args)
+        self.keep.extend(a for a in args if isinstance(a, C.Structure))
+        fn = getattr(hip.lib(), name)
+        tape.append((fn, conv, name))
+
+    def run(self, tape):
+        st = hip.stream()
+        for fn, args, name in tape:
+            rc = fn(*args, st)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed with code {rc}")
+
+    # ------------------------------------------------------------------ convolution
+    def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None, stats=None,
+              coeffs=None, act=0, bias=None):
+        p = S.ConvGemmParams()
+        p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = Aptr, A.N, A.H, A.W, gemm_cin, A.ld
+        p.W, p.Nout, p.wtaps = W.data_ptr(), Nout, wtaps
+        p.OH, p.OW, p.sh, p.sw = OH, OW, stride, stride
+        if full is None:
+            p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, OH, OW
+        else:
+            p.oh_mul, p.ow_mul, p.OHf, p.OWf = full
+        p.nclasses = len(classes)
+        for i, (taps, oa, wa) in enumerate(classes):
+            _fill_class(p.cls[i], taps, oa, wa)
+        p.epi, p.out, p.ldC = epi, out_ptr, ldC
+        p.stats = stats.data_ptr() if stats is not None else None
+        if coeffs is not None:
+            Cn = coeffs.shape[1]
+            p.scale, p.shift = coeffs.data_ptr() + 2 * Cn * 4, coeffs.data_ptr() + 3 * Cn * 4
+        p.act = act
+        p.bias = bias
+        self._call(tape, "ryolo_conv_gemm", p)
+
+    def _conv_geom(self, conv, x):
+        k, s = conv.kernel_size[0], conv.stride[0]
+        pad = conv.padding[0]
+        OH = (x.H + 2 * pad - k) // s + 1
+        OW = (x.W + 2 * pad - k) // s + 1
+        return k, s, pad, OH, OW
+
+    def _dgrad(self, conv, pk, dy, dy_ptr, dy_cin, x):
+        """x.grad (=|+=) conv_transpose(dy).  dy: TRef-like geometry (N, OH, OW, ld)."""
+        k, s, pad, OH, OW = self._conv_geom(conv, x)
+        mode = x.grad_write_mode()
+        epi = S.EPI_ACCUM if mode else S.EPI_RAW
+        cin = conv.in_channels
+        if s == 1:
+            taps = [(pad - r, pad - c, r * k + c) for r in range(k) for c in range(k)]
+            self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld)
+        else:
+            assert s == 2 and x.H % 2 == 0 and x.W % 2 == 0
+            classes = []
+            for ph in range(2):
+                for pw in range(2):
+                    taps = [((ph + pad - r) // 2, (pw + pad - c) // 2, r * k + c) for r in range(k) for c in range(k)
+                            if (ph + pad - r) % 2 == 0 and (pw + pad - c) % 2 == 0]
+                    classes.append((taps, ph, pw))
+            self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H // 2, x.W // 2, 1, classes, epi, x.gptr(), x.ld,
+                       full=(2, 2, x.H, x.W))
+
+    def _wgrad(self, conv, dy, dy_ptr, cout_pad, x, x_ptr=None):
+        k, s, pad, OH, OW = self._conv_geom(conv, x)
+        p = S.WgradParams()
+        p.dY, p.ldY, p.Cout, p.CoutPad = dy_ptr, dy.ld, conv.out_channels, cout_pad
+        p.X, p.NB, p.IH, p.IW, p.Cin, p.ldX = x_ptr or x.ptr(), x.N, x.H, x.W, conv.in_channels, x.ld
+        p.OH, p.OW, p.sh, p.sw = OH, OW, s, s
+        taps = _taps_fwd(k, pad)
+        p.ntaps = len(taps)
+        for i, (dh, dw, _) in enumerate(taps):
+            p.dh[i], p.dw[i] = dh, dw
+        p.dW = self.rt.grad_ptr(conv.weight)
+        self._call(self.bwd, "ryolo_conv_wgrad", p)
+
+    def conv_raw(self, conv, x, want_stats):
+        """Emit the forward conv; returns (y TRef [M, Cout] raw bf16, stats tensor or None, backward-emitter)."""
+        rt = self.rt
+        pk = rt.packed(conv)
+        k, s, pad, OH, OW = self._conv_geom(conv, x)
+        cout = conv.out_channels
+        y = self.new(x.N, OH, OW, cout)
+        M = y.M
+        stats = None
+        if want_stats:
+            rows = S.I()
+            hip.call("ryolo_conv_gemm_stats_rows", M, cout, rows)
+            stats = self.f32(rows.value, 2, cout)
+        epi = S.EPI_STATS if want_stats else S.EPI_RAW
+        self._gemm(self.fwd, x, x.ptr(), pk["wf"], cout, k * k, conv.in_channels, OH, OW, s, [(_taps_fwd(k, pad), 0, 0)], epi, y.ptr(),
+                   y.ld, stats=stats)
+
+        def backward(need_dx=True):
+            self._wgrad(conv, y, y.gptr(), cout, x)
+            if need_dx:
+                self._dgrad(conv, pk, y, y.gptr(), cout, x)
+        return y, stats, backward
+
+    def stem_raw(self, conv, want_stats):
+        """First layer (Cin=3): explicit im2col of the fp32 NCHW image + single-tap GEMM (K padded to a multiple of 32)."""
+        rt = self.rt
+        pk = rt.packed(conv)
+        k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        OH = (self.Hin + 2 * pad - k) // s + 1
+        OW = (self.Win + 2 * pad - k) // s + 1
+        kp = pk["CinP"]
+        col = self.new(self.B, OH, OW, kp)
+        self._call(self.fwd, "ryolo_im2col", self.img.data_ptr(), self.B, 3, self.Hin, self.Win, k, k, s, pad, OH, OW, kp, col.ptr())
+        cout = conv.out_channels
+        y = self.new(self.B, OH, OW, cout)
+        stats = None
+        if want_stats:
+            rows = S.I()
+            hip.call("ryolo_conv_gemm_stats_rows", y.M, cout, rows)
+            stats = self.f32(rows.value, 2, cout)
+        self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)], S.EPI_STATS if want_stats else S.EPI_RAW,
+                   y.ptr(), y.ld, stats=stats)
+
+        def backward(need_dx=False):
+            scratch = self.f32(cout, kp)
+            self.bwd.append((lambda *_a: (scratch.zero_(), 0)[1], (), "zero_scratch"))
+            p = S.WgradParams()
+            p.dY, p.ldY, p.Cout, p.CoutPad = y.gptr(), y.ld, cout, cout
+            p.X, p.NB, p.IH, p.IW, p.Cin, p.ldX = col.ptr(), col.N, col.H, col.W, kp, col.ld
+            p.OH, p.OW, p.sh, p.sw, p.ntaps = OH, OW, 1, 1, 1
+            p.dh[0], p.dw[0] = 0, 0
+            p.dW = scratch.data_ptr()
+            self._call(self.bwd, "ryolo_conv_wgrad", p)
+            self._call(self.bwd, "ryolo_unpack_wgrad", scratch.data_ptr(), cout, 3, k * k, kp, rt.grad_ptr(conv.weight))
+        return y, stats, backward
+
+    # ------------------------------------------------------------------ Conv = conv -> BN -> act (+ residual)
+    def conv_bn_act(self, conv, bn, act, x, out=None, residual=None, stem=False):
+        """model/utils.py:6-32.  x None => stem on the staged input image.  Returns the activation TRef."""
+        rt = self.rt
+        train = self.training
+        actc = S.ACT[act]
+        cout = conv.out_channels
+        y, stats, conv_bwd = (self.stem_raw(conv, train) if stem else self.conv_raw(conv, x, train))
+        co = self.f32(4, cout)
+        if train:
+            self._call(self.fwd, "ryolo_bn_finalize", stats.data_ptr(), stats.shape[0], cout, float(y.M), float(bn.eps), float(bn.momentum),
+                       bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), co.data_ptr())
+            rt.bn_counters.append(bn)
+        else:
+            self._call(self.fwd, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                       bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
+        z = out if out is not None else self.new(y.N, y.H, y.W, cout)
+        assert z.C == cout and z.M == y.M
+        p = S.BnActParams()
+        p.y1, p.ld1, p.co1 = y.ptr(), y.ld, co.data_ptr()
+        if residual is not None:
+            p.res, p.ldr = residual.ptr(), residual.ld
+        p.z, p.ldz, p.M, p.C, p.act = z.ptr(), z.ld, y.M, cout, actc
+        self._call(self.fwd, "ryolo_bn_act_fwd", p)
+        if train:
+            def backward():
+                nblk, rpb = S.I(), S.I()
+                hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
+                partial = self.f32(nblk.value, 2, cout)
+                bco = self.f32(3, cout)
+                q = S.BnActParams()
+                C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
+                q.dz, q.lddz = z.gptr(), z.ld
+                q.dy1, q.lddy1 = y.gptr(), y.ld
+                if residual is not None:
+                    q.dres, q.lddres, q.dres_accum = residual.gptr(), residual.ld, residual.grad_write_mode()
+                q.partial = partial.data_ptr()
+                self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn.weight), rt.grad_ptr(bn.bias), None, None, bco.data_ptr())
+                conv_bwd(need_dx=not stem)
+            self._pending_bwd.append(backward)
+        return z
+
+    # RepConv: silu(bn(conv3x3(x)) + bn(conv1x1(x)) [+ bn(x)])  (model/utils.py:189-215)
+    def repconv(self, rep, x):
+        if rep.rbr_identity is not None:
+            raise NotImplementedError("RepConv identity branch (c1 == c2) is not used by the reference's necks")
+        rt, train = self.rt, self.training
+        conv_a, bn_a = rep.rbr_dense[0], rep.rbr_dense[1]
+        conv_b, bn_b = rep.rbr_1x1[0], rep.rbr_1x1[1]
+        cout = conv_a.out_channels
+        ya, sa, bwd_a = self.conv_raw(conv_a, x, train)
+        yb, sb, bwd_b = self.conv_raw(conv_b, x, train)
+        coa, cob = self.f32(4, cout), self.f32(4, cout)
+        for bn, st, co, y in ((bn_a, sa, coa, ya), (bn_b, sb, cob, yb)):
+            if train:
+                self._call(self.fwd, "ryolo_bn_finalize", st.data_ptr(), st.shape[0], cout, float(y.M), float(bn.eps), float(bn.momentum),
+                           bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), co.data_ptr())
+                rt.bn_counters.append(bn)
+            else:
+                self._call(self.fwd, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                           bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
+        z = self.new(ya.N, ya.H, ya.W, cout)
+        p = S.BnActParams()
+        p.y1, p.ld1, p.co1 = ya.ptr(), ya.ld, coa.data_ptr()
+        p.y2, p.ld2, p.co2 = yb.ptr(), yb.ld, cob.data_ptr()
+        p.z, p.ldz, p.M, p.C, p.act = z.ptr(), z.ld, ya.M, cout, S.ACT["swish"]
+        self._call(self.fwd, "ryolo_bn_act_fwd", p)
+        if train:
+            def backward():
+                nblk, rpb = S.I(), S.I()
+                hip.call("ryolo_bn_act_bwd_blocks", ya.M, cout, nblk, rpb)
+                partial = self.f32(nblk.value, 3, cout)
+                bco = self.f32(3, cout)
+                q = S.BnActParams()
+                C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
+                q.dz, q.lddz = z.gptr(), z.ld
+                q.dy1, q.lddy1, q.dy2, q.lddy2 = ya.gptr(), ya.ld, yb.gptr(), yb.ld
+                q.partial = partial.data_ptr()
+                self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn_a.weight), rt.grad_ptr(bn_a.bias), rt.grad_ptr(bn_b.weight),
+                           rt.grad_ptr(bn_b.bias), bco.data_ptr())
+                bwd_a()
+                bwd_b()
+            self._pending_bwd.append(backward)
+        return z
+
+    # ------------------------------------------------------------------ pooling / upsample
+    def maxpool(self, x, k, stride, out=None):
+        pad = 0 if stride == 2 else k // 2
+        OH = (x.H + 2 * pad - k) // stride + 1
+        OW = (x.W + 2 * pad - k) // stride + 1
+        z = out if out is not None else self.new(x.N, OH, OW, x.C)
+        idx = torch.empty((x.N * OH * OW, x.C), dtype=torch.uint8, device=self.dev) if self.training else None
+        self.keep.append(idx)
+        p = S.PoolParams()
+        p.x, p.ldx, p.z, p.ldz = x.ptr(), x.ld, z.ptr(), z.ld
+        p.NB, p.H, p.W, p.C, p.k, p.stride, p.pad, p.OH, p.OW = x.N, x.H, x.W, x.C, k, stride, pad, OH, OW
+        p.idx = idx.data_ptr() if idx is not None else None
+        self._call(self.fwd, "ryolo_maxpool_fwd", p)
+        if self.training:
+            def backward():
+                q = S.PoolParams()
+                C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
+                q.dz, q.lddz, q.dx, q.lddx, q.accum = z.gptr(), z.ld, x.gptr(), x.ld, x.grad_write_mode()
+                self._call(self.bwd, "ryolo_maxpool_bwd", q)
+            self._pending_bwd.append(backward)
+        return z
+
+    def upsample(self, x, out=None):
+        z = out if out is not None else self.new(x.N, 2 * x.H, 2 * x.W, x.C)
+        p = S.UpParams()
+        p.x, p.ldx, p.z, p.ldz, p.NB, p.H, p.W, p.C = x.ptr(), x.ld, z.ptr(), z.ld, x.N, x.H, x.W, x.C
+        self._call(self.fwd, "ryolo_upsample2x_fwd", p)
+        if self.training:
+            def backward():
+                q = S.UpParams()
+                q.x, q.ldx, q.z, q.ldz, q.NB, q.H, q.W, q.C, q.accum = z.gptr(), z.ld, x.gptr(), x.ld, x.N, x.H, x.W, x.C, x.grad_write_mode()
+                self._call(self.bwd, "ryolo_upsample2x_bwd", q)
+            self._pending_bwd.append(backward)
+        return z
+
+    def copy_slice(self, x, out):
+        """Materialise an already-produced tensor into a concat slice (only needed when the producer could not be planned to
+        write there directly).  Plumbing-level strided copy; gradient flows back by accumulation."""
+        xs = x.buf.t[:, x.c0:x.c0 + x.C]
+        os_ = out.buf.t[:, out.c0:out.c0 + out.C]
+        self.fwd.append((lambda *_a: (os_.copy_(xs), 0)[1], (), "copy_slice"))
+        if self.training:
+            def backward():
+                mode = x.grad_write_mode()
+                gx = x.buf.grad_tensor()[:, x.c0:x.c0 + x.C]
+                go = out.buf.grad_tensor()[:, out.c0:out.c0 + out.C]
+                self.bwd.append(((lambda *_a: (gx.add_(go), 0)[1]) if mode else (lambda *_a: (gx.copy_(go), 0)[1]), (), "copy_slice_bwd"))
+            self._pending_bwd.append(backward)
+        return out
+
+    # ------------------------------------------------------------------ detection head
+    def head(self, conv, x, na, attrs, implicit_a=None, implicit_m=None):
+        """[ImplicitA ->] 1x1 conv + bias [-> ImplicitM] -> fp32 [B, na, gs, gs, attrs]  (model/neck.py:173-186,201,208,215;
+        the view/permute of model/yololayer.py:25 is fused into the store)."""
+        rt = self.rt
+        pk = rt.packed(conv)
+        cout, coutp = conv.out_channels, pk["CoutP"]
+        assert cout == na * attrs
+        xin = x
+        if implicit_a is not None:
+            xin = self.new(x.N, x.H, x.W, x.C)
+            self._call(self.fwd, "ryolo_chan_add", x.ptr(), x.ld, implicit_a.data_ptr(), x.M, x.C, xin.ptr(), xin.ld)
+        M = x.M
+        pre = self.f32(M, coutp)
+        self._gemm(self.fwd, xin, xin.ptr(), pk["wf"], cout, 1, conv.in_channels, x.H, x.W, 1, [([(0, 0, 0)], 0, 0)], S.EPI_F32_BIAS,
+                   pre.data_ptr(), coutp, bias=conv.bias.data_ptr())
+        out = self.f32(x.N, na, x.H, x.W, attrs)
+        mptr = implicit_m.data_ptr() if implicit_m is not None else None
+        self._call(self.fwd, "ryolo_head_finish_fwd", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr())
+        rec = dict(out=out, dout=None)
+        self.heads.append(rec)
+        if self.training:
+            dout = self.f32(x.N, na, x.H, x.W, attrs)
+            rec["dout"] = dout
+            dpre = torch.empty((M, coutp), dtype=BF16, device=self.dev)
+            self.keep.append(dpre)
+            nblk = (M + 63) // 64
+            scratch = self.f32(max(nblk * cout, ((M + 255) // 256) * max(coutp, x.C)))
+
+            class _G:                      # geometry shim so dpre can be used as a gathered operand
+                N, H, W, ld = x.N, x.H, x.W, coutp
+
+            def backward():
+                self._call(self.bwd, "ryolo_head_finish_bwd", dout.data_ptr(), pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs,
+                           dpre.data_ptr(), coutp, rt.grad_ptr(implicit_m) if implicit_m is not None else None, scratch.data_ptr())
+                self._call(self.bwd, "ryolo_colsum_bf16", dpre.data_ptr(), coutp, M, cout, rt.grad_ptr(conv.bias), scratch.data_ptr())
+                self._wgrad(conv, _G, dpre.data_ptr(), coutp, xin)
+                self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, xin)
+                if implicit_a is not None:
+                    self._call(self.bwd, "ryolo_colsum_bf16", xin.gptr(), xin.ld, M, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
+                    # d(x + a)/dx = 1: route the gradient through by copying the slice (x has a single consumer here)
+                    mode = x.grad_write_mode()
+                    assert mode == 0
+                    xg, xing = x, xin
+                    self.bwd.append((lambda *_a: (xg.buf.grad_tensor()[:, xg.c0:xg.c0 + xg.C].copy_(xing.buf.grad_tensor()[:, xing.c0:xing.c0 + xing.C]), 0)[1],
+                                     (), "implicit_a_grad_copy"))
+            self._pending_bwd.append(backward)
+        return out
+
+    # ------------------------------------------------------------------ plan assembly
+    def begin(self):
+        self._pending_bwd = []
+
+    def finish(self):
+        """Backward tape = the per-op backward emitters in reverse forward order (plan-time accumulate/store resolution
+        relies on this order)."""
+        for emit in reversed(self._pending_bwd):
+            emit()
+        self._pending_bwd = None

@@ -1,0 +1,166 @@
+"""Per-model device runtime: flat fp32 parameter / gradient / momentum buffers, bf16 packed weights, cached execution
+plans, and the autograd bridge (ONE autograd node for the whole backbone + neck instead of ~600)."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from . import structs as S
+from .graph import Graph
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Runtime:
+    def __init__(self, model, device):
+        hip.lib()
+        S.check_layouts()
+        self.model, self.device = model, device
+        self.bn_counters = []
+        self._flatten()
+        self._packed = {}
+        self._pack_table = None
+        self._graphs = {}
+        self.momentum_buf = None
+
+    # ------------------------------------------------------------------ parameters
+    def _flatten(self):
+        """Re-home every parameter into one flat fp32 buffer (views keep the nn.Parameter objects and state_dict keys)."""
+        params = [p for p in self.model.parameters()]
+        offs, total = [], 0
+        for p in params:
+            if p.dtype != torch.float32:
+                raise RuntimeError("ryolov4_amd: parameters must be float32 masters (bf16 copies are made internally)")
+            offs.append(total)
+            total += _round_up(p.numel(), 64)               # 256-byte aligned slices
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._pslice = {}
+        for p, o in zip(params, offs):
+            v = self.flat[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self._pslice[id(p)] = (o, p.numel(), p)
+        self.params = params
+        self.n_flat = total
+        # one flat counter tensor for every BatchNorm's num_batches_tracked (a single add per step)
+        bns = [m for m in self.model.modules() if isinstance(m, nn.BatchNorm2d)]
+        self.nbt = torch.zeros(len(bns), dtype=torch.int64, device=self.device)
+        for i, m in enumerate(bns):
+            self.nbt[i] = m.num_batches_tracked.to(self.device)
+            m.num_batches_tracked.data = self.nbt[i]
+
+    def check_resident(self):
+        for o, n, p in self._pslice.values():
+            if p.data_ptr() != self.flat.data_ptr() + 4 * o:
+                return False
+        return True
+
+    def grad_ptr(self, p):
+        o, n, _ = self._pslice[id(p)]
+        return self.gflat.data_ptr() + 4 * o
+
+    def grad_view(self, p):
+        o, n, _ = self._pslice[id(p)]
+        return self.gflat[o:o + n].view(p.shape)
+
+    def prepare_grads(self):
+        """Called at the start of every backward: parameters whose .grad is not (a view of) the flat gradient buffer are
+        (re)attached; a freshly attached slice starts from zero (== optimizer.zero_grad(set_to_none=True) semantics),
+        an attached one keeps accumulating (== the reference's gradient accumulation, train.py:198-202)."""
+        fresh = [p for p in self.params if p.grad is None or p.grad.data_ptr() != self.grad_ptr(p)]
+        if len(fresh) == len(self.params):
+            self.gflat.zero_()
+        else:
+            for p in fresh:
+                self.grad_view(p).zero_()
+        for p in fresh:
+            if p.grad is not None:
+                raise RuntimeError("ryolov4_amd: a parameter's .grad was replaced by a foreign tensor")
+            p.grad = self.grad_view(p)
+
+    # ------------------------------------------------------------------ packed bf16 weights
+    def packed(self, conv):
+        pk = self._packed.get(id(conv))
+        if pk is None:
+            cout, cin = conv.out_channels, conv.in_channels
+            taps = conv.kernel_size[0] * conv.kernel_size[1]
+            small = cin % 32 != 0                               # stem: K = taps*cin padded, single tap
+            cinp = _round_up(taps * cin, 32) if small else cin
+            coutp = _round_up(cout, 32)
+            wf = torch.zeros((cout, 1 if small else taps, cinp), dtype=torch.bfloat16, device=self.device)
+            wd = None if small else torch.zeros((cin, taps, coutp), dtype=torch.bfloat16, device=self.device)
+            pk = dict(conv=conv, wf=wf, wd=wd, Cout=cout, Cin=cin, taps=taps, CinP=cinp, CoutP=coutp)
+            self._packed[id(conv)] = pk
+            self._pack_table = None
+        return pk
+
+    def pack(self):
+        """fp32 masters -> bf16 GEMM images ([Cout][tap][Cin] for fwd/wgrad, [Cin][tap][Cout] for dgrad); one launch."""
+        if self._pack_table is None:
+            ents = list(self._packed.values())
+            arr = (S.PackEntry * len(ents))()
+            start = 0
+            for e, pk in zip(arr, ents):
+                e.src, e.wf = pk["conv"].weight.data_ptr(), pk["wf"].data_ptr()
+                e.wd = pk["wd"].data_ptr() if pk["wd"] is not None else None
+                e.Cout, e.Cin, e.taps, e.CinP, e.CoutP, e.start = pk["Cout"], pk["Cin"], pk["taps"], pk["CinP"], pk["CoutP"], start
+                start += pk["wf"].numel()
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._pack_table = (host.to(self.device), len(ents), start)
+        tab, n, total = self._pack_table
+        hip.call("ryolo_pack_weights", tab.data_ptr(), n, total, hip.stream())
+
+    # ------------------------------------------------------------------ plans
+    def graph(self, B, H, W, training):
+        key = (B, H, W, bool(training))
+        g = self._graphs.get(key)
+        if g is None:
+            if not self.check_resident():
+                raise RuntimeError("ryolov4_amd: parameters were moved after the first forward; build a new Yolo/runtime")
+            g = Graph(self, B, H, W, training)
+            g.begin()
+            self.model._emit(g)
+            g.finish()
+            self._graphs[key] = g
+        return g
+
+    # ------------------------------------------------------------------ fused optimizer (bench / DP path)
+    def sgd_step(self, lr, momentum=0.937, grad_scale=1.0):
+        """torch.optim.SGD(lr, momentum=0.937, nesterov=True) of train.py:156 as ONE kernel over the flat buffers."""
+        if self.momentum_buf is None:
+            self.momentum_buf = torch.zeros_like(self.flat)
+        hip.call("ryolo_sgd_nesterov", self.flat.data_ptr(), self.gflat.data_ptr(), self.momentum_buf.data_ptr(), self.n_flat, float(lr),
+                 float(momentum), float(grad_scale), hip.stream())
+
+
+class NetFunction(torch.autograd.Function):
+    """imgs -> 3 head maps [B, na, gs, gs, attrs] fp32.  The parameters are not autograd inputs: their gradients are
+    accumulated by the backward tape straight into Runtime.gflat, which `.grad` of every parameter aliases."""
+
+    @staticmethod
+    def forward(ctx, imgs, anchor, rt, g):
+        g.img.copy_(imgs)
+        rt.pack()
+        g.run(g.fwd)
+        if g.training:
+            rt.nbt += 1
+        ctx.rt, ctx.g = rt, g
+        return tuple(h["out"].detach() for h in g.heads)      # fresh tensor objects over the plan's output buffers
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rt, g = ctx.rt, ctx.g
+        rt.prepare_grads()
+        for h, go in zip(g.heads, grads):
+            if go is None:
+                h["dout"].zero_()
+            else:
+                h["dout"].copy_(go)
+        g.run(g.bwd)
+        if rt.model._grad_hook is not None:
+            rt.model._grad_hook(rt)
+        return None, None, None, None

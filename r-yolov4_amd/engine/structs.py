@@ -1,0 +1,102 @@
+"""ctypes mirrors of the POD parameter blocks of csrc/conv.hip, elementwise.hip and loss.hip (checked against the
+library's own sizeof at load time) and the registration of their entry points with hip.py."""
+import ctypes as C
+
+from .. import hip
+
+P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+MAX_TAPS = 9
+EPI_RAW, EPI_STATS, EPI_AFFINE_ACT, EPI_F32_BIAS, EPI_ACCUM = range(5)
+ACT = {"linear": 0, "mish": 1, "leaky": 2, "swish": 3}
+
+
+class TapClass(C.Structure):
+    _fields_ = [("ntaps", I), ("oh_add", I), ("ow_add", I), ("dh", C.c_byte * MAX_TAPS), ("dw", C.c_byte * MAX_TAPS),
+                ("widx", C.c_byte * MAX_TAPS)]
+
+
+class ConvGemmParams(C.Structure):
+    _fields_ = [("A", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldA", I),
+                ("W", P), ("Nout", I), ("wtaps", I), ("OH", I), ("OW", I), ("sh", I), ("sw", I),
+                ("oh_mul", I), ("ow_mul", I), ("OHf", I), ("OWf", I), ("nclasses", I), ("cls", TapClass * 4),
+                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [("dY", P), ("ldY", I), ("Cout", I), ("CoutPad", I),
+                ("X", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldX", I),
+                ("OH", I), ("OW", I), ("sh", I), ("sw", I), ("ntaps", I), ("dh", C.c_byte * MAX_TAPS), ("dw", C.c_byte * MAX_TAPS),
+                ("dW", P), ("splitk", I), ("kchunk", L)]
+
+
+class BnActParams(C.Structure):
+    _fields_ = [("y1", P), ("ld1", I), ("co1", P), ("y2", P), ("ld2", I), ("co2", P), ("res", P), ("ldr", I),
+                ("z", P), ("ldz", I), ("M", L), ("C", I), ("act", I),
+                ("dz", P), ("lddz", I), ("dy1", P), ("lddy1", I), ("dy2", P), ("lddy2", I),
+                ("dres", P), ("lddres", I), ("dres_accum", I), ("partial", P), ("bco", P), ("rows_per_block", I)]
+
+
+class PoolParams(C.Structure):
+    _fields_ = [("x", P), ("ldx", I), ("z", P), ("ldz", I), ("NB", I), ("H", I), ("W", I), ("C", I), ("k", I), ("stride", I),
+                ("pad", I), ("OH", I), ("OW", I), ("idx", P), ("dz", P), ("lddz", I), ("dx", P), ("lddx", I), ("accum", I)]
+
+
+class UpParams(C.Structure):
+    _fields_ = [("x", P), ("ldx", I), ("z", P), ("ldz", I), ("NB", I), ("H", I), ("W", I), ("C", I), ("accum", I)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [("src", P), ("wf", P), ("wd", P), ("Cout", I), ("Cin", I), ("taps", I), ("CinP", I), ("CoutP", I), ("pad_", I),
+                ("start", L)]
+
+
+class LossParams(C.Structure):
+    _fields_ = [("mode", I), ("nc", I), ("na", I), ("batch", I), ("nt", I), ("tcols", I), ("targets", P),
+                ("head", P * 3), ("grad", P * 3), ("gs", I * 3), ("anchors", (F * 3 * 18) * 3),
+                ("box", F), ("obj", F), ("cls", F), ("theta_gain", F), ("obj_pw", F), ("cls_pw", F),
+                ("ws", P), ("ws_bytes", Z), ("items", P), ("compute_grad", I)]
+
+
+_PTR = C.POINTER
+for _name, _sig in {
+    "ryolo_conv_gemm": [_PTR(ConvGemmParams), P],
+    "ryolo_conv_gemm_stats_rows": [L, I, _PTR(I)],
+    "ryolo_conv_wgrad": [_PTR(WgradParams), P],
+    "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
+    "ryolo_bn_eval_coeffs": [P, P, P, P, F, I, P, P],
+    "ryolo_bn_act_fwd": [_PTR(BnActParams), P],
+    "ryolo_bn_act_bwd_blocks": [L, I, _PTR(I), _PTR(I)],
+    "ryolo_bn_act_bwd": [_PTR(BnActParams), P, P, P, P, P, P],
+    "ryolo_maxpool_fwd": [_PTR(PoolParams), P],
+    "ryolo_maxpool_bwd": [_PTR(PoolParams), P],
+    "ryolo_upsample2x_fwd": [_PTR(UpParams), P],
+    "ryolo_upsample2x_bwd": [_PTR(UpParams), P],
+    "ryolo_im2col": [P, I, I, I, I, I, I, I, I, I, I, I, P, P],
+    "ryolo_head_finish_fwd": [P, I, P, I, I, I, I, P, P],
+    "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P],
+    "ryolo_chan_add": [P, I, P, L, I, P, I, P],
+    "ryolo_colsum_bf16": [P, I, L, I, P, P, P],
+    "ryolo_pack_weights": [P, I, L, P],
+    "ryolo_unpack_wgrad": [P, I, I, I, I, P, P],
+    "ryolo_sgd_nesterov": [P, P, P, L, F, F, F, P],
+    "ryolo_struct_sizes": [_PTR(I)],
+    "ryolo_loss_workspace_bytes": [_PTR(LossParams), _PTR(Z)],
+    "ryolo_loss": [_PTR(LossParams), P],
+}.items():
+    hip.register(_name, _sig)
+
+_checked = False
+
+
+def check_layouts():
+    """Fail loudly if a ctypes mirror drifted from the C struct it shadows."""
+    global _checked
+    if _checked:
+        return
+    sizes = (I * 8)()
+    hip.call("ryolo_struct_sizes", sizes)
+    want = [BnActParams, PoolParams, UpParams, PackEntry, ConvGemmParams, WgradParams, LossParams, TapClass]
+    for k, t in enumerate(want):
+        if sizes[k] != C.sizeof(t):
+            raise RuntimeError(f"ryolov4_amd: struct layout mismatch for {t.__name__}: C {sizes[k]} vs ctypes {C.sizeof(t)}")
+    _checked = True

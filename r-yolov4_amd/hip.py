@@ -40,6 +40,10 @@ def build(verbose=False):
 
 def register(name, argtypes):
     _SIGNATURES[name] = argtypes
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
 
 
 def lib():
@@ -50,6 +54,7 @@ def lib():
                 f"ryolov4_amd: HIP library not built ({LIB_PATH}). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "there is no CPU/PyTorch fallback for the hot path.")
         L = ctypes.CDLL(LIB_PATH)
+        from .engine import structs  # noqa: F401  (registers the conv-stack / loss entry points)
         for name, sig in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError => header/library mismatch, fail loudly
             fn.argtypes = sig
@@ -59,6 +64,7 @@ def lib():
 
 
 def exported_symbols():
+    from .engine import structs  # noqa: F401  (registers the conv-stack / loss entry points)
     return sorted(_SIGNATURES)
 
 

@@ -1,0 +1,131 @@
+"""Drop-in for the reference's lib/loss.py: ComputeCSLLoss (:153-331) and ComputeKFIoULoss (:334-492) on the fused HIP
+loss kernels (csrc/loss.hip).  Same constructor `(model, hyp)`, same `.loss_items` dict (present before the first call,
+same keys, python floats), same `__call__(outputs, target) -> (loss[1], loss_items)`; works under torch.no_grad() and
+with zero targets.  One device->host read per call (the reference does 4-5); pass `sync_items=False` to skip even that
+(loss_items then holds 0-d device tensors) — the training benchmark uses this.
+FocalLoss (lib/loss.py:10-33) is inactive in the reference's configuration (fl_gamma: 0.0, data/hyp.yaml:12); a positive
+gamma raises NotImplementedError here instead of silently computing something else.
+"""
+import torch
+
+from .. import hip
+from ..engine import structs as S
+from .general import norm_angle, xywhr2xywhrsigma  # noqa: F401  (re-exported like the reference's import at lib/loss.py:7)
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, targets, o0, o1, o2):
+        grads, items = owner._run([o0, o1, o2], targets, True)
+        ctx.grads = grads
+        owner._last_items = items
+        return items[4:5].clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        g = ctx.grads
+        return (None, None) + tuple(gi * go for gi in g)
+
+
+class _ComputeLossBase:
+    MODE = None
+    KEYS = ()
+
+    def __init__(self, model, hyp):
+        if hyp.get("fl_gamma", 0.0) > 0:
+            raise NotImplementedError("FocalLoss (fl_gamma > 0) is not implemented on the HIP path; the reference runs fl_gamma = 0.0")
+        self.hyp = {k: float(hyp[k]) for k in ("box", "obj", "cls", "obj_pw", "cls_pw")}
+        self.lambda_theta = 0.5                     # lib/loss.py:160
+        self.anchors_list = model.anchors
+        self.na = len(model.anchors[0])
+        self.nl = 3
+        self.nc = model.nc
+        self.loss_items = {k: 0 for k in self.KEYS}
+        self._ws = None
+        self._items = None
+        self._last_items = None
+
+    def _params(self, outputs, targets, compute_grad, grads):
+        p = S.LossParams()
+        p.mode, p.nc, p.na = self.MODE, self.nc, self.na
+        p.batch = outputs[0].shape[0]
+        p.nt = targets.shape[0]
+        p.tcols = targets.shape[1] if targets.dim() == 2 else 0
+        p.targets = targets.data_ptr() if p.nt else None
+        for i in range(3):
+            p.head[i] = outputs[i].data_ptr()
+            p.grad[i] = grads[i].data_ptr() if compute_grad else None
+            p.gs[i] = outputs[i].shape[2]
+            for a, an in enumerate(self.anchors_list[i]):
+                for k in range(len(an)):
+                    p.anchors[i][a][k] = float(an[k])
+        p.box, p.obj, p.cls = self.hyp["box"], self.hyp["obj"], self.hyp["cls"]
+        p.theta_gain, p.obj_pw, p.cls_pw = self.lambda_theta, self.hyp["obj_pw"], self.hyp["cls_pw"]
+        p.compute_grad = 1 if compute_grad else 0
+        return p
+
+    def _run(self, outputs, targets, compute_grad):
+        S.check_layouts()
+        dev = outputs[0].device
+        attrs = self.nc + (185 if self.MODE == 0 else 6)
+        outs = []
+        for o in outputs:
+            hip.require_device(o, "loss")
+            if o.dim() != 5 or o.shape[1] != self.na or o.shape[4] != attrs or o.shape[2] != o.shape[3]:
+                raise RuntimeError("loss: expected head maps [B, na, gs, gs, attrs], got {}".format(tuple(o.shape)))
+            outs.append(o.detach().float().contiguous())
+        targets = targets.to(dev).float().contiguous()
+        grads = [torch.empty_like(o) for o in outs] if compute_grad else [None] * 3
+        items = torch.empty(5, dtype=torch.float32, device=dev)
+        p = self._params(outs, targets, compute_grad, grads)
+        self._last_shape, self._last_gs = (p.nt, self.na, p.batch), [o.shape[2] for o in outs]
+        need = S.Z()
+        hip.call("ryolo_loss_workspace_bytes", p, need)
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != dev:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        p.ws, p.ws_bytes, p.items = self._ws.data_ptr(), self._ws.numel(), items.data_ptr()
+        hip.call("ryolo_loss", p, hip.stream())
+        return grads, items
+
+    def debug_matches(self):
+        """Test hook: the (b, a, gj, gi, cls, tidx, cell) records of the last call, per scale, read back from the workspace
+        (layout = carve() in csrc/loss.hip)."""
+        al = lambda v: (v + 255) & ~255
+        nt, na, B = self._last_shape
+        out, off = [], 0
+        ws = self._ws.cpu().numpy()
+        for gs in self._last_gs:
+            cap, cells = 5 * na * nt, B * na * gs * gs
+            nbm = (cap + 3) // 4
+            nbo = max(1, min(2048, (cells + 1023) // 1024))
+            cnt = int(ws[off:off + 4].view("int32")[0]); off += 256
+            rec = ws[off:off + cap * 32].view("int32").reshape(-1, 8)[:cnt].copy(); off += al(cap * 32)
+            off += al(cap * 32) + al(cells * 4) * 2 + al(max(nbm, 1) * 16) + al(nbo * 4)
+            out.append(rec.astype("int64"))
+        return out
+
+    def __call__(self, outputs, target, sync_items=True):
+        needs_grad = torch.is_grad_enabled() and any(o.requires_grad for o in outputs)
+        if needs_grad:
+            loss = _LossFn.apply(self, target, *outputs)
+            items = self._last_items
+        else:
+            _, items = self._run(list(outputs), target, False)
+            loss = items[4:5].clone()
+        names = ("reg_loss", "conf_loss", "cls_loss", "theta_loss", "total_loss")
+        if sync_items:
+            vals = items.tolist()                      # the single device->host read of the step
+            self.loss_items.update({k: vals[names.index(k)] for k in self.KEYS})
+        else:
+            self.loss_items.update({k: items[names.index(k)] for k in self.KEYS})
+        return loss, self.loss_items
+
+
+class ComputeCSLLoss(_ComputeLossBase):
+    MODE = 0
+    KEYS = ("reg_loss", "theta_loss", "conf_loss", "cls_loss", "total_loss")      # lib/loss.py:183-189
+
+
+class ComputeKFIoULoss(_ComputeLossBase):
+    MODE = 1
+    KEYS = ("reg_loss", "conf_loss", "cls_loss", "total_loss")                    # lib/loss.py:361-366

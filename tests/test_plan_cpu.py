@@ -1,0 +1,50 @@
+"""CPU tests of the host logic of the static-graph engine: plans for every ver x mode build without a GPU (buffers on
+CPU, nothing launched), the module tree keeps the reference's state_dict ABI, and gradient-write resolution is sane."""
+import pytest
+import torch
+
+from oracle import ref_model
+from ryolov4_amd.engine.runtime import Runtime
+from ryolov4_amd.model.yolo import Yolo
+from ryolov4_amd.synth import CFG
+
+
+@pytest.mark.parametrize("ver", ["yolov4", "yolov5", "yolov7"])
+@pytest.mark.parametrize("mode", ["csl", "kfiou"])
+def test_state_dict_abi_matches_reference_layout(ver, mode):
+    ours = Yolo(2, CFG, mode, ver).state_dict()
+    ref = ref_model.Yolo(2, CFG, mode, ver).state_dict()          # pinned against the imported reference by make_golden.py
+    assert list(ours.keys()) == list(ref.keys())
+    for k in ours:
+        assert ours[k].shape == ref[k].shape, k
+
+
+@pytest.mark.parametrize("ver", ["yolov4", "yolov5", "yolov7"])
+@pytest.mark.parametrize("mode,nc", [("csl", 2), ("kfiou", 16)])
+@pytest.mark.parametrize("training", [True, False])
+def test_plan_builds(ver, mode, nc, training):
+    m = Yolo(nc, CFG, mode, ver)
+    m.train(training)
+    rt = Runtime(m, torch.device("cpu"))
+    g = rt.graph(2, 64, 64, training)
+    na = 3 if mode == "csl" else 18
+    attrs = nc + (185 if mode == "csl" else 6)
+    assert [tuple(h["out"].shape) for h in g.heads] == [(2, na, 8, 8, attrs), (2, na, 4, 4, attrs), (2, na, 2, 2, attrs)]
+    nconv = sum(1 for x in m.modules() if isinstance(x, torch.nn.Conv2d))
+    names = [n for _, _, n in g.fwd]
+    assert names.count("ryolo_conv_gemm") == nconv
+    if training:
+        bnames = [n for _, _, n in g.bwd]
+        assert bnames.count("ryolo_conv_wgrad") == nconv
+        assert bnames.count("ryolo_conv_gemm") == nconv - 1          # every conv but the stem has a data gradient
+        for p in m.parameters():
+            assert rt.grad_view(p).shape == p.shape
+    else:
+        assert g.bwd == []
+
+
+def test_unknown_mode_raises_like_reference():
+    with pytest.raises(NotImplementedError):
+        Yolo(2, CFG, "smooth_l1", "yolov4")
+    with pytest.raises(RuntimeError):
+        Yolo(2, CFG, "csl", "yolov4")(torch.zeros(1, 3, 64, 64), True)          # CPU tensor: no fallback
