@@ -111,9 +111,10 @@ int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* run
 /* z = act(bn1(y1) [+ bn2(y2)]) [+ residual]   (Conv / RepConv / Bottleneck of model/utils.py) */
 int ryolo_bn_act_fwd(const BnActParams* p, ryolo_stream_t stream);
 int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_per_block);
-/* backward of the above: dy1 [, dy2] [, dres], dgamma/dbeta accumulated; p->partial needs nblk*K*C floats, bco 3*C */
+/* backward of the above: dy1 [, dy2] [, dres], dgamma/dbeta accumulated; p->partial needs nblk*K*C floats, bco 3*C.
+ * frozen=1: the coefficients came from ryolo_bn_eval_coeffs (fixed affine map, no batch-statistics coupling). */
 int ryolo_bn_act_bwd(const BnActParams* p, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
-                     ryolo_stream_t stream);
+                     int frozen, ryolo_stream_t stream);
 
 int ryolo_maxpool_fwd(const PoolParams* p, ryolo_stream_t stream);      /* nn.MaxPool2d k2 s2 / k5,9,13 s1 (utils.py:152,231-233) */
 int ryolo_maxpool_bwd(const PoolParams* p, ryolo_stream_t stream);

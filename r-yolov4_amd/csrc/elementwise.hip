@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
 }
 
 // backward finalize: sums over blocks (double) -> coefficients + dgamma/dbeta accumulation
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int K, int C, double count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int K, int C, double count, int frozen,
                                                                float* __restrict__ bco /*[K][C]*/, float* __restrict__ dgamma1,
                                                                float* __restrict__ dbeta1, float* __restrict__ dgamma2,
                                                                float* __restrict__ dbeta2)
@@ -200,9 +200,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (rl == 0 && c < C) {
         for (int k = 1; k < 32; k++)
             for (int q = 0; q < K; q++) s[q] += red[q][k * 32 + cl];
-        bco[0 * C + c] = (float)(s[0] / count);
-        bco[1 * C + c] = (float)(s[1] / count);
-        if (K == 3) bco[2 * C + c] = (float)(s[2] / count);
+        // frozen statistics (eval-mode BatchNorm used as a fixed affine map): no coupling through the batch mean/variance
+        bco[0 * C + c] = frozen ? 0.f : (float)(s[0] / count);
+        bco[1 * C + c] = frozen ? 0.f : (float)(s[1] / count);
+        if (K == 3) bco[2 * C + c] = frozen ? 0.f : (float)(s[2] / count);
         if (dgamma1) { dgamma1[c] += (float)s[1]; dbeta1[c] += (float)s[0]; }
         if (K == 3 && dgamma2) { dgamma2[c] += (float)s[2]; dbeta2[c] += (float)s[0]; }
     }
@@ -585,7 +586,7 @@ extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_pe
 
 // reduce -> finalize -> apply; `partial` needs nblk*K*C floats, bco needs 3*C floats
 extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
-                                hipStream_t stream)
+                                int frozen, hipStream_t stream)
 {
     if (!pp || check_bnact(*pp) || !pp->dz || !pp->dy1 || !pp->partial || !bco) return RY_ERR_ARG;
     BnActParams p = *pp;
@@ -597,7 +598,7 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     const int K = p.y2 ? 3 : 2;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, p.partial, nblk, K, p.C,
-                       (double)p.M, bco, dgamma1, dbeta1, dgamma2, dbeta2);
+                       (double)p.M, frozen, bco, dgamma1, dbeta1, dgamma2, dbeta2);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(p.M * (p.C >> 3))), dim3(256), 0, stream, p);
     RY_CHECK_LAUNCH();
     return RY_OK;

@@ -85,8 +85,10 @@ def _fill_class(tc, taps, oh_add=0, ow_add=0):
 
 
 class Graph:
-    def __init__(self, rt, B, Hin, Win, training):
+    def __init__(self, rt, B, Hin, Win, training, frozen=False):
         self.rt, self.B, self.Hin, self.Win, self.training = rt, B, Hin, Win, training
+        self.frozen = frozen                   # backward tape with eval-mode (running-statistics) BatchNorm
+        self.batch_stats = training and not frozen
         self.dev = rt.device
         self.fwd, self.bwd = [], []            # tapes: lists of (fn_name, args...) closures
         self.keep = []                         # tensors/structs kept alive
@@ -244,11 +246,12 @@ class Graph:
         """model/utils.py:6-32.  x None => stem on the staged input image.  Returns the activation TRef."""
         rt = self.rt
         train = self.training
+        bstat = self.batch_stats
         actc = S.ACT[act]
         cout = conv.out_channels
-        y, stats, conv_bwd = (self.stem_raw(conv, train) if stem else self.conv_raw(conv, x, train))
+        y, stats, conv_bwd = (self.stem_raw(conv, bstat) if stem else self.conv_raw(conv, x, bstat))
         co = self.f32(4, cout)
-        if train:
+        if bstat:
             self._call(self.fwd, "ryolo_bn_finalize", stats.data_ptr(), stats.shape[0], cout, float(y.M), float(bn.eps), float(bn.momentum),
                        bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), co.data_ptr())
             rt.bn_counters.append(bn)
@@ -257,6 +260,7 @@ class Graph:
                        bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
         z = out if out is not None else self.new(y.N, y.H, y.W, cout)
         assert z.C == cout and z.M == y.M
+        self.debug[id(conv)] = (y, z, x)
         p = S.BnActParams()
         p.y1, p.ld1, p.co1 = y.ptr(), y.ld, co.data_ptr()
         if residual is not None:
@@ -276,7 +280,7 @@ class Graph:
                 if residual is not None:
                     q.dres, q.lddres, q.dres_accum = residual.gptr(), residual.ld, residual.grad_write_mode()
                 q.partial = partial.data_ptr()
-                self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn.weight), rt.grad_ptr(bn.bias), None, None, bco.data_ptr())
+                self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn.weight), rt.grad_ptr(bn.bias), None, None, bco.data_ptr(), 1 if self.frozen else 0)
                 conv_bwd(need_dx=not stem)
             self._pending_bwd.append(backward)
         return z
@@ -285,15 +289,15 @@ class Graph:
     def repconv(self, rep, x):
         if rep.rbr_identity is not None:
             raise NotImplementedError("RepConv identity branch (c1 == c2) is not used by the reference's necks")
-        rt, train = self.rt, self.training
+        rt, train, bstat = self.rt, self.training, self.batch_stats
         conv_a, bn_a = rep.rbr_dense[0], rep.rbr_dense[1]
         conv_b, bn_b = rep.rbr_1x1[0], rep.rbr_1x1[1]
         cout = conv_a.out_channels
-        ya, sa, bwd_a = self.conv_raw(conv_a, x, train)
-        yb, sb, bwd_b = self.conv_raw(conv_b, x, train)
+        ya, sa, bwd_a = self.conv_raw(conv_a, x, bstat)
+        yb, sb, bwd_b = self.conv_raw(conv_b, x, bstat)
         coa, cob = self.f32(4, cout), self.f32(4, cout)
         for bn, st, co, y in ((bn_a, sa, coa, ya), (bn_b, sb, cob, yb)):
-            if train:
+            if bstat:
                 self._call(self.fwd, "ryolo_bn_finalize", st.data_ptr(), st.shape[0], cout, float(y.M), float(bn.eps), float(bn.momentum),
                            bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), co.data_ptr())
                 rt.bn_counters.append(bn)
@@ -318,7 +322,7 @@ class Graph:
                 q.dy1, q.lddy1, q.dy2, q.lddy2 = ya.gptr(), ya.ld, yb.gptr(), yb.ld
                 q.partial = partial.data_ptr()
                 self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn_a.weight), rt.grad_ptr(bn_a.bias), rt.grad_ptr(bn_b.weight),
-                           rt.grad_ptr(bn_b.bias), bco.data_ptr())
+                           rt.grad_ptr(bn_b.bias), bco.data_ptr(), 1 if self.frozen else 0)
                 bwd_a()
                 bwd_b()
             self._pending_bwd.append(backward)

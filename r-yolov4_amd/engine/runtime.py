@@ -115,13 +115,13 @@ class Runtime:
         hip.call("ryolo_pack_weights", tab.data_ptr(), n, total, hip.stream())
 
     # ------------------------------------------------------------------ plans
-    def graph(self, B, H, W, training):
-        key = (B, H, W, bool(training))
+    def graph(self, B, H, W, training, frozen=False):
+        key = (B, H, W, bool(training), bool(frozen))
         g = self._graphs.get(key)
         if g is None:
             if not self.check_resident():
                 raise RuntimeError("ryolov4_amd: parameters were moved after the first forward; build a new Yolo/runtime")
-            g = Graph(self, B, H, W, training)
+            g = Graph(self, B, H, W, training, frozen)
             g.begin()
             self.model._emit(g)
             g.finish()
@@ -146,7 +146,7 @@ class NetFunction(torch.autograd.Function):
         g.img.copy_(imgs)
         rt.pack()
         g.run(g.fwd)
-        if g.training:
+        if g.batch_stats:
             rt.nbt += 1
         ctx.rt, ctx.g = rt, g
         return tuple(h["out"].detach() for h in g.heads)      # fresh tensor objects over the plan's output buffers

@@ -66,7 +66,7 @@ for _name, _sig in {
     "ryolo_bn_eval_coeffs": [P, P, P, P, F, I, P, P],
     "ryolo_bn_act_fwd": [_PTR(BnActParams), P],
     "ryolo_bn_act_bwd_blocks": [L, I, _PTR(I), _PTR(I)],
-    "ryolo_bn_act_bwd": [_PTR(BnActParams), P, P, P, P, P, P],
+    "ryolo_bn_act_bwd": [_PTR(BnActParams), P, P, P, P, P, I, P],
     "ryolo_maxpool_fwd": [_PTR(PoolParams), P],
     "ryolo_maxpool_bwd": [_PTR(PoolParams), P],
     "ryolo_upsample2x_fwd": [_PTR(UpParams), P],

@@ -253,6 +253,7 @@ class Yolo(nn.Module):
         self._rt = None
         self._grad_hook = None                  # set by parallel.DataParallel: all-reduce of the flat gradient buffer
         self._flag = torch.zeros(1, requires_grad=True)
+        self.frozen_bn = False                  # True: BatchNorm keeps its running statistics but gradients still flow (fine-tuning)
 
     # model/yolo.py:54-72
     @staticmethod
@@ -285,7 +286,7 @@ class Yolo(nn.Module):
         if i.dim() != 4 or i.size(1) != 3 or i.size(2) % 32 or i.size(3) % 32 or i.size(2) != i.size(3):
             raise RuntimeError("Yolo.forward: expected [B, 3, S, S] with S a multiple of 32")
         rt = self.runtime(i.device)
-        g = rt.graph(i.size(0), i.size(2), i.size(3), self.training)
+        g = rt.graph(i.size(0), i.size(2), i.size(3), self.training or self.frozen_bn, frozen=self.frozen_bn)
         from ..engine.runtime import NetFunction
         x = i.float().contiguous()
         if g.training and torch.is_grad_enabled():

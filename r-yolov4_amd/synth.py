@@ -31,9 +31,10 @@ def fill_state(sd):
         elif name.endswith("implicit"):
             base = 1.0 if ".im" in name else 0.0
             v = base + 0.02 * torch.sin(0.29 * i + 0.4 * k)
-        else:                                                    # conv weight: ~ kaiming-ish scale so activations stay O(1)
+        else:                                                    # conv weight: hash-uniform, variance 0.81/fan_in (well conditioned)
             fan_in = max(1, n // t.shape[0])
-            v = (1.7 / math.sqrt(fan_in)) * torch.sin(0.37 * i * (1 + (k % 7) * 0.01) + 1.3 * k + 0.011 * (i % 13) ** 2)
+            h = torch.sin(i * 12.9898 + k * 78.233 + 0.5) * 43758.5453
+            v = (2.0 * (h - torch.floor(h)) - 1.0) * (math.sqrt(3.0) * 0.9 / math.sqrt(fan_in))
         out[name] = v.to(t.dtype).reshape(t.shape)
     return out
 

@@ -69,7 +69,7 @@ def main():
             mine.load_state_dict(sd, strict=True)
             g = torch.Generator().manual_seed(1)
             x = torch.rand(2, 3, 64, 64, generator=g)
-            for train in (True, False):
+            for train in (False, True):      # eval first: it must see the pristine closed-form running statistics
                 ref.train(train)
                 mine.train(train)
                 with torch.no_grad():
