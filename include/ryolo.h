@@ -135,7 +135,8 @@ int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, float* out, fl
 int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t total, ryolo_stream_t stream);
 int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int CinP, float* grad, ryolo_stream_t stream);
 /* torch.optim.SGD(momentum, nesterov=True) of train.py:156 over flat buffers: buf = mu*buf + g; p -= lr*(g + mu*buf) */
-int ryolo_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, ryolo_stream_t stream);
+int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, float mu, float gscale, int zero_grad,
+                       ryolo_stream_t stream);   /* g is scaled by gscale on read; zero_grad=1 clears it (optimizer.zero_grad fused) */
 int ryolo_struct_sizes(int* sizes /* [8] */);
 
 /* ------------------------------------------------------------------------------------------------------------

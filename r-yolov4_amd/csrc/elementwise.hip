@@ -524,14 +524,21 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ scratch, int Cout,
 }
 
 // SGD with Nesterov momentum, dampening 0, no weight decay (train.py:156): buf = mu*buf + g; p -= lr*(g + mu*buf)
-__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                           int64_t n, float lr, float mu, float gscale)
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
+                                                           int64_t n4, float lr, float mu, float gscale, int zero_grad)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i] * gscale;
-        const float b = mu * buf[i] + gi;
-        buf[i] = b;
-        p[i] -= lr * (gi + mu * b);
+    // 16-byte lanes; the flat buffers are 256-byte aligned and padded to a multiple of 64 floats
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* b4 = reinterpret_cast<float4*>(buf);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 gv = g4[i], bv = b4[i], pv = p4[i];
+        gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
+        bv.x = mu * bv.x + gv.x; bv.y = mu * bv.y + gv.y; bv.z = mu * bv.z + gv.z; bv.w = mu * bv.w + gv.w;
+        pv.x -= lr * (gv.x + mu * bv.x); pv.y -= lr * (gv.y + mu * bv.y); pv.z -= lr * (gv.z + mu * bv.z); pv.w -= lr * (gv.w + mu * bv.w);
+        b4[i] = bv;
+        p4[i] = pv;
+        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);       // optimizer.zero_grad() fused (train.py:202)
     }
 }
 
@@ -713,11 +720,12 @@ extern "C" int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int t
     return RY_OK;
 }
 
-extern "C" int ryolo_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float gscale, hipStream_t stream)
+extern "C" int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, float mu, float gscale, int zero_grad,
+                                  hipStream_t stream)
 {
-    if (!p || !g || !buf || n < 0) return RY_ERR_ARG;
+    if (!p || !g || !buf || n < 0 || (n & 3)) return RY_ERR_ARG;
     if (n == 0) return RY_OK;
-    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, buf, n, lr, mu, gscale);
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, buf, n / 4, lr, mu, gscale, zero_grad);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

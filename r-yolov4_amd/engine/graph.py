@@ -96,6 +96,8 @@ class Graph:
         self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
         self.heads = []                        # per scale: dict(out=fp32 tensor, dout=fp32 tensor)
         self.debug = {}
+        self.meta = {}                         # (tape id, index) -> (kernel class, algorithmic flops)
+        self.timer = None                      # set by bench.py: per-launch HIP-event timing of the conv kernels
 
     # ------------------------------------------------------------------ helpers
     def new(self, N, H, W, Cc):
@@ -114,11 +116,42 @@ class Graph:
         self.keep.extend(a for a in args if isinstance(a, C.Structure))
         fn = getattr(hip.lib(), name)
         tape.append((fn, conv, name))
+        self.meta[(id(tape), len(tape) - 1)] = self._describe(name, args)
 
-    def run(self, tape):
+    @staticmethod
+    def _describe(name, args):
+        """(kernel class, algorithmic FLOPs) of a launch — used by bench.py's live roofline accounting."""
+        if name == "ryolo_conv_gemm":
+            p = args[0]
+            fl = 0
+            for c in range(p.nclasses):
+                fl += 2 * p.NB * p.OH * p.OW * p.Nout * p.cls[c].ntaps * p.Cin
+            tile = "256x32" if p.Nout <= 32 else ("128x64" if p.Nout <= 64 else "128x128")
+            return (f"conv_gemm_kernel<{tile}>", fl)
+        if name == "ryolo_conv_wgrad":
+            p = args[0]
+            return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin)
+        return (name, 0)
+
+    def run(self, tape, timer=None):
         st = hip.stream()
-        for fn, args, name in tape:
-            rc = fn(*args, st)
+        if timer is None:
+            for fn, args, name in tape:
+                rc = fn(*args, st)
+                if rc != 0:
+                    raise RuntimeError(f"{name} failed with code {rc}")
+            return
+        tid = id(tape)
+        for i, (fn, args, name) in enumerate(tape):
+            kind, fl = self.meta.get((tid, i), (name, 0))
+            if fl:
+                e0, e1 = timer.pair()
+                e0.record()
+                rc = fn(*args, st)
+                e1.record()
+                timer.note(kind, fl, e0, e1)
+            else:
+                rc = fn(*args, st)
             if rc != 0:
                 raise RuntimeError(f"{name} failed with code {rc}")
 

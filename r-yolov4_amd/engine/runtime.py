@@ -129,12 +129,13 @@ class Runtime:
         return g
 
     # ------------------------------------------------------------------ fused optimizer (bench / DP path)
-    def sgd_step(self, lr, momentum=0.937, grad_scale=1.0):
-        """torch.optim.SGD(lr, momentum=0.937, nesterov=True) of train.py:156 as ONE kernel over the flat buffers."""
+    def sgd_step(self, lr, momentum=0.937, grad_scale=1.0, zero_grad=True):
+        """torch.optim.SGD(lr, momentum=0.937, nesterov=True).step() [+ zero_grad()] of train.py:156,201-202 as ONE kernel over
+        the flat parameter / gradient / momentum buffers."""
         if self.momentum_buf is None:
             self.momentum_buf = torch.zeros_like(self.flat)
         hip.call("ryolo_sgd_nesterov", self.flat.data_ptr(), self.gflat.data_ptr(), self.momentum_buf.data_ptr(), self.n_flat, float(lr),
-                 float(momentum), float(grad_scale), hip.stream())
+                 float(momentum), float(grad_scale), 1 if zero_grad else 0, hip.stream())
 
 
 class NetFunction(torch.autograd.Function):
@@ -145,7 +146,7 @@ class NetFunction(torch.autograd.Function):
     def forward(ctx, imgs, anchor, rt, g):
         g.img.copy_(imgs)
         rt.pack()
-        g.run(g.fwd)
+        g.run(g.fwd, g.timer)
         if g.batch_stats:
             rt.nbt += 1
         ctx.rt, ctx.g = rt, g
@@ -160,7 +161,7 @@ class NetFunction(torch.autograd.Function):
                 h["dout"].zero_()
             else:
                 h["dout"].copy_(go)
-        g.run(g.bwd)
+        g.run(g.bwd, g.timer)
         if rt.model._grad_hook is not None:
             rt.model._grad_hook(rt)
         return None, None, None, None
