@@ -64,7 +64,7 @@ def cpu_baseline(args, budget_s=25.0):
     doing the same training step on the host cores: fp32, SGD nesterov.  Bounded sample: batch 1, at most 2 steps."""
     from oracle import ref_model, ref_ops
     from ryolov4_amd.synth import CFG, HYP, synth_batch
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)       # torch-CPU convs stop scaling (and oversubscribe) beyond ~32 threads at batch 1
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     net = ref_model.Yolo(args.nc, CFG, args.mode, args.ver)

@@ -98,7 +98,9 @@ int ryolo_pp_emit(const float* dets, const int64_t* keep, const int32_t* num_kee
 int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
 /* number of [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem */
 int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int* rows);
-/* weight gradient, split-K over output pixels, fp32 atomics into the torch-layout .grad [Cout][Cin][kh*kw] */
+/* weight gradient: split-K over output pixels into p->partial ([splitk][Cout][taps*Cin] fp32, size from _plan), then a
+ * deterministic reduction that accumulates into the torch-layout .grad [Cout][Cin][kh*kw] (no float atomics). */
+int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_bytes);
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
 
 /* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] -> coeffs [4][C] =

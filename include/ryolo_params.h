@@ -37,7 +37,8 @@ typedef struct WgradParams {
     int OH, OW, sh, sw;
     int ntaps; signed char dh[RY_MAX_TAPS], dw[RY_MAX_TAPS];
     float* dW;                                       // torch layout [Cout][Cin][ntaps] fp32, atomically accumulated
-    int splitk; int64_t kchunk;                      // pixels per split (multiple of BK)
+    int splitk; int64_t kchunk;                      // pixels per split (multiple of BK) — filled by the library
+    float* partial;                                  // split-K workspace [splitk][Cout][ntaps*Cin] fp32 (ryolo_conv_wgrad_plan)
 } WgradParams;
 
 typedef struct BnActParams {

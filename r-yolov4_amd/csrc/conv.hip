@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = (BM * 4 + 255) / 256, PB = (BN * 4 + 255) / 256;       // 16-byte pieces per thread
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 64 == 0, "tile config");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+    constexpr int WTM = BM / WM, WTN = BN / WN;               // rows x cols of one wave's output block
+    constexpr int EP_LD = WTN + 8;                            // staging row stride (bf16), 16-byte aligned, breaks bank aliasing
+    constexpr int MAINLOOP_ELEMS = 2 * (BM + BN) * BK, EPI_ELEMS = 4 * WTM * EP_LD;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS];
 #define sA_(b) (smem + (b) * (BM + BN) * BK)
 #define sB_(b) (smem + (b) * (BM + BN) * BK + BM * BK)
 
@@ -175,13 +178,67 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
 #pragma unroll
     for (int j = 0; j < TN; j++) { csum[j] = 0.f; csq[j] = 0.f; }
 
+    if (p.epi == EPI_F32_BIAS || p.epi == EPI_AFFINE_ACT) {
+        // small / rare outputs (detection heads, fused eval epilogue): direct per-element stores
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
+        for (int i = 0; i < TM; i++) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            const int64_t m = m0 + row;
-            if (m >= M) continue;
+            for (int e = 0; e < 16; e++) {
+                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int64_t m = m0 + row;
+                if (m >= M) continue;
+                int64_t pix = m;
+                if (!identity) {
+                    const int img = (int)(m / ((int64_t)p.OH * p.OW));
+                    const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    pix = ((int64_t)img * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+                    if (n >= p.Nout) continue;
+                    float v = acc[i][j][e];
+                    if (p.epi == EPI_F32_BIAS) {
+                        if (p.bias) v += p.bias[n];
+                        reinterpret_cast<float*>(p.out)[pix * p.ldC + n] = v;
+                    } else {
+                        v = act_fwd(v * p.scale[n] + p.shift[n], p.act);
+                        reinterpret_cast<bf16_t*>(p.out)[pix * p.ldC + n] = f2bf(v);
+                    }
+                }
+            }
+        }
+    } else {
+        // bf16 outputs: stage the wave's WTM x WTN block in LDS, then write whole 16-byte row segments (8 channels per lane)
+        __syncthreads();                                       // every wave is done reading the operand tiles
+        bf16_t* stage = smem + wave * WTM * EP_LD;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const bf16_t b = f2bf(acc[i][j][e]);
+                    stage[r * EP_LD + j * 32 + (lane & 31)] = b;
+                    if (p.epi == EPI_STATS) {
+                        const bool live = (m0 + wm * WTM + r) < M;          // rows past M are zero anyway (zero-filled A rows)
+                        const float rv = live ? bf2f(b) : 0.f;              // statistics of the values actually stored
+                        csum[j] += rv;
+                        csq[j] += rv * rv;
+                    }
+                }
+        // (same-wave LDS hand-off: no workgroup barrier needed, only the wave's own ds_write -> ds_read ordering)
+        constexpr int CH = WTN / 8;                            // 16-byte chunks per row
+        constexpr int RPI = 64 / CH;                           // rows per iteration
+        const int ch = lane % CH, r0 = lane / CH;
+        const int n = n0 + wn * WTN + ch * 8;
+#pragma unroll
+        for (int it = 0; it < WTM / RPI; it++) {
+            const int r = it * RPI + r0;
+            const int64_t m = m0 + wm * WTM + r;
+            if (m >= M || n >= p.Nout) continue;
             int64_t pix = m;
             if (!identity) {
                 const int img = (int)(m / ((int64_t)p.OH * p.OW));
@@ -189,30 +246,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
                 const int oh = rem / p.OW, ow = rem - oh * p.OW;
                 pix = ((int64_t)img * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
             }
+            uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
+            bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
+            if (p.epi == EPI_ACCUM) {
+                const uint4 old = *reinterpret_cast<const uint4*>(o);
+                const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                const unsigned* b = reinterpret_cast<const unsigned*>(&old);
+                unsigned w[4];
 #pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-                if (n >= p.Nout) continue;
-                float v = acc[i][j][e];
-                if (p.epi == EPI_F32_BIAS) {
-                    if (p.bias) v += p.bias[n];
-                    reinterpret_cast<float*>(p.out)[pix * p.ldC + n] = v;
-                } else if (p.epi == EPI_AFFINE_ACT) {
-                    v = act_fwd(v * p.scale[n] + p.shift[n], p.act);
-                    reinterpret_cast<bf16_t*>(p.out)[pix * p.ldC + n] = f2bf(v);
-                } else if (p.epi == EPI_ACCUM) {
-                    bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
-                    *o = f2bf(bf2f(*o) + v);
-                } else {
-                    const bf16_t b = f2bf(v);
-                    reinterpret_cast<bf16_t*>(p.out)[pix * p.ldC + n] = b;
-                    if (p.epi == EPI_STATS) {
-                        const float r = bf2f(b);          // statistics of the values actually stored
-                        csum[j] += r;
-                        csq[j] += r * r;
-                    }
-                }
+                for (int q = 0; q < 4; q++)
+                    w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
+                                    __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
             }
+            *reinterpret_cast<uint4*>(o) = v;
         }
     }
     if (p.epi == EPI_STATS) {
@@ -244,7 +291,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
 // ------------------------------------------------------------------------------------------------ weight gradient
 
 // BM = 128 output channels x BN = 128 (tap,cin) columns; K = pixels.  LDS tiles are pixel-major [BK][128+PAD].
-#define WG_LD 136
+// pixel-major LDS rows of 128 channels + 32 pad: row stride 320 B = 64 B (mod 256 B), so the 4 rows x 32 B a 16-lane group of
+// ds_read_b64_tr_b16 touches (and the neighbouring group's +32 B) fall on 8 disjoint bank ranges -> conflict free
+#define WG_LD 160
 template <int BM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 {
@@ -342,24 +391,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         if (k + 1 < nk) gload(k + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            const int kb = ks * 16 + (lane >> 5) * 8;          // first of this lane's 8 pixels
+            // Transposed fragment reads (gfx950 ds_read_b64_tr_b16): the tiles are pixel-major [pixel][channel] as they come
+            // from HBM, the MFMA wants 8 consecutive pixels (K) per lane for ONE channel.  Within each 16-lane group the
+            // instruction transposes a 4(pixel) x 16(channel) block: lane s supplies the address of pixel (s>>2), channels
+            // 4*(s&3)..+3 and receives channel s for the 4 pixels.  Two reads (pixels +0..3, +4..7) build one operand.
+            const int s16 = lane & 15, grp = lane >> 4;
+            const int prow = ks * 16 + (grp >> 1) * 8 + (s16 >> 2);
+            const int pcol = 16 * (grp & 1) + 4 * (s16 & 3);
             bf16x8 af[TM], bfr[TN];
+            unsigned long long lo[TM + TN], hi[TM + TN];
+            unsigned addr[TM + TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int c = wm * (BM / WM) + i * 32 + (lane & 31);
-                u16x8 t;
+            for (int i = 0; i < TM; i++)
+                addr[i] = (unsigned)(size_t)(wA_(buf) + prow * WG_LD + wm * (BM / WM) + i * 32 + pcol);
 #pragma unroll
-                for (int e = 0; e < 8; e++) t[e] = wA_(buf)[(kb + e) * WG_LD + c];
-                af[i] = __builtin_bit_cast(bf16x8, t);
+            for (int j = 0; j < TN; j++)
+                addr[TM + j] = (unsigned)(size_t)(wB_(buf) + prow * WG_LD + wn * (BN / WN) + j * 32 + pcol);
+            // all reads and their wait in ONE asm statement (hipcc does not count asm LDS reads): early-clobber outputs
+            if constexpr (TM + TN == 4) {
+                asm volatile(
+                    "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+                    "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+                    "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+                    "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:%12\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+                    : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(4 * WG_LD * 2)
+                    : "memory");
+            } else {
+                static_assert(TM + TN == 3, "fragment count");
+                asm volatile(
+                    "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:%9\n\t"
+                    "ds_read_b64_tr_b16 %2, %7\n\tds_read_b64_tr_b16 %3, %7 offset:%9\n\t"
+                    "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:%9\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2])
+                    : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "i"(4 * WG_LD * 2)
+                    : "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+            typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
 #pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int c = wn * (BN / WN) + j * 32 + (lane & 31);
-                u16x8 t;
+            for (int i = 0; i < TM; i++) { u64x2 t = {lo[i], hi[i]}; af[i] = __builtin_bit_cast(bf16x8, t); }
 #pragma unroll
-                for (int e = 0; e < 8; e++) t[e] = wB_(buf)[(kb + e) * WG_LD + c];
-                bfr[j] = __builtin_bit_cast(bf16x8, t);
-            }
+            for (int j = 0; j < TN; j++) { u64x2 t = {lo[TM + j], hi[TM + j]}; bfr[j] = __builtin_bit_cast(bf16x8, t); }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -370,21 +445,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         __syncthreads();
     }
 
+    // split-K partial tile -> workspace [z][Cout][ntaps*Cin] (GEMM layout; 128-byte row segments per store instruction).
+    // No float atomics: the reduction over z is a separate deterministic pass.
+    const int NK = p.ntaps * p.Cin;
+    float* part = p.partial + (int64_t)blockIdx.z * p.Cout * NK;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int col = wn * (BN / WN) + j * 32 + (lane & 31);
         const int q = q0 + (col >> 5);
         if (q >= nchunks) continue;
-        const int tap = q / cchunks;
-        const int cin = (q - tap * cchunks) * BK + (col & 31);
+        const int kc = q * BK + (col & 31);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int co = i0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (co < p.Cout) atomicAdd(p.dW + ((int64_t)co * p.Cin + cin) * p.ntaps + tap, acc[i][j][e]);
+                if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[i][j][e];
             }
         }
+    }
+}
+
+// dW[co][cin][tap] += sum_z partial[z][co][tap*Cin + cin]   (torch weight layout, one thread per element, fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splitk, int Cout, int Cin, int ntaps,
+                                                           float* __restrict__ dW)
+{
+    const int NK = ntaps * Cin;
+    const int64_t total = (int64_t)Cout * NK;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splitk; z++) s += partial[(int64_t)z * total + i];
+        const int co = (int)(i / NK), kc = (int)(i - (int64_t)co * NK);
+        const int tap = kc / Cin, cin = kc - tap * Cin;
+        dW[((int64_t)co * Cin + cin) * ntaps + tap] += s;
     }
 }
 
@@ -423,29 +516,54 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
     return launch_gemm<128, 128, 2, 2>(p, stream);
 }
 
+static int wgrad_geometry(WgradParams& p, int& bm, int& gx, int& gy)
+{
+    if (p.Cin <= 0 || p.Cin % BK || p.ldX % 8 || p.ldY % 8 || p.Cout <= 0 || p.CoutPad % 8 || p.CoutPad < p.Cout || p.CoutPad > p.ldY ||
+        p.ntaps < 1 || p.ntaps > RY_MAX_TAPS)
+        return RY_ERR_ARG;
+    const int64_t M = (int64_t)p.NB * p.OH * p.OW;
+    bm = p.Cout <= 64 ? 64 : 128;
+    gx = (int)ry_cdiv(p.Cout, bm);
+    gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), 4);
+    int64_t want = ry_cdiv(2048, (int64_t)gx * gy);                  // ~8 workgroups per CU
+    int64_t maxsplit = ry_cdiv(M, 16 * BK);                          // at least 16 K-steps per split
+    int64_t sk = want > maxsplit ? maxsplit : want;
+    if (sk < 1) sk = 1;
+    if (sk > 65535) sk = 65535;
+    p.kchunk = ry_cdiv(ry_cdiv(M > 0 ? M : 1, sk), BK) * BK;
+    p.splitk = (int)ry_cdiv(M > 0 ? M : 1, p.kchunk);
+    return RY_OK;
+}
+
+extern "C" int ryolo_conv_wgrad_plan(const WgradParams* pp, int* splitk, size_t* workspace_bytes)
+{
+    if (!pp || !splitk || !workspace_bytes) return RY_ERR_ARG;
+    WgradParams p = *pp;
+    int bm, gx, gy;
+    const int rc = wgrad_geometry(p, bm, gx, gy);
+    if (rc) return rc;
+    *splitk = p.splitk;
+    *workspace_bytes = (size_t)p.splitk * p.Cout * p.ntaps * p.Cin * sizeof(float);
+    return RY_OK;
+}
+
 extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
 {
     if (!pp) return RY_ERR_ARG;
     WgradParams p = *pp;
-    if (!p.dY || !p.X || !p.dW || p.Cin <= 0 || p.Cin % BK || p.ldX % 8 || p.ldY % 8 || p.Cout <= 0 || p.CoutPad % 8 || p.CoutPad < p.Cout || p.CoutPad > p.ldY ||
-        p.ntaps < 1 || p.ntaps > RY_MAX_TAPS)
-        return RY_ERR_ARG;
-    const int64_t M = (int64_t)p.NB * p.OH * p.OW;
-    if (M <= 0) return RY_OK;
-    const int bm = p.Cout <= 64 ? 64 : 128;
-    const int gx = (int)ry_cdiv(p.Cout, bm);
-    const int gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), 4);
-    int64_t want = ry_cdiv(1024, (int64_t)gx * gy);                 // aim for >= ~4 workgroups per CU
-    int64_t maxsplit = ry_cdiv(M, 8 * BK);                           // at least 8 K-steps per split
-    int64_t sk = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
-    if (sk < 1) sk = 1;
-    if (sk > 65535) sk = 65535;
-    p.kchunk = ry_cdiv(ry_cdiv(M, sk), BK) * BK;
-    p.splitk = (int)ry_cdiv(M, p.kchunk);
+    if (!p.dY || !p.X || !p.dW || !p.partial) return RY_ERR_ARG;
+    int bm, gx, gy;
+    const int rc = wgrad_geometry(p, bm, gx, gy);
+    if (rc) return rc;
+    if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
     if (bm == 64)
         hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3(gx, gy, p.splitk), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128>), dim3(gx, gy, p.splitk), dim3(256), 0, stream, p);
+    const int64_t total = (int64_t)p.Cout * p.ntaps * p.Cin;
+    int64_t g = ry_cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, p.partial, p.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

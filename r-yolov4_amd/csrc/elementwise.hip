@@ -108,26 +108,44 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // ------------------------------------------------------------------------------------------------ BN + act forward
 
+// Thread mapping shared by the three BN+act kernels: a thread owns ONE group of 8 channels (its BN coefficients live in
+// registers for the whole kernel) and walks rows; 256 threads = cols column-groups x (256/cols) rows per iteration.
+struct Co8 { float sc[8], sh[8], mu[8], is[8]; };
+__device__ __forceinline__ void load_co(const float* co, int C, int c, Co8& o)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) { o.mu[k] = co[c + k]; o.is[k] = co[C + c + k]; o.sc[k] = co[2 * C + c + k]; o.sh[k] = co[3 * C + c + k]; }
+}
+
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActParams p)
 {
     const int c8 = p.C >> 3;
-    const int64_t total = p.M * c8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / c8;
-        const int c = (int)(i - m * c8) << 3;
-        const V8 a = ld8(p.y1 + m * p.ld1 + c);
-        V8 b, r, o;
-        if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
-        if (p.res) r = ld8(p.res + m * p.ldr + c);
+    const int cols = c8 < 256 ? c8 : 256;
+    const int rpi = 256 / cols;                               // rows per iteration of one workgroup
+    const int rl = threadIdx.x / cols, cl = threadIdx.x - rl * cols;
+    if (rl >= rpi) return;
+    for (int cb = 0; cb < c8; cb += cols) {
+        const int cc = cb + cl;
+        if (cc >= c8) continue;
+        const int c = cc << 3;
+        Co8 k1, k2;
+        load_co(p.co1, p.C, c, k1);
+        if (p.y2) load_co(p.co2, p.C, c, k2);
+        for (int64_t m = (int64_t)blockIdx.x * rpi + rl; m < p.M; m += (int64_t)gridDim.x * rpi) {
+            const V8 a = ld8(p.y1 + m * p.ld1 + c);
+            V8 b, r, o;
+            if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+            if (p.res) r = ld8(p.res + m * p.ldr + c);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float u = a.v[k] * p.co1[2 * p.C + c + k] + p.co1[3 * p.C + c + k];
-            if (p.y2) u += b.v[k] * p.co2[2 * p.C + c + k] + p.co2[3 * p.C + c + k];
-            float zv = act_f(u, p.act);
-            if (p.res) zv += r.v[k];
-            o.v[k] = zv;
+            for (int k = 0; k < 8; k++) {
+                float u = a.v[k] * k1.sc[k] + k1.sh[k];
+                if (p.y2) u += b.v[k] * k2.sc[k] + k2.sh[k];
+                float zv = act_f(u, p.act);
+                if (p.res) zv += r.v[k];
+                o.v[k] = zv;
+            }
+            st8(p.z + m * p.ldz + c, o);
         }
-        st8(p.z + m * p.ldz + c, o);
     }
 }
 
@@ -149,6 +167,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
         for (int k = 0; k < 8; k++) { sg[k] = 0.f; sx1[k] = 0.f; sx2[k] = 0.f; }
         if (rl < nrl && cc < c8) {
             const int c = cc << 3;
+            Co8 k1, k2;
+            load_co(p.co1, p.C, c, k1);
+            if (p.y2) load_co(p.co2, p.C, c, k2);
             for (int64_t m = r0 + rl; m < r1; m += nrl) {
                 const V8 d = ld8(p.dz + m * p.lddz + c);
                 const V8 a = ld8(p.y1 + m * p.ld1 + c);
@@ -156,12 +177,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
                 if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    float u = a.v[k] * p.co1[2 * p.C + c + k] + p.co1[3 * p.C + c + k];
-                    if (p.y2) u += b.v[k] * p.co2[2 * p.C + c + k] + p.co2[3 * p.C + c + k];
+                    float u = a.v[k] * k1.sc[k] + k1.sh[k];
+                    if (p.y2) u += b.v[k] * k2.sc[k] + k2.sh[k];
                     const float g = d.v[k] * act_d(u, p.act);
                     sg[k] += g;
-                    sx1[k] += g * (a.v[k] - p.co1[c + k]) * p.co1[p.C + c + k];
-                    if (p.y2) sx2[k] += g * (b.v[k] - p.co2[c + k]) * p.co2[p.C + c + k];
+                    sx1[k] += g * (a.v[k] - k1.mu[k]) * k1.is[k];
+                    if (p.y2) sx2[k] += g * (b.v[k] - k2.mu[k]) * k2.is[k];
                 }
             }
         }
@@ -213,33 +234,45 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnActParams p)
 {
     const int c8 = p.C >> 3;
-    const int64_t total = p.M * c8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / c8;
-        const int c = (int)(i - m * c8) << 3;
-        const V8 d = ld8(p.dz + m * p.lddz + c);
-        const V8 a = ld8(p.y1 + m * p.ld1 + c);
-        V8 b, o1, o2;
-        if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+    const int cols = c8 < 256 ? c8 : 256;
+    const int rpi = 256 / cols;
+    const int rl = threadIdx.x / cols, cl = threadIdx.x - rl * cols;
+    if (rl >= rpi) return;
+    for (int cb = 0; cb < c8; cb += cols) {
+        const int cc = cb + cl;
+        if (cc >= c8) continue;
+        const int c = cc << 3;
+        Co8 k1, k2;
+        float mg[8], mx1[8], mx2[8];
+        load_co(p.co1, p.C, c, k1);
+        if (p.y2) load_co(p.co2, p.C, c, k2);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float u = a.v[k] * p.co1[2 * p.C + c + k] + p.co1[3 * p.C + c + k];
-            if (p.y2) u += b.v[k] * p.co2[2 * p.C + c + k] + p.co2[3 * p.C + c + k];
-            const float g = d.v[k] * act_d(u, p.act);
-            const float gm = g - p.bco[c + k];
-            o1.v[k] = p.co1[2 * p.C + c + k] * (gm - (a.v[k] - p.co1[c + k]) * p.co1[p.C + c + k] * p.bco[p.C + c + k]);
-            if (p.y2) o2.v[k] = p.co2[2 * p.C + c + k] * (gm - (b.v[k] - p.co2[c + k]) * p.co2[p.C + c + k] * p.bco[2 * p.C + c + k]);
-        }
-        st8(p.dy1 + m * p.lddy1 + c, o1);
-        if (p.y2) st8(p.dy2 + m * p.lddy2 + c, o2);
-        if (p.dres) {
-            V8 r = d;
-            if (p.dres_accum) {
-                const V8 e = ld8(p.dres + m * p.lddres + c);
+        for (int k = 0; k < 8; k++) { mg[k] = p.bco[c + k]; mx1[k] = p.bco[p.C + c + k]; mx2[k] = p.y2 ? p.bco[2 * p.C + c + k] : 0.f; }
+        for (int64_t m = (int64_t)blockIdx.x * rpi + rl; m < p.M; m += (int64_t)gridDim.x * rpi) {
+            const V8 d = ld8(p.dz + m * p.lddz + c);
+            const V8 a = ld8(p.y1 + m * p.ld1 + c);
+            V8 b, o1, o2;
+            if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
 #pragma unroll
-                for (int k = 0; k < 8; k++) r.v[k] += e.v[k];
+            for (int k = 0; k < 8; k++) {
+                float u = a.v[k] * k1.sc[k] + k1.sh[k];
+                if (p.y2) u += b.v[k] * k2.sc[k] + k2.sh[k];
+                const float g = d.v[k] * act_d(u, p.act);
+                const float gm = g - mg[k];
+                o1.v[k] = k1.sc[k] * (gm - (a.v[k] - k1.mu[k]) * k1.is[k] * mx1[k]);
+                if (p.y2) o2.v[k] = k2.sc[k] * (gm - (b.v[k] - k2.mu[k]) * k2.is[k] * mx2[k]);
             }
-            st8(p.dres + m * p.lddres + c, r);
+            st8(p.dy1 + m * p.lddy1 + c, o1);
+            if (p.y2) st8(p.dy2 + m * p.lddy2 + c, o2);
+            if (p.dres) {
+                V8 r = d;
+                if (p.dres_accum) {
+                    const V8 e = ld8(p.dres + m * p.lddres + c);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) r.v[k] += e.v[k];
+                }
+                st8(p.dres + m * p.lddres + c, r);
+            }
         }
     }
 }
@@ -545,6 +578,14 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p
 // fp32 NCHW image -> is consumed directly by im2col_kernel; nothing else needed for the input side.
 
 // ------------------------------------------------------------------------------------------------ C ABI
+static inline unsigned grid_rows(int64_t M, int C)
+{
+    const int c8 = C >> 3, cols = c8 < 256 ? c8 : 256, rpi = 256 / cols;
+    int64_t g = ry_cdiv(M, (int64_t)rpi * 4);               // >= 4 rows per thread
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
 static inline unsigned grid_for(int64_t work_items) { int64_t g = ry_cdiv(work_items, 256); if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g; }
 
 extern "C" int ryolo_bn_finalize(const float* partial, int rows, int C, double count, float eps, float momentum, const float* gamma,
@@ -572,7 +613,7 @@ extern "C" int ryolo_bn_act_fwd(const BnActParams* pp, hipStream_t stream)
 {
     if (!pp || check_bnact(*pp) || !pp->z) return RY_ERR_ARG;
     if (pp->M == 0) return RY_OK;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(pp->M * (pp->C >> 3))), dim3(256), 0, stream, *pp);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_rows(pp->M, pp->C)), dim3(256), 0, stream, *pp);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -606,7 +647,7 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, p.partial, nblk, K, p.C,
                        (double)p.M, frozen, bco, dgamma1, dbeta1, dgamma2, dbeta2);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(p.M * (p.C >> 3))), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_rows(p.M, p.C)), dim3(256), 0, stream, p);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -98,6 +98,7 @@ class Graph:
         self.debug = {}
         self.meta = {}                         # (tape id, index) -> (kernel class, algorithmic flops)
         self.timer = None                      # set by bench.py: per-launch HIP-event timing of the conv kernels
+        self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by every weight-gradient launch (backward is serial)
 
     # ------------------------------------------------------------------ helpers
     def new(self, N, H, W, Cc):
@@ -216,6 +217,13 @@ class Graph:
         for i, (dh, dw, _) in enumerate(taps):
             p.dh[i], p.dw[i] = dh, dw
         p.dW = self.rt.grad_ptr(conv.weight)
+        self._emit_wgrad(p)
+
+    def _emit_wgrad(self, p):
+        sk, need = S.I(), S.Z()
+        hip.call("ryolo_conv_wgrad_plan", p, sk, need)
+        self._wgrad_ws_bytes = max(self._wgrad_ws_bytes, need.value)
+        self._wgrads.append(p)
         self._call(self.bwd, "ryolo_conv_wgrad", p)
 
     def conv_raw(self, conv, x, want_stats):
@@ -270,7 +278,7 @@ class Graph:
             p.OH, p.OW, p.sh, p.sw, p.ntaps = OH, OW, 1, 1, 1
             p.dh[0], p.dw[0] = 0, 0
             p.dW = scratch.data_ptr()
-            self._call(self.bwd, "ryolo_conv_wgrad", p)
+            self._emit_wgrad(p)
             self._call(self.bwd, "ryolo_unpack_wgrad", scratch.data_ptr(), cout, 3, k * k, kp, rt.grad_ptr(conv.weight))
         return y, stats, backward
 
@@ -470,3 +478,8 @@ class Graph:
         for emit in reversed(self._pending_bwd):
             emit()
         self._pending_bwd = None
+        if self._wgrads:
+            ws = torch.empty(self._wgrad_ws_bytes, dtype=torch.uint8, device=self.dev)
+            self.keep.append(ws)
+            for p in self._wgrads:
+                p.partial = ws.data_ptr()
