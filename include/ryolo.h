@@ -96,14 +96,15 @@ int ryolo_pp_emit(const float* dets, const int64_t* keep, const int32_t* num_kee
  * classes on grid.z).  Epilogues (p->epi): 0 raw bf16, 1 raw + per-tile BatchNorm partial sums, 2 folded-BN + activation,
  * 3 fp32 + bias (detection heads), 4 bf16 accumulate (tensor with several consumers). */
 int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
-/* number of [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem */
-int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int* rows);
+/* number of [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem under mainloop variant `pipe` */
+int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows);
 /* weight gradient: split-K over output pixels into p->partial ([splitk][Cout][taps*Cin] fp32, size from _plan), then a
  * deterministic reduction that accumulates into the torch-layout .grad [Cout][Cin][kh*kw] (no float atomics). */
 int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_bytes);
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
 
-/* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] -> coeffs [4][C] =
+/* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] (the buffer must have
+ * room for 64 more rows: fold scratch for big layers) -> coeffs [4][C] =
  * mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean/var updated in place (unbiased var). */
 int ryolo_bn_finalize(const float* partial, int rows, int C, double count, float eps, float momentum, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float* coeffs, ryolo_stream_t stream);
@@ -113,7 +114,7 @@ int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* run
 /* z = act(bn1(y1) [+ bn2(y2)]) [+ residual]   (Conv / RepConv / Bottleneck of model/utils.py) */
 int ryolo_bn_act_fwd(const BnActParams* p, ryolo_stream_t stream);
 int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_per_block);
-/* backward of the above: dy1 [, dy2] [, dres], dgamma/dbeta accumulated; p->partial needs nblk*K*C floats, bco 3*C.
+/* backward of the above: dy1 [, dy2] [, dres], dgamma/dbeta accumulated; p->partial needs (nblk+64)*K*C floats, bco 3*C.
  * frozen=1: the coefficients came from ryolo_bn_eval_coeffs (fixed affine map, no batch-statistics coupling). */
 int ryolo_bn_act_bwd(const BnActParams* p, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
                      int frozen, ryolo_stream_t stream);
@@ -131,7 +132,8 @@ int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, in
 int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
                           bf16_t* dpre, int ldd, float* dmul, float* scratch, ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
-int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, float* out, float* scratch, ryolo_stream_t stream);
+/* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= ceil(M/1024)*C floats */
+int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);
 
 /* fp32 master weights (torch layout) -> bf16 GEMM images, all convolutions in one launch */
 int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t total, ryolo_stream_t stream);

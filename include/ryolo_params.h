@@ -29,6 +29,9 @@ typedef struct ConvGemmParams {
     float* stats;                                   // EPI_STATS: [gridM][2][Nout]
     const float* scale; const float* shift; int act; // EPI_AFFINE_ACT
     const float* bias;                              // EPI_F32_BIAS (may be null)
+    const bf16_t* zeros;                            // >= 64 zero bytes in device memory: source of padded / out-of-range rows (LDS-DMA path)
+    int pipe;                                       // 0: register-staged double buffer, 1: LDS-DMA ring (flat), 2: buffer-DMA ring, 256-row tiles
+    unsigned a_bytes, w_bytes;                      // byte extents of A / W for the buffer descriptors (pipe 2; both < 2^31)
 } ConvGemmParams;
 
 typedef struct WgradParams {

@@ -23,6 +23,7 @@
 //     both operands staged pixel-major and read transposed from LDS.
 #include "common.h"
 #include "params.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
@@ -54,16 +55,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+#define RY_STAGES 3
+
+template <int BM, int BN, int WM, int WN, int PIPE>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = (BM * 4 + 255) / 256, PB = (BN * 4 + 255) / 256;       // 16-byte pieces per thread
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 64 == 0, "tile config");
     constexpr int WTM = BM / WM, WTN = BN / WN;               // rows x cols of one wave's output block
     constexpr int EP_LD = WTN + 8;                            // staging row stride (bf16), 16-byte aligned, breaks bank aliasing
-    constexpr int MAINLOOP_ELEMS = 2 * (BM + BN) * BK, EPI_ELEMS = 4 * WTM * EP_LD;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS];
+    constexpr int MAINLOOP_ELEMS = (PIPE == 2 ? 3 : (PIPE ? RY_STAGES : 2)) * (BM + BN) * BK, EPI_ELEMS = 4 * WTM * EP_LD;
+    constexpr int TAPTAB = 64;                                // 32 ints after the tiles: per-tap (dh, dw, widx) for the DMA loop
+    __shared__ __attribute__((aligned(16))) bf16_t smem[(MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS) + TAPTAB];
 #define sA_(b) (smem + (b) * (BM + BN) * BK)
 #define sB_(b) (smem + (b) * (BM + BN) * BK + BM * BK)
 
@@ -77,62 +83,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
     const int64_t m0 = (int64_t)mb * BM;
     const int n0 = nb * BN;
 
-    // ---- per-thread gather bookkeeping -----------------------------------------------------------------
-    int a_ih0[PA], a_iw0[PA];
-    int64_t a_base[PA];
-    bool a_ok[PA];
-#pragma unroll
-    for (int u = 0; u < PA; u++) {
-        const int r = (tid >> 2) + u * 64;
-        const int64_t m = m0 + r;
-        a_ok[u] = m < M;
-        const int64_t mm = a_ok[u] ? m : 0;
-        const int img = (int)(mm / ((int64_t)p.OH * p.OW));
-        const int rem = (int)(mm - (int64_t)img * p.OH * p.OW);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        a_ih0[u] = oh * p.sh;
-        a_iw0[u] = ow * p.sw;
-        a_base[u] = (int64_t)img * p.IH * p.IW;
-    }
-    const int slot = tid & 3;
-    const int cchunks = p.Cin / BK;
-    const int nk = tc.ntaps * cchunks;
-
-    uint4 ra[PA], rb[PB];
-    auto gload = [&](int step) {
-        const int t = step / cchunks;
-        const int c0 = (step - t * cchunks) * BK + slot * 8;
-        const int dh = tc.dh[t], dw = tc.dw[t], wi = tc.widx[t];
-#pragma unroll
-        for (int u = 0; u < PA; u++) {
-            const int ih = a_ih0[u] + dh, iw = a_iw0[u] + dw;
-            const bool ok = a_ok[u] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(p.A + (a_base[u] + (int64_t)ih * p.IW + iw) * p.ldA + c0);
-            ra[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < PB; u++) {
-            const int rr = (tid >> 2) + u * 64;
-            const int n = n0 + rr;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (rr < BN && n < p.Nout) v = *reinterpret_cast<const uint4*>(p.W + ((int64_t)n * p.wtaps + wi) * p.Cin + c0);
-            rb[u] = v;
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PA; u++) {
-            const int r = (tid >> 2) + u * 64;
-            *reinterpret_cast<uint4*>(sA_(buf) + (r * 4 + (slot ^ ((r >> 2) & 3))) * 8) = ra[u];
-        }
-#pragma unroll
-        for (int u = 0; u < PB; u++) {
-            const int r = (tid >> 2) + u * 64;
-            if (r < BN) *reinterpret_cast<uint4*>(sB_(buf) + (r * 4 + (slot ^ ((r >> 2) & 3))) * 8) = rb[u];
-        }
-    };
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
@@ -141,34 +91,315 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int k = 0; k < nk; k++) {
-        const int buf = k & 1;
-        if (k + 1 < nk) gload(k + 1);
+    const int cchunks = p.Cin / BK;
+    const int nk = tc.ntaps * cchunks;
+    if constexpr (PIPE == 0) {
+        // ---- per-thread gather bookkeeping -----------------------------------------------------------------
+        int a_ih0[PA], a_iw0[PA];
+        int64_t a_base[PA];
+        bool a_ok[PA];
+    #pragma unroll
+        for (int u = 0; u < PA; u++) {
+            const int r = (tid >> 2) + u * 64;
+            const int64_t m = m0 + r;
+            a_ok[u] = m < M;
+            const int64_t mm = a_ok[u] ? m : 0;
+            const int img = (int)(mm / ((int64_t)p.OH * p.OW));
+            const int rem = (int)(mm - (int64_t)img * p.OH * p.OW);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih0[u] = oh * p.sh;
+            a_iw0[u] = ow * p.sw;
+            a_base[u] = (int64_t)img * p.IH * p.IW;
+        }
+        const int slot = tid & 3;
+
+        uint4 ra[PA], rb[PB];
+        auto gload = [&](int step) {
+            const int t = step / cchunks;
+            const int c0 = (step - t * cchunks) * BK + slot * 8;
+            const int dh = tc.dh[t], dw = tc.dw[t], wi = tc.widx[t];
+    #pragma unroll
+            for (int u = 0; u < PA; u++) {
+                const int ih = a_ih0[u] + dh, iw = a_iw0[u] + dw;
+                const bool ok = a_ok[u] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *reinterpret_cast<const uint4*>(p.A + (a_base[u] + (int64_t)ih * p.IW + iw) * p.ldA + c0);
+                ra[u] = v;
+            }
+    #pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int rr = (tid >> 2) + u * 64;
+                const int n = n0 + rr;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (rr < BN && n < p.Nout) v = *reinterpret_cast<const uint4*>(p.W + ((int64_t)n * p.wtaps + wi) * p.Cin + c0);
+                rb[u] = v;
+            }
+        };
+        auto sstore = [&](int buf) {
+    #pragma unroll
+            for (int u = 0; u < PA; u++) {
+                const int r = (tid >> 2) + u * 64;
+                *reinterpret_cast<uint4*>(sA_(buf) + (r * 4 + (slot ^ ((r >> 2) & 3))) * 8) = ra[u];
+            }
+    #pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int r = (tid >> 2) + u * 64;
+                if (r < BN) *reinterpret_cast<uint4*>(sB_(buf) + (r * 4 + (slot ^ ((r >> 2) & 3))) * 8) = rb[u];
+            }
+        };
+
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int k = 0; k < nk; k++) {
+            const int buf = k & 1;
+            if (k + 1 < nk) gload(k + 1);
+    #pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 af[TM], bfr[TN];
+                const int sl = ks * 2 + (lane >> 5);
+    #pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int r = wm * (BM / WM) + i * 32 + (lane & 31);
+                    af[i] = *reinterpret_cast<const bf16x8*>(sA_(buf) + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
+                }
+    #pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int r = wn * (BN / WN) + j * 32 + (lane & 31);
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sB_(buf) + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
+                }
+    #pragma unroll
+                for (int i = 0; i < TM; i++)
+    #pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (k + 1 < nk) sstore(buf ^ 1);
+            __syncthreads();
+        }
+
+
+    } else if constexpr (PIPE == 1) {
+        // ---- LDS-DMA ring: RY_STAGES stages of (BM + BN) x 32 bf16, filled by global_load_lds_dwordx4 (no VGPR staging) ----
+        // One wave instruction moves 1 KiB = 16 rows x 64 B into a lane-linear LDS image, so the bank swizzle of the
+        // fragment reads (slot ^= (row>>2)&3) is applied on the SOURCE side: lane l of a piece lands in physical slot l&3
+        // of row l>>2 and therefore fetches logical k-slot (l&3) ^ ((row>>2)&3).  Padded / out-of-range rows read p.zeros.
+        constexpr int STG = (BM + BN) * BK;                     // elements per stage
+        constexpr int PCS_A = BM / 16, PCS_B = BN / 16;         // 1-KiB pieces per stage
+        constexpr int NPA = (PCS_A + 3) / 4, NPB = (PCS_B + 3) / 4;   // pieces per wave
+        // Per-row state is hoisted out of the K loop: a 64-bit base pointer per DMA piece (row pixel at tap (0,0), k-slot already
+        // swizzled) — inside the loop a stage's source is base + ONE wave-uniform scalar offset (tap shift + channel chunk), so the
+        // loop carries no 64-bit multiplies and no divisions (the first version of this loop was instruction-issue bound on them).
+        int a_ih0[NPA], a_iw0[NPA];
+        const bf16_t* a_ptr[NPA];
+        bool a_ok[NPA];
+#pragma unroll
+        for (int u = 0; u < NPA; u++) {
+            const int piece = wave + 4 * u;
+            const int r = piece * 16 + (lane >> 2);
+            const int64_t m = m0 + r;
+            a_ok[u] = piece < PCS_A && m < M;
+            const int64_t mm = a_ok[u] ? m : 0;
+            const int img = (int)(mm / ((int64_t)p.OH * p.OW));
+            const int rem = (int)(mm - (int64_t)img * p.OH * p.OW);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih0[u] = oh * p.sh;
+            a_iw0[u] = ow * p.sw;
+            a_ptr[u] = p.A + ((int64_t)img * p.IH * p.IW + (int64_t)a_ih0[u] * p.IW + a_iw0[u]) * p.ldA + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+        }
+        const bf16_t* b_ptr[NPB];
+        bool b_ok[NPB];
+#pragma unroll
+        for (int u = 0; u < NPB; u++) {
+            const int piece = wave + 4 * u;
+            const int r = piece * 16 + (lane >> 2);
+            b_ok[u] = piece < PCS_B && (n0 + r) < p.Nout;
+            b_ptr[u] = p.W + (int64_t)(n0 + r) * p.wtaps * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+        }
+        // tap table -> LDS (ONE __shared__ object; an ordinary VMEM load inside the loop would make hipcc drain vmcnt(0))
+        int* taptab = reinterpret_cast<int*>(smem + (MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS));
+        if (tid < tc.ntaps) taptab[tid] = (tc.dh[tid] & 0xff) | ((tc.dw[tid] & 0xff) << 8) | ((tc.widx[tid] & 0xff) << 16);
+        __syncthreads();
+        int is_t = 0, is_c0 = 0;                                  // (tap, channel chunk) of the next stage to issue
+        auto issue = [&](int step) {
+            const int packed = __builtin_amdgcn_readfirstlane(taptab[is_t]);         // wave-uniform -> scalar registers
+            const int dh = (int)(signed char)(packed & 0xff), dw = (int)(signed char)((packed >> 8) & 0xff), wi = (packed >> 16) & 0xff;
+            const int c0 = is_c0;
+            is_c0 += BK;
+            if (is_c0 >= p.Cin) { is_c0 = 0; is_t++; }
+            const int64_t a_off = ((int64_t)dh * p.IW + dw) * p.ldA + c0;            // scalar
+            const int64_t b_off = (int64_t)wi * p.Cin + c0;                          // scalar
+            bf16_t* stage = smem + (step % RY_STAGES) * STG;
+#pragma unroll
+            for (int u = 0; u < NPA; u++) {
+                const int piece = wave + 4 * u;
+                if (piece < PCS_A) {                                          // wave-uniform
+                    const bool ok = a_ok[u] && (unsigned)(a_ih0[u] + dh) < (unsigned)p.IH && (unsigned)(a_iw0[u] + dw) < (unsigned)p.IW;
+                    const bf16_t* src = ok ? a_ptr[u] + a_off : p.zeros;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + piece * 512), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NPB; u++) {
+                const int piece = wave + 4 * u;
+                if (piece < PCS_B) {
+                    const bf16_t* src = b_ok[u] ? b_ptr[u] + b_off : p.zeros;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + BM * BK + piece * 512), 16, 0, 0);
+                }
+            }
+        };
+        constexpr int LPS = NPA + NPB;                                        // DMA instructions per wave per stage (upper bound)
+#pragma unroll
+        for (int st = 0; st < RY_STAGES - 1; st++)
+            if (st < nk) issue(st);
+        for (int k = 0; k < nk; k++) {
+            // stages allowed to stay in flight while stage k is consumed
+            const int pend = min(RY_STAGES - 2, nk - 1 - k);
+            if (pend >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                     // stage k visible to all waves; stage k-1 fully consumed
+            if (k + RY_STAGES - 1 < nk) issue(k + RY_STAGES - 1);
+            const bf16_t* sa = smem + (k % RY_STAGES) * STG;
+            const bf16_t* sb = sa + BM * BK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 af[TM], bfr[TN];
+                const int sl = ks * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int r = wm * (BM / WM) + i * 32 + (lane & 31);
+                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int r = wn * (BN / WN) + j * 32 + (lane & 31);
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    else {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the kernel stub; __amdgpu_buffer_rsrc_t exists on the device side only
+        // ---- v3 mainloop: 3-stage LDS ring, `buffer_load_dwordx4 ... lds` DMA, loop unrolled by the ring size ------------------
+        // What the PMC runs showed about the first LDS-DMA loop (profiles/): the kernel was INSTRUCTION-ISSUE bound
+        // (SQ_ACTIVE_INST_ANY 41 % of wave cycles, MFMA pipe 20 % busy, ~19 non-MFMA instructions per MFMA) and occupancy bound
+        // (4 stages x 16 KiB -> 2 workgroups per CU).  Hence:
+        //   * larger per-wave tiles (TM x TN up to 4 x 2 MFMA tiles): twice the MFMAs per fragment read / DMA / loop overhead;
+        //   * buffer addressing: per-row 32-bit byte offsets computed once; per stage ONE v_add (tap shift) + ONE v_cndmask per
+        //     piece; the channel-chunk offset rides in the scalar soffset; padded / out-of-range rows set voffset = 0x80000000 and
+        //     the buffer bounds check returns zeros (hardware zero-fill, no select on pointers, no zero page);
+        //   * A stages and B stages live in two LDS regions so every fragment read is `base VGPR + immediate` (ds_read_b128
+        //     offset:imm) plus one scalar-operand add for the ring slot.
+        constexpr int NST = 3;
+        constexpr int A_ST = BM * BK, B_ST = BN * BK;             // elements per stage
+        bf16_t* const ldsA = smem;
+        bf16_t* const ldsB = smem + NST * A_ST;
+        constexpr int PCS_A = BM / 16, PCS_B = BN / 16;
+        constexpr int NPA = (PCS_A + 3) / 4, NPB = (PCS_B + 3) / 4;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+        unsigned a_voff[NPA], a_vmask[NPA], b_voff[NPB];
+#pragma unroll
+        for (int u = 0; u < NPA; u++) {
+            const int piece = wave + 4 * u;
+            const int r = piece * 16 + (lane >> 2);
+            const int64_t m = m0 + r;
+            const bool live = piece < PCS_A && m < M;
+            const int64_t mm = live ? m : 0;
+            const int img = (int)(mm / ((int64_t)p.OH * p.OW));
+            const int rem = (int)(mm - (int64_t)img * p.OH * p.OW);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih0 = oh * p.sh, iw0 = ow * p.sw;
+            a_voff[u] = (unsigned)((((int64_t)img * p.IH * p.IW + (int64_t)ih0 * p.IW + iw0) * p.ldA + ((lane & 3) ^ ((r >> 2) & 3)) * 8) * 2);
+            unsigned vm = 0;                                       // bit t: tap t reads inside the image for this row
+            for (int t = 0; t < tc.ntaps; t++)
+                if (live && (unsigned)(ih0 + tc.dh[t]) < (unsigned)p.IH && (unsigned)(iw0 + tc.dw[t]) < (unsigned)p.IW) vm |= 1u << t;
+            a_vmask[u] = vm;
+        }
+#pragma unroll
+        for (int u = 0; u < NPB; u++) {
+            const int piece = wave + 4 * u;
+            const int r = piece * 16 + (lane >> 2);
+            const bool live = piece < PCS_B && (n0 + r) < p.Nout;
+            b_voff[u] = live ? (unsigned)((((int64_t)(n0 + r) * p.wtaps) * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8) * 2) : 0x80000000u;
+        }
+        // per-tap scalars -> LDS table (read with ds_read, never with VMEM inside the loop)
+        int* taptab = reinterpret_cast<int*>(smem + (MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS));
+        if (tid < tc.ntaps) {
+            taptab[2 * tid] = (int)((((int64_t)tc.dh[tid] * p.IW + tc.dw[tid]) * p.ldA) * 2);     // A byte shift of the tap
+            taptab[2 * tid + 1] = (int)(((int64_t)tc.widx[tid] * p.Cin) * 2);                     // W byte offset of the tap
+        }
+        __syncthreads();
+        int is_t = 0, is_c0 = 0;
+        auto issue = [&](int st) {                                     // st: ring slot (wave-uniform scalar)
+            const int a_tap = __builtin_amdgcn_readfirstlane(taptab[2 * is_t]);
+            const int w_tap = __builtin_amdgcn_readfirstlane(taptab[2 * is_t + 1]);
+            const unsigned tbit = 1u << is_t;
+            const int c_off = is_c0 * 2;                               // scalar byte offset of the channel chunk
+            is_c0 += BK;
+            if (is_c0 >= p.Cin) { is_c0 = 0; is_t++; }
+            bf16_t* const da = ldsA + st * A_ST;
+            bf16_t* const db = ldsB + st * B_ST;
+#pragma unroll
+            for (int u = 0; u < NPA; u++) {
+                const int piece = wave + 4 * u;
+                if (piece < PCS_A) {
+                    const unsigned vo = (a_vmask[u] & tbit) ? a_voff[u] + (unsigned)a_tap : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(da + piece * 512), 16, vo, c_off, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NPB; u++) {
+                const int piece = wave + 4 * u;
+                if (piece < PCS_B)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(db + piece * 512), 16, b_voff[u], w_tap + c_off, 0, 0);
+            }
+        };
+        // fragment read addresses (loop invariant): [ks][tile] -> element offset inside a stage
+        int fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[TM], bfr[TN];
             const int sl = ks * 2 + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int r = wm * (BM / WM) + i * 32 + (lane & 31);
-                af[i] = *reinterpret_cast<const bf16x8*>(sA_(buf) + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
-            }
+            for (int i = 0; i < TM; i++) { const int r = wm * WTM + i * 32 + (lane & 31); fa[ks][i] = (r * 4 + (sl ^ ((r >> 2) & 3))) * 8; }
 #pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int r = wn * (BN / WN) + j * 32 + (lane & 31);
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sB_(buf) + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; j++) { const int r = wn * WTN + j * 32 + (lane & 31); fb[ks][j] = (r * 4 + (sl ^ ((r >> 2) & 3))) * 8; }
         }
-        if (k + 1 < nk) sstore(buf ^ 1);
+        constexpr int LPS = NPA + NPB;
+        issue(0);
+        if (nk > 1) issue(1);
+        int st = 0;                                                    // ring slot of stage k
+        for (int k = 0; k < nk; k++) {
+            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");     // stage k landed, stage k+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // visible to all waves; slot (k-1)%3 fully consumed
+            if (k + 2 < nk) issue(st == 0 ? 2 : st - 1);               // (k+2)%3 == (k-1)%3
+            const bf16_t* sa = ldsA + st * A_ST;
+            const bf16_t* sb = ldsB + st * B_ST;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const bf16x8*>(sa + fa[ks][i]);
+#pragma unroll
+                for (int j = 0; j < TN; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + fb[ks][j]);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
         __syncthreads();
+#endif
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------
@@ -332,32 +563,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         b_tap[u] = qq / cchunks;
         b_c0[u] = (qq - b_tap[u] * cchunks) * BK + (id & 3) * 8;
     }
+    int b_dh[2], b_dw[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) { b_dh[u] = p.dh[b_tap[u]]; b_dw[u] = p.dw[b_tap[u]]; }
+    // Loop-carried gather state (no division and no 64-bit multiply chain per K step — the first version of this loop
+    // recomputed (img, oh, ow) from the pixel index with two integer divisions per piece per step):
+    //   A pieces walk dY rows linearly: pointer += BK*ldY per step;
+    //   B pieces share ONE pixel lane per thread ((tid & 127) >> 2): (img, oh, ow) advances by BK pixels per step.
+    const bf16_t* a_ptr[PA];
+    int a_px[PA];
+    bool a_chan_ok[PA];
+#pragma unroll
+    for (int u = 0; u < PA; u++) {
+        const int id = tid + 256 * u;
+        const int px = id / APP, pc = id % APP;
+        a_px[u] = px;
+        a_chan_ok[u] = i0 + pc * 8 < p.CoutPad;
+        a_ptr[u] = p.dY + (kbeg + px) * (int64_t)p.ldY + i0 + pc * 8;
+    }
+    const int b_px = (tid & 127) >> 2;
+    int b_img, b_oh, b_ow;
+    {
+        const int64_t m = kbeg + b_px;
+        b_img = (int)(m / ((int64_t)p.OH * p.OW));
+        const int rem = (int)(m - (int64_t)b_img * p.OH * p.OW);
+        b_oh = rem / p.OW;
+        b_ow = rem - b_oh * p.OW;
+    }
+    int64_t m_step = kbeg;                                   // first pixel of the step being loaded
     auto gload = [&](int step) {
-        const int64_t mk = kbeg + (int64_t)step * BK;
+        (void)step;
 #pragma unroll
         for (int u = 0; u < PA; u++) {
-            const int id = tid + 256 * u;
-            const int px = id / APP, pc = id % APP;
-            const int64_t m = mk + px;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < kend && i0 + pc * 8 < p.CoutPad) v = *reinterpret_cast<const uint4*>(p.dY + m * p.ldY + i0 + pc * 8);
+            if (m_step + a_px[u] < kend && a_chan_ok[u]) v = *reinterpret_cast<const uint4*>(a_ptr[u]);
             ra[u] = v;
+            a_ptr[u] += (int64_t)BK * p.ldY;
         }
+        const bool pix_ok = m_step + b_px < kend;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int id = tid + 256 * u;
-            const int px = (id & 127) >> 2;
-            const int64_t m = mk + px;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < kend && b_chunk_ok[u]) {
-                const int img = (int)(m / ((int64_t)p.OH * p.OW));
-                const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                const int ih = oh * p.sh + p.dh[b_tap[u]], iw = ow * p.sw + p.dw[b_tap[u]];
+            if (pix_ok && b_chunk_ok[u]) {
+                const int ih = b_oh * p.sh + b_dh[u], iw = b_ow * p.sw + b_dw[u];
                 if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
-                    v = *reinterpret_cast<const uint4*>(p.X + (((int64_t)img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0[u]);
+                    v = *reinterpret_cast<const uint4*>(p.X + (((int64_t)b_img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0[u]);
             }
             rb[u] = v;
+        }
+        m_step += BK;
+        b_ow += BK;
+        while (b_ow >= p.OW) {
+            b_ow -= p.OW;
+            if (++b_oh >= p.OH) { b_oh = 0; b_img++; }
         }
     };
     auto sstore = [&](int buf) {
@@ -466,37 +724,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     }
 }
 
-// dW[co][cin][tap] += sum_z partial[z][co][tap*Cin + cin]   (torch weight layout, one thread per element, fixed order)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splitk, int Cout, int Cin, int ntaps,
-                                                           float* __restrict__ dW)
+// dW[co][cin][tap] += sum_z partial[z][co][tap*Cin + cin]   (torch weight layout; fixed summation order => deterministic).
+// One workgroup per (co, 32-channel chunk): 32 channel lanes x 32 split lanes read the split-K slabs with 128-byte
+// coalesced rows, an LDS tree folds the split lanes, and the [tap][cin] -> [cin][tap] transpose happens in LDS so the
+// read-modify-write of the torch-layout gradient is one contiguous 32*ntaps-float run.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splitk, int Cout, int Cin, int ntaps,
+                                                            float* __restrict__ dW)
 {
+    __shared__ float red[32][RY_MAX_TAPS][33];
+    const int c = threadIdx.x & 31, zl = threadIdx.x >> 5;
+    const int co = blockIdx.x, cin0 = blockIdx.y * 32;
     const int NK = ntaps * Cin;
-    const int64_t total = (int64_t)Cout * NK;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t slab = (int64_t)Cout * NK;
+    const float* base = partial + (int64_t)co * NK + cin0 + c;
+    for (int t = 0; t < ntaps; t++) {
         float s = 0.f;
-        for (int z = 0; z < splitk; z++) s += partial[(int64_t)z * total + i];
-        const int co = (int)(i / NK), kc = (int)(i - (int64_t)co * NK);
-        const int tap = kc / Cin, cin = kc - tap * Cin;
-        dW[((int64_t)co * Cin + cin) * ntaps + tap] += s;
+        for (int z = zl; z < splitk; z += 32) s += base[(int64_t)z * slab + (int64_t)t * Cin];
+        red[zl][t][c] = s;
+    }
+    __syncthreads();
+    const int j = threadIdx.x;                       // output element within the contiguous run: j = cl*ntaps + t
+    if (j < 32 * ntaps) {
+        const int cl = j / ntaps, t = j - cl * ntaps;
+        float s = 0.f;
+#pragma unroll 8
+        for (int z = 0; z < 32; z++) s += red[z][t][cl];
+        dW[((int64_t)co * Cin + cin0) * ntaps + j] += s;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PIPE>
 static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
 {
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 
-extern "C" int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int* rows)
+extern "C" int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows)
 {
     // number of [2][Nout] partial-statistics rows the EPI_STATS epilogue writes (== gridM of the chosen tile)
     if (!rows) return RY_ERR_ARG;
-    *rows = (int)ry_cdiv(M, Nout <= 32 ? 256 : 128);
+    *rows = (int)ry_cdiv(M, (pipe == 2 || Nout <= 32) ? 256 : 128);
     return RY_OK;
 }
 
@@ -511,9 +783,21 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         if (p.cls[c].ntaps < 1 || p.cls[c].ntaps > RY_MAX_TAPS) return RY_ERR_ARG;
     if (p.epi == EPI_STATS && (!p.stats || p.nclasses != 1)) return RY_ERR_ARG;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
-    if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1>(p, stream);
-    if (p.Nout <= 64) return launch_gemm<128, 64, 2, 2>(p, stream);
-    return launch_gemm<128, 128, 2, 2>(p, stream);
+    if (p.pipe == 2) {
+        if (p.a_bytes == 0 || p.w_bytes == 0) return RY_ERR_ARG;
+        if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 2>(p, stream);
+        if (p.Nout <= 64) return launch_gemm<256, 64, 4, 1, 2>(p, stream);
+        return launch_gemm<256, 128, 2, 2, 2>(p, stream);
+    }
+    if (p.pipe) {
+        if (!p.zeros) return RY_ERR_ARG;
+        if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 1>(p, stream);
+        if (p.Nout <= 64) return launch_gemm<128, 64, 2, 2, 1>(p, stream);
+        return launch_gemm<128, 128, 2, 2, 1>(p, stream);
+    }
+    if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 0>(p, stream);
+    if (p.Nout <= 64) return launch_gemm<128, 64, 2, 2, 0>(p, stream);
+    return launch_gemm<128, 128, 2, 2, 0>(p, stream);
 }
 
 static int wgrad_geometry(WgradParams& p, int& bm, int& gx, int& gy)
@@ -525,7 +809,7 @@ static int wgrad_geometry(WgradParams& p, int& bm, int& gx, int& gy)
     bm = p.Cout <= 64 ? 64 : 128;
     gx = (int)ry_cdiv(p.Cout, bm);
     gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), 4);
-    int64_t want = ry_cdiv(2048, (int64_t)gx * gy);                  // ~8 workgroups per CU
+    int64_t want = ry_cdiv(1536, (int64_t)gx * gy);                  // ~6 workgroups per CU
     int64_t maxsplit = ry_cdiv(M, 16 * BK);                          // at least 16 K-steps per split
     int64_t sk = want > maxsplit ? maxsplit : want;
     if (sk < 1) sk = 1;
@@ -560,10 +844,7 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
         hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3(gx, gy, p.splitk), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128>), dim3(gx, gy, p.splitk), dim3(256), 0, stream, p);
-    const int64_t total = (int64_t)p.Cout * p.ntaps * p.Cin;
-    int64_t g = ry_cdiv(total, 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, p.partial, p.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, p.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

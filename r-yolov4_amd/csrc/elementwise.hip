@@ -14,25 +14,31 @@
 
 enum { ACT_LINEAR = 0, ACT_MISH = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
 
+// Activations and their derivatives with ONE v_exp_f32 and one/two v_rcp_f32 per element (no IEEE division, no libm):
+// these kernels move 4-6 bytes per element, so a libm tanhf/log1pf or a correctly-rounded divide per element makes them
+// VALU-bound instead of HBM-bound.  Mish uses tanh(softplus(u)) = (n^2 + 2n) / (n^2 + 2n + 2) with n = e^u.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float act_f(float u, int act)
 {
-    if (act == ACT_SILU) return u / (1.f + __expf(-u));
+    if (act == ACT_SILU) return u * fast_rcp(1.f + __expf(-u));
     if (act == ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
     if (act == ACT_MISH) {
-        const float sp = u > 20.f ? u : log1pf(__expf(u));
-        return u * tanhf(sp);
+        if (u > 20.f) return u;
+        const float n = __expf(u), w = n * (n + 2.f);
+        return u * w * fast_rcp(w + 2.f);
     }
     return u;
 }
 __device__ __forceinline__ float act_d(float u, int act)
 {
-    if (act == ACT_SILU) { const float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
+    if (act == ACT_SILU) { const float s = fast_rcp(1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
     if (act == ACT_LEAKY) return u > 0.f ? 1.f : 0.1f;
     if (act == ACT_MISH) {
-        const float sp = u > 20.f ? u : log1pf(__expf(u));
-        const float t = tanhf(sp);
-        const float s = 1.f / (1.f + __expf(-u));
-        return t + u * (1.f - t * t) * s;
+        if (u > 20.f) return 1.f;
+        const float n = __expf(u), w = n * (n + 2.f);
+        const float t = w * fast_rcp(w + 2.f);                 // tanh(softplus(u))
+        const float sg = n * fast_rcp(1.f + n);                // sigmoid(u)
+        return t + u * (1.f - t * t) * sg;
     }
     return 1.f;
 }
@@ -54,6 +60,30 @@ __device__ __forceinline__ void st8(bf16_t* p, const V8& a)
     r.x = pack_bf2(a.v[0], a.v[1]); r.y = pack_bf2(a.v[2], a.v[3]);
     r.z = pack_bf2(a.v[4], a.v[5]); r.w = pack_bf2(a.v[6], a.v[7]);
     *reinterpret_cast<uint4*>(p) = r;
+}
+
+// ------------------------------------------------------------------------------------------------ partial-row folding
+// in [rows][K*C] float -> out [S][K*C] float: slice s sums rows s, s+S, s+2S, ... in double.  Keeps the finalize kernels
+// (one workgroup per 32 channels) short when a big layer produced tens of thousands of per-tile partial rows.
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ in, int rows, int KC, int S, float* __restrict__ out)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int s = blockIdx.y, rl = threadIdx.x >> 6;             // 4 row lanes per slice
+    __shared__ double red[4][64];
+    double acc = 0.0;
+    if (col < KC)
+        for (int r = s + rl * S; r < rows; r += 4 * S) acc += (double)in[(int64_t)r * KC + col];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < KC) out[(int64_t)s * KC + col] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+#define FOLD_S 64
+static inline const float* fold_rows(const float* partial, int& rows, int KC, float* scratch, hipStream_t stream)
+{
+    if (rows <= 4 * FOLD_S || !scratch) return partial;
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)ry_cdiv(KC, 64), FOLD_S), dim3(256), 0, stream, partial, rows, KC, FOLD_S, scratch);
+    rows = FOLD_S;
+    return scratch;
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
@@ -131,6 +161,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActParams p)
         Co8 k1, k2;
         load_co(p.co1, p.C, c, k1);
         if (p.y2) load_co(p.co2, p.C, c, k2);
+#pragma unroll 2
         for (int64_t m = (int64_t)blockIdx.x * rpi + rl; m < p.M; m += (int64_t)gridDim.x * rpi) {
             const V8 a = ld8(p.y1 + m * p.ld1 + c);
             V8 b, r, o;
@@ -170,6 +201,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
             Co8 k1, k2;
             load_co(p.co1, p.C, c, k1);
             if (p.y2) load_co(p.co2, p.C, c, k2);
+#pragma unroll 2
             for (int64_t m = r0 + rl; m < r1; m += nrl) {
                 const V8 d = ld8(p.dz + m * p.lddz + c);
                 const V8 a = ld8(p.y1 + m * p.ld1 + c);
@@ -248,6 +280,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnActParams
         if (p.y2) load_co(p.co2, p.C, c, k2);
 #pragma unroll
         for (int k = 0; k < 8; k++) { mg[k] = p.bco[c + k]; mx1[k] = p.bco[p.C + c + k]; mx2[k] = p.y2 ? p.bco[2 * p.C + c + k] : 0.f; }
+#pragma unroll 2
         for (int64_t m = (int64_t)blockIdx.x * rpi + rl; m < p.M; m += (int64_t)gridDim.x * rpi) {
             const V8 d = ld8(p.dz + m * p.lddz + c);
             const V8 a = ld8(p.y1 + m * p.ld1 + c);
@@ -481,10 +514,10 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
 }
 
 // out[c] += sum_r partial[r][c]
-__global__ void colsum_rows_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out)
+__global__ void colsum_rows_kernel(const float* __restrict__ partial, int rows, int C, int Cvalid, float* __restrict__ out)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (c >= Cvalid) return;
     double s = 0.0;
     for (int r = 0; r < rows; r++) s += (double)partial[(int64_t)r * C + c];
     out[c] += (float)s;
@@ -509,11 +542,34 @@ __global__ __launch_bounds__(256) void chan_add_kernel(const bf16_t* __restrict_
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int ldx, int64_t M, int C, int rows_per_block,
                                                           float* __restrict__ partial)
 {
+    // C is a multiple of 8 here (padded head widths / ImplicitA channels): 8 channels per thread, 16-byte loads
+    __shared__ float red[256][8 + 1];
+    const int c8 = C >> 3;
+    const int cols = c8 < 256 ? c8 : 256, nrl = 256 / cols;
+    const int rl = threadIdx.x / cols, cl = threadIdx.x - rl * cols;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int64_t m = r0; m < r1; m++) s += bf2f(x[m * ldx + c]);
-        partial[(int64_t)blockIdx.x * C + c] = s;
+    for (int cb = 0; cb < c8; cb += cols) {
+        const int cc = cb + cl;
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = 0.f;
+        if (rl < nrl && cc < c8)
+            for (int64_t m = r0 + rl; m < r1; m += nrl) {
+                const V8 v = ld8(x + m * ldx + (cc << 3));
+#pragma unroll
+                for (int k = 0; k < 8; k++) s[k] += v.v[k];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) red[threadIdx.x][k] = s[k];
+        __syncthreads();
+        if (rl == 0 && cc < c8)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float t = 0.f;
+                for (int j = 0; j < nrl; j++) t += red[j * cols + cl][k];
+                partial[(int64_t)blockIdx.x * C + (cc << 3) + k] = t;
+            }
     }
 }
 
@@ -521,27 +577,46 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 // fp32 master [Cout][Cin][taps] (torch layout) -> Wf bf16 [Cout][taps][CinP] and Wd bf16 [Cin][taps][Cout] (Wd may be null).
 // CinP >= Cin: small-Cin first layers are packed as a single tap with k = tap*Cin + c zero-padded to CinP.
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __restrict__ table, int n, int64_t total)
+// Tiled repack: one workgroup per (conv, 32 output channels, 32 input channels).  Reads are whole contiguous runs of
+// 32*taps floats per output channel, the [co][c][t] block is transposed in LDS, and both bf16 images are written as
+// 64-byte segments (Wf along c, Wd along co).  `start` of an entry = index of its first tile.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __restrict__ table, int n, int64_t total_tiles)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    __shared__ float tile[32][32 * RY_MAX_TAPS + 1];
+    for (int64_t b = blockIdx.x; b < total_tiles; b += gridDim.x) {
         int lo = 0, hi = n - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].start <= i) lo = mid; else hi = mid - 1; }
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].start <= b) lo = mid; else hi = mid - 1; }
         const PackEntry e = table[lo];
-        const int64_t j = i - e.start;                      // index into the Wf image [Cout][taps or 1][CinP]
-        if (e.CinP == e.Cin) {
-            const int c = (int)(j % e.Cin);
-            const int t = (int)((j / e.Cin) % e.taps);
-            const int co = (int)(j / ((int64_t)e.Cin * e.taps));
-            const bf16_t v = f2bf(e.src[((int64_t)co * e.Cin + c) * e.taps + t]);
-            e.wf[j] = v;
-            if (e.wd) e.wd[((int64_t)c * e.taps + t) * e.CoutP + co] = v;
-        } else {
-            const int k = (int)(j % e.CinP);
-            const int co = (int)(j / e.CinP);
-            float v = 0.f;
-            if (k < e.taps * e.Cin) { const int t = k / e.Cin, c = k - t * e.Cin; v = e.src[((int64_t)co * e.Cin + c) * e.taps + t]; }
-            e.wf[j] = f2bf(v);
+        const int64_t t = b - e.start;
+        if (e.CinP != e.Cin) {
+            // small-Cin stem: single-tap image [Cout][CinP], k = tap*Cin + c (zero padded); one tile = 256 elements
+            const int64_t j = t * 256 + threadIdx.x;
+            if (j < (int64_t)e.Cout * e.CinP) {
+                const int k = (int)(j % e.CinP), co = (int)(j / e.CinP);
+                float v = 0.f;
+                if (k < e.taps * e.Cin) { const int tp = k / e.Cin, c = k - tp * e.Cin; v = e.src[((int64_t)co * e.Cin + c) * e.taps + tp]; }
+                e.wf[j] = f2bf(v);
+            }
+            continue;
         }
+        const int nct = e.Cin / 32;
+        const int co0 = (int)(t / nct) * 32, c0 = (int)(t % nct) * 32;
+        const int run = 32 * e.taps;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * run; i += 256) {
+            const int r = i / run, k = i - r * run;
+            tile[r][k] = (co0 + r < e.Cout) ? e.src[((int64_t)(co0 + r) * e.Cin + c0) * e.taps + k] : 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * run; i += 256) {          // Wf[co][t][c]: c fastest
+            const int c = i & 31, tp = (i >> 5) % e.taps, r = i / run;
+            if (co0 + r < e.Cout) e.wf[((int64_t)(co0 + r) * e.taps + tp) * e.CinP + c0 + c] = f2bf(tile[r][c * e.taps + tp]);
+        }
+        if (e.wd)
+            for (int i = threadIdx.x; i < 32 * run; i += 256) {      // Wd[c][t][co]: co fastest
+                const int r = i & 31, tp = (i >> 5) % e.taps, c = i / run;
+                if (co0 + r < e.Cout) e.wd[((int64_t)(c0 + c) * e.taps + tp) * e.CoutP + co0 + r] = f2bf(tile[r][c * e.taps + tp]);
+            }
     }
 }
 
@@ -582,7 +657,7 @@ static inline unsigned grid_rows(int64_t M, int C)
 {
     const int c8 = C >> 3, cols = c8 < 256 ? c8 : 256, rpi = 256 / cols;
     int64_t g = ry_cdiv(M, (int64_t)rpi * 4);               // >= 4 rows per thread
-    if (g > 4096) g = 4096;
+    if (g > 8192) g = 8192;
     if (g < 1) g = 1;
     return (unsigned)g;
 }
@@ -592,6 +667,12 @@ extern "C" int ryolo_bn_finalize(const float* partial, int rows, int C, double c
                                  const float* beta, float* running_mean, float* running_var, float* coeffs, hipStream_t stream)
 {
     if (!partial || !gamma || !beta || !coeffs || C <= 0 || rows <= 0) return RY_ERR_ARG;
+    // rows > 256: fold in place into the first FOLD_S rows' worth of a scratch area appended by the caller?  The partial
+    // buffer itself is dead after this call, so its tail (rows >= FOLD_S) is reused as the folded output.
+    if (rows > 4 * FOLD_S) {
+        float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * C;      // caller allocates rows + FOLD_S rows
+        partial = fold_rows(partial, rows, 2 * C, scratch, stream);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ry_cdiv(C, 32)), dim3(1024), 0, stream, partial, rows, C, count, eps, momentum,
                        gamma, beta, running_mean, running_var, coeffs);
     RY_CHECK_LAUNCH();
@@ -624,8 +705,8 @@ extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_pe
     const int c8 = C >> 3;
     const int cols = c8 < 256 ? c8 : 256;
     const int nrl = 256 / cols;
-    int64_t blocks = ry_cdiv(M, (int64_t)nrl * 16);                 // >= 16 rows per row lane
-    if (blocks > 1024) blocks = 1024;
+    int64_t blocks = ry_cdiv(M, (int64_t)nrl * 8);                  // >= 8 rows per row lane
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     *rows_per_block = (int)ry_cdiv(M, blocks);
     *nblk = (int)ry_cdiv(M, *rows_per_block);
@@ -645,7 +726,9 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     p.bco = bco;
     const int K = p.y2 ? 3 : 2;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, p.partial, nblk, K, p.C,
+    int frows = nblk;
+    const float* fpart = fold_rows(p.partial, frows, K * p.C, p.partial + (int64_t)nblk * K * p.C, stream);   // caller allocates nblk + 64 rows
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, fpart, frows, K, p.C,
                        (double)p.M, frozen, bco, dgamma1, dbeta1, dgamma2, dbeta2);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_rows(p.M, p.C)), dim3(256), 0, stream, p);
     RY_CHECK_LAUNCH();
@@ -717,7 +800,7 @@ extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ld
     hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd,
                        mul ? scratch : nullptr, rpb);
     if (mul)
-        hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(na * attrs, 256)), dim3(256), 0, stream, scratch, nblk, na * attrs, dmul);
+        hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(na * attrs, 256)), dim3(256), 0, stream, scratch, nblk, na * attrs, na * attrs, dmul);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -731,15 +814,15 @@ extern "C" int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t 
     return RY_OK;
 }
 
-// out[c] += sum_m x[m][c]; scratch needs ceil(M/256)*C floats
-extern "C" int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, float* out, float* scratch, hipStream_t stream)
+// out[c] += sum_m x[m][c] for c < Cout (C = padded width, multiple of 8); scratch needs ceil(M/1024)*C floats
+extern "C" int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, hipStream_t stream)
 {
-    if (!x || !out || !scratch) return RY_ERR_ARG;
+    if (!x || !out || !scratch || (C & 7) || (ldx & 7) || Cvalid > C) return RY_ERR_ARG;
     if (M == 0) return RY_OK;
-    const int rpb = 256;
+    const int rpb = 1024;
     const int nblk = (int)ry_cdiv(M, rpb);
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, M, C, rpb, scratch);
-    hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, scratch, nblk, C, out);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, scratch, nblk, C, Cvalid, out);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -747,7 +830,7 @@ extern "C" int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, flo
 extern "C" int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t total, hipStream_t stream)
 {
     if (!table_dev || n <= 0 || total <= 0) return RY_ERR_ARG;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, stream, table_dev, n, total);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)(total > 16384 ? 16384 : total)), dim3(256), 0, stream, table_dev, n, total);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -51,6 +51,10 @@ class TRef:
     def ptr(self):
         return self.buf.t.data_ptr() + 2 * self.c0
 
+    @property
+    def span_bytes(self):
+        return (self.M * self.ld - self.c0) * 2
+
     def gptr(self):
         return self.buf.grad_tensor().data_ptr() + 2 * self.c0
 
@@ -177,6 +181,9 @@ class Graph:
             p.scale, p.shift = coeffs.data_ptr() + 2 * Cn * 4, coeffs.data_ptr() + 3 * Cn * 4
         p.act = act
         p.bias = bias
+        p.zeros = self.rt.zeros.data_ptr()
+        p.a_bytes, p.w_bytes = A.span_bytes, W.numel() * 2
+        p.pipe = self.rt.gemm_pipe if max(p.a_bytes, p.w_bytes) < (1 << 31) else 1
         self._call(tape, "ryolo_conv_gemm", p)
 
     def _conv_geom(self, conv, x):
@@ -237,8 +244,8 @@ class Graph:
         stats = None
         if want_stats:
             rows = S.I()
-            hip.call("ryolo_conv_gemm_stats_rows", M, cout, rows)
-            stats = self.f32(rows.value, 2, cout)
+            hip.call("ryolo_conv_gemm_stats_rows", M, cout, rt.gemm_pipe, rows)
+            stats = self.f32(rows.value + 64, 2, cout)[:rows.value]      # +64 rows: fold scratch of ryolo_bn_finalize
         epi = S.EPI_STATS if want_stats else S.EPI_RAW
         self._gemm(self.fwd, x, x.ptr(), pk["wf"], cout, k * k, conv.in_channels, OH, OW, s, [(_taps_fwd(k, pad), 0, 0)], epi, y.ptr(),
                    y.ld, stats=stats)
@@ -264,8 +271,8 @@ class Graph:
         stats = None
         if want_stats:
             rows = S.I()
-            hip.call("ryolo_conv_gemm_stats_rows", y.M, cout, rows)
-            stats = self.f32(rows.value, 2, cout)
+            hip.call("ryolo_conv_gemm_stats_rows", y.M, cout, rt.gemm_pipe, rows)
+            stats = self.f32(rows.value + 64, 2, cout)[:rows.value]
         self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)], S.EPI_STATS if want_stats else S.EPI_RAW,
                    y.ptr(), y.ld, stats=stats)
 
@@ -312,7 +319,7 @@ class Graph:
             def backward():
                 nblk, rpb = S.I(), S.I()
                 hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
-                partial = self.f32(nblk.value, 2, cout)
+                partial = self.f32(nblk.value + 64, 2, cout)
                 bco = self.f32(3, cout)
                 q = S.BnActParams()
                 C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
@@ -355,7 +362,7 @@ class Graph:
             def backward():
                 nblk, rpb = S.I(), S.I()
                 hip.call("ryolo_bn_act_bwd_blocks", ya.M, cout, nblk, rpb)
-                partial = self.f32(nblk.value, 3, cout)
+                partial = self.f32(nblk.value + 64, 3, cout)
                 bco = self.f32(3, cout)
                 q = S.BnActParams()
                 C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
@@ -450,15 +457,16 @@ class Graph:
 
             class _G:                      # geometry shim so dpre can be used as a gathered operand
                 N, H, W, ld = x.N, x.H, x.W, coutp
+                span_bytes = M * coutp * 2
 
             def backward():
                 self._call(self.bwd, "ryolo_head_finish_bwd", dout.data_ptr(), pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs,
                            dpre.data_ptr(), coutp, rt.grad_ptr(implicit_m) if implicit_m is not None else None, scratch.data_ptr())
-                self._call(self.bwd, "ryolo_colsum_bf16", dpre.data_ptr(), coutp, M, cout, rt.grad_ptr(conv.bias), scratch.data_ptr())
+                self._call(self.bwd, "ryolo_colsum_bf16", dpre.data_ptr(), coutp, M, coutp, cout, rt.grad_ptr(conv.bias), scratch.data_ptr())
                 self._wgrad(conv, _G, dpre.data_ptr(), coutp, xin)
                 self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, xin)
                 if implicit_a is not None:
-                    self._call(self.bwd, "ryolo_colsum_bf16", xin.gptr(), xin.ld, M, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
+                    self._call(self.bwd, "ryolo_colsum_bf16", xin.gptr(), xin.ld, M, x.C, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
                     # d(x + a)/dx = 1: route the gradient through by copying the slice (x has a single consumer here)
                     mode = x.grad_write_mode()
                     assert mode == 0

@@ -1,6 +1,7 @@
 """Per-model device runtime: flat fp32 parameter / gradient / momentum buffers, bf16 packed weights, cached execution
 plans, and the autograd bridge (ONE autograd node for the whole backbone + neck instead of ~600)."""
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,8 @@ class Runtime:
         self._pack_table = None
         self._graphs = {}
         self.momentum_buf = None
+        self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)       # source of padded rows for the LDS-DMA GEMM loop
+        self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", "1"))          # 2: buffer-DMA ring + 256-row tiles, 1: flat LDS-DMA ring, 0: register staged
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -108,7 +111,10 @@ class Runtime:
                 e.src, e.wf = pk["conv"].weight.data_ptr(), pk["wf"].data_ptr()
                 e.wd = pk["wd"].data_ptr() if pk["wd"] is not None else None
                 e.Cout, e.Cin, e.taps, e.CinP, e.CoutP, e.start = pk["Cout"], pk["Cin"], pk["taps"], pk["CinP"], pk["CoutP"], start
-                start += pk["wf"].numel()
+                if pk["CinP"] != pk["Cin"]:
+                    start += (pk["Cout"] * pk["CinP"] + 255) // 256          # stem: 256-element tiles
+                else:
+                    start += ((pk["Cout"] + 31) // 32) * (pk["Cin"] // 32)       # 32x32 (co, cin) tiles
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._pack_table = (host.to(self.device), len(ents), start)
         tab, n, total = self._pack_table

@@ -19,7 +19,7 @@ class ConvGemmParams(C.Structure):
     _fields_ = [("A", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldA", I),
                 ("W", P), ("Nout", I), ("wtaps", I), ("OH", I), ("OW", I), ("sh", I), ("sw", I),
                 ("oh_mul", I), ("ow_mul", I), ("OHf", I), ("OWf", I), ("nclasses", I), ("cls", TapClass * 4),
-                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P)]
+                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint)]
 
 
 class WgradParams(C.Structure):
@@ -60,7 +60,7 @@ class LossParams(C.Structure):
 _PTR = C.POINTER
 for _name, _sig in {
     "ryolo_conv_gemm": [_PTR(ConvGemmParams), P],
-    "ryolo_conv_gemm_stats_rows": [L, I, _PTR(I)],
+    "ryolo_conv_gemm_stats_rows": [L, I, I, _PTR(I)],
     "ryolo_conv_wgrad": [_PTR(WgradParams), P],
     "ryolo_conv_wgrad_plan": [_PTR(WgradParams), _PTR(I), _PTR(Z)],
     "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
@@ -76,7 +76,7 @@ for _name, _sig in {
     "ryolo_head_finish_fwd": [P, I, P, I, I, I, I, P, P],
     "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P],
     "ryolo_chan_add": [P, I, P, L, I, P, I, P],
-    "ryolo_colsum_bf16": [P, I, L, I, P, P, P],
+    "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],
     "ryolo_unpack_wgrad": [P, I, I, I, I, P, P],
     "ryolo_sgd_nesterov": [P, P, P, L, F, F, F, I, P],

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libryolo_hip.so")
+LIB_PATH = os.environ.get("RYOLO_LIB", os.path.join(_HERE, "csrc", "libryolo_hip.so"))     # RYOLO_LIB: A/B builds of the same ABI
 _ERR = {1: "invalid argument", 2: "workspace too small", 3: "kernel launch failed", 4: "unsupported size/configuration"}
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t

@@ -1,0 +1,46 @@
+"""Single-layer microbenchmark of ryolo_conv_gemm (forward 3x3 / 1x1) through the C ABI — for PMC runs and A/B tests.
+usage: python tools/bench_conv.py [B H Cin Cout k stride pipe reps]"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ryolov4_amd import hip
+from ryolov4_amd.engine import structs as S
+args = [int(a) for a in sys.argv[1:]] + [None] * 8
+B, H, Cin, Cout, k, stride, pipe, reps = [a if a is not None else d for a, d in zip(args[:8], (8, 200, 128, 128, 3, 1, 1, 20))]
+dev = "cuda:0"
+hip.lib(); S.check_layouts()
+pad = (k - 1) // 2
+OH = (H + 2 * pad - k) // stride + 1
+x = torch.randn(B * H * H, Cin, device=dev).to(torch.bfloat16)
+w = (torch.randn(Cout, k * k, Cin, device=dev) * 0.05).to(torch.bfloat16)
+y = torch.empty(B * OH * OH, Cout, dtype=torch.bfloat16, device=dev)
+zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+p = S.ConvGemmParams()
+p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = x.data_ptr(), B, H, H, Cin, Cin
+p.W, p.Nout, p.wtaps = w.data_ptr(), Cout, k * k
+p.OH, p.OW, p.sh, p.sw = OH, OH, stride, stride
+p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, OH, OH
+p.nclasses = 1
+tc = p.cls[0]; tc.ntaps = k * k
+for r in range(k):
+    for s in range(k):
+        tc.dh[r * k + s], tc.dw[r * k + s], tc.widx[r * k + s] = r - pad, s - pad, r * k + s
+p.epi, p.out, p.ldC = 0, y.data_ptr(), Cout
+p.zeros, p.pipe = zeros.data_ptr(), pipe
+p.a_bytes, p.w_bytes = x.numel() * 2, w.numel() * 2
+st = hip.stream()
+for _ in range(3): hip.call("ryolo_conv_gemm", p, st)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): hip.call("ryolo_conv_gemm", p, st)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / reps * 1e3
+fl = 2 * B * OH * OH * Cout * k * k * Cin
+print(f"B{B} H{H} Cin{Cin} Cout{Cout} k{k} s{stride} pipe{pipe}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s   in {x.numel()*2/1e6:.0f} MB out {y.numel()*2/1e6:.0f} MB")
+# reference check against torch (fp32) on a sample
+xr = x.float().view(B, H, H, Cin).permute(0, 3, 1, 2)
+wr = w.float().view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+ref = torch.nn.functional.conv2d(xr[:1], wr, stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+got = y[: OH * OH].float()
+print("rel err", float((got - ref).norm() / ref.norm()))
