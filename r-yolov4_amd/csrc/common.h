@@ -21,14 +21,16 @@ static inline int64_t ry_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 #include "ryolo_params.h"   // bf16_t + POD parameter blocks
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f)
+// fp32 -> bf16, round-to-nearest-even: gfx950 has a packed hardware convert (v_cvt_pk_bf16_f32); clang emits exactly that
+// instruction for a float2 -> __bf16x2 vector conversion (the hand-written integer RNE cost ~6 VALU per element).
+typedef __bf16 ry_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ry_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi)
 {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const ry_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, ry_bf16x2));
 }
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 // ---- wave64 reductions --------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)

@@ -138,41 +138,43 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // ------------------------------------------------------------------------------------------------ BN + act forward
 
-// Thread mapping shared by the three BN+act kernels: a thread owns ONE group of 8 channels (its BN coefficients live in
-// registers for the whole kernel) and walks rows; 256 threads = cols column-groups x (256/cols) rows per iteration.
-struct Co8 { float sc[8], sh[8], mu[8], is[8]; };
-__device__ __forceinline__ void load_co(const float* co, int C, int c, Co8& o)
-{
-#pragma unroll
-    for (int k = 0; k < 8; k++) { o.mu[k] = co[c + k]; o.is[k] = co[C + c + k]; o.sc[k] = co[2 * C + c + k]; o.sh[k] = co[3 * C + c + k]; }
-}
-
+// Thread mapping shared by the three BN+act kernels: a thread owns ONE group of 8 channels and walks rows; 256 threads =
+// cols column-groups x (256/cols) rows per iteration.  The kernels are templates over (activation, second branch, residual)
+// so the per-element code is branch free and small enough for 5-8 waves per SIMD (the first, runtime-switched version
+// needed ~200 VGPRs -> 2 waves per SIMD and ran at 2.4 TB/s).  Algebra is arranged for few per-channel registers:
+//   forward          u = sc*y + sh                                   (2 coefficients / channel)
+//   backward reduce  S0 = sum g, S1 = sum g*y  (g = dz*act'(u));  sum g*xhat = is*(S1 - mu*S0) is formed at finalize
+//   backward apply   dy = sc*(g - mg - xhat*mx) = sc*g + A*y + Bc,  A = -sc*is*mx,  Bc = sc*(is*mx*mu - mg)
+template <int ACT, bool Y2, bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActParams p)
 {
     const int c8 = p.C >> 3;
     const int cols = c8 < 256 ? c8 : 256;
-    const int rpi = 256 / cols;                               // rows per iteration of one workgroup
+    const int rpi = 256 / cols;
     const int rl = threadIdx.x / cols, cl = threadIdx.x - rl * cols;
     if (rl >= rpi) return;
     for (int cb = 0; cb < c8; cb += cols) {
         const int cc = cb + cl;
         if (cc >= c8) continue;
         const int c = cc << 3;
-        Co8 k1, k2;
-        load_co(p.co1, p.C, c, k1);
-        if (p.y2) load_co(p.co2, p.C, c, k2);
+        float sc1[8], sh1[8], sc2[8], sh2[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sc1[k] = p.co1[2 * p.C + c + k]; sh1[k] = p.co1[3 * p.C + c + k];
+            if (Y2) { sc2[k] = p.co2[2 * p.C + c + k]; sh2[k] = p.co2[3 * p.C + c + k]; }
+        }
 #pragma unroll 2
         for (int64_t m = (int64_t)blockIdx.x * rpi + rl; m < p.M; m += (int64_t)gridDim.x * rpi) {
             const V8 a = ld8(p.y1 + m * p.ld1 + c);
             V8 b, r, o;
-            if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
-            if (p.res) r = ld8(p.res + m * p.ldr + c);
+            if (Y2) b = ld8(p.y2 + m * p.ld2 + c);
+            if (RES) r = ld8(p.res + m * p.ldr + c);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                float u = a.v[k] * k1.sc[k] + k1.sh[k];
-                if (p.y2) u += b.v[k] * k2.sc[k] + k2.sh[k];
-                float zv = act_f(u, p.act);
-                if (p.res) zv += r.v[k];
+                float u = a.v[k] * sc1[k] + sh1[k];
+                if (Y2) u += b.v[k] * sc2[k] + sh2[k];
+                float zv = act_f(u, ACT);
+                if (RES) zv += r.v[k];
                 o.v[k] = zv;
             }
             st8(p.z + m * p.ldz + c, o);
@@ -180,49 +182,54 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActParams p)
     }
 }
 
-// backward pass 1: per-channel sums of g = dz*act'(u) and g*xhat (per branch); block = (C/8 or fewer) x row lanes
+// backward pass 1: per-channel S0 = sum g, S1 = sum g*y1 (, S2 = sum g*y2); partial [nblk][K][C]
+template <int ACT, bool Y2>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParams p)
 {
     __shared__ float red[3][256][8 + 1];
     const int c8 = p.C >> 3;
-    const int cols = c8 < 256 ? c8 : 256;              // thread columns per pass
+    const int cols = c8 < 256 ? c8 : 256;
     const int rl = threadIdx.x / cols, nrl = 256 / cols;
     const int cl = threadIdx.x - rl * cols;
     const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
     const int64_t r1 = min(p.M, r0 + p.rows_per_block);
-    const int K = p.y2 ? 3 : 2;
+    constexpr int K = Y2 ? 3 : 2;
     for (int cb = 0; cb < c8; cb += cols) {
         const int cc = cb + cl;
-        float sg[8], sx1[8], sx2[8];
+        float s0[8], s1[8], s2[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { sg[k] = 0.f; sx1[k] = 0.f; sx2[k] = 0.f; }
+        for (int k = 0; k < 8; k++) { s0[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; }
         if (rl < nrl && cc < c8) {
             const int c = cc << 3;
-            Co8 k1, k2;
-            load_co(p.co1, p.C, c, k1);
-            if (p.y2) load_co(p.co2, p.C, c, k2);
-#pragma unroll 2
+            float sc1[8], sh1[8], sc2[8], sh2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                sc1[k] = p.co1[2 * p.C + c + k]; sh1[k] = p.co1[3 * p.C + c + k];
+                if (Y2) { sc2[k] = p.co2[2 * p.C + c + k]; sh2[k] = p.co2[3 * p.C + c + k]; }
+            }
+#pragma unroll 1
             for (int64_t m = r0 + rl; m < r1; m += nrl) {
                 const V8 d = ld8(p.dz + m * p.lddz + c);
                 const V8 a = ld8(p.y1 + m * p.ld1 + c);
                 V8 b;
-                if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+                if (Y2) b = ld8(p.y2 + m * p.ld2 + c);
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    float u = a.v[k] * k1.sc[k] + k1.sh[k];
-                    if (p.y2) u += b.v[k] * k2.sc[k] + k2.sh[k];
-                    const float g = d.v[k] * act_d(u, p.act);
-                    sg[k] += g;
-                    sx1[k] += g * (a.v[k] - k1.mu[k]) * k1.is[k];
-                    if (p.y2) sx2[k] += g * (b.v[k] - k2.mu[k]) * k2.is[k];
+                    float u = a.v[k] * sc1[k] + sh1[k];
+                    if (Y2) u += b.v[k] * sc2[k] + sh2[k];
+                    const float g = d.v[k] * act_d(u, ACT);
+                    s0[k] += g;
+                    s1[k] += g * a.v[k];
+                    if (Y2) s2[k] += g * b.v[k];
                 }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; k++) { red[0][threadIdx.x][k] = sg[k]; red[1][threadIdx.x][k] = sx1[k]; red[2][threadIdx.x][k] = sx2[k]; }
+        for (int k = 0; k < 8; k++) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; if (Y2) red[2][threadIdx.x][k] = s2[k]; }
         __syncthreads();
         if (rl == 0 && cc < c8) {
+#pragma unroll
             for (int q = 0; q < K; q++) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -235,8 +242,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
     }
 }
 
-// backward finalize: sums over blocks (double) -> coefficients + dgamma/dbeta accumulation
+// backward finalize: sums over blocks (double) -> coefficients + dgamma/dbeta accumulation.
+// sum g*xhat = invstd * (S1 - mean*S0) per branch (formed in double).
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int K, int C, double count, int frozen,
+                                                               const float* __restrict__ co1, const float* __restrict__ co2,
                                                                float* __restrict__ bco /*[K][C]*/, float* __restrict__ dgamma1,
                                                                float* __restrict__ dbeta1, float* __restrict__ dgamma2,
                                                                float* __restrict__ dbeta2)
@@ -253,16 +262,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (rl == 0 && c < C) {
         for (int k = 1; k < 32; k++)
             for (int q = 0; q < K; q++) s[q] += red[q][k * 32 + cl];
+        const double gx1 = (double)co1[C + c] * (s[1] - (double)co1[c] * s[0]);
+        const double gx2 = K == 3 ? (double)co2[C + c] * (s[2] - (double)co2[c] * s[0]) : 0.0;
         // frozen statistics (eval-mode BatchNorm used as a fixed affine map): no coupling through the batch mean/variance
         bco[0 * C + c] = frozen ? 0.f : (float)(s[0] / count);
-        bco[1 * C + c] = frozen ? 0.f : (float)(s[1] / count);
-        if (K == 3) bco[2 * C + c] = frozen ? 0.f : (float)(s[2] / count);
-        if (dgamma1) { dgamma1[c] += (float)s[1]; dbeta1[c] += (float)s[0]; }
-        if (K == 3 && dgamma2) { dgamma2[c] += (float)s[2]; dbeta2[c] += (float)s[0]; }
+        bco[1 * C + c] = frozen ? 0.f : (float)(gx1 / count);
+        if (K == 3) bco[2 * C + c] = frozen ? 0.f : (float)(gx2 / count);
+        if (dgamma1) { dgamma1[c] += (float)gx1; dbeta1[c] += (float)s[0]; }
+        if (K == 3 && dgamma2) { dgamma2[c] += (float)gx2; dbeta2[c] += (float)s[0]; }
     }
 }
 
-// backward pass 2: dy = scale * (g - mean_g - xhat * mean_gx); residual gradient = dz
+// backward pass 2: dy = sc*g + A*y + Bc (see header); residual gradient = dz
+template <int ACT, bool Y2, bool DRES>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnActParams p)
 {
     const int c8 = p.C >> 3;
@@ -274,30 +286,36 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnActParams
         const int cc = cb + cl;
         if (cc >= c8) continue;
         const int c = cc << 3;
-        Co8 k1, k2;
-        float mg[8], mx1[8], mx2[8];
-        load_co(p.co1, p.C, c, k1);
-        if (p.y2) load_co(p.co2, p.C, c, k2);
+        float sc1[8], sh1[8], A1[8], B1[8], sc2[8], sh2[8], A2[8], B2[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { mg[k] = p.bco[c + k]; mx1[k] = p.bco[p.C + c + k]; mx2[k] = p.y2 ? p.bco[2 * p.C + c + k] : 0.f; }
-#pragma unroll 2
+        for (int k = 0; k < 8; k++) {
+            const float mg = p.bco[c + k];
+            {
+                const float mu = p.co1[c + k], is = p.co1[p.C + c + k], sc = p.co1[2 * p.C + c + k], mx = p.bco[p.C + c + k];
+                sc1[k] = sc; sh1[k] = p.co1[3 * p.C + c + k]; A1[k] = -sc * is * mx; B1[k] = sc * (is * mx * mu - mg);
+            }
+            if (Y2) {
+                const float mu = p.co2[c + k], is = p.co2[p.C + c + k], sc = p.co2[2 * p.C + c + k], mx = p.bco[2 * p.C + c + k];
+                sc2[k] = sc; sh2[k] = p.co2[3 * p.C + c + k]; A2[k] = -sc * is * mx; B2[k] = sc * (is * mx * mu - mg);
+            }
+        }
+#pragma unroll 1
         for (int64_t m = (int64_t)blockIdx.x * rpi + rl; m < p.M; m += (int64_t)gridDim.x * rpi) {
             const V8 d = ld8(p.dz + m * p.lddz + c);
             const V8 a = ld8(p.y1 + m * p.ld1 + c);
             V8 b, o1, o2;
-            if (p.y2) b = ld8(p.y2 + m * p.ld2 + c);
+            if (Y2) b = ld8(p.y2 + m * p.ld2 + c);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                float u = a.v[k] * k1.sc[k] + k1.sh[k];
-                if (p.y2) u += b.v[k] * k2.sc[k] + k2.sh[k];
-                const float g = d.v[k] * act_d(u, p.act);
-                const float gm = g - mg[k];
-                o1.v[k] = k1.sc[k] * (gm - (a.v[k] - k1.mu[k]) * k1.is[k] * mx1[k]);
-                if (p.y2) o2.v[k] = k2.sc[k] * (gm - (b.v[k] - k2.mu[k]) * k2.is[k] * mx2[k]);
+                float u = a.v[k] * sc1[k] + sh1[k];
+                if (Y2) u += b.v[k] * sc2[k] + sh2[k];
+                const float g = d.v[k] * act_d(u, ACT);
+                o1.v[k] = sc1[k] * g + A1[k] * a.v[k] + B1[k];
+                if (Y2) o2.v[k] = sc2[k] * g + A2[k] * b.v[k] + B2[k];
             }
             st8(p.dy1 + m * p.lddy1 + c, o1);
-            if (p.y2) st8(p.dy2 + m * p.lddy2 + c, o2);
-            if (p.dres) {
+            if (Y2) st8(p.dy2 + m * p.lddy2 + c, o2);
+            if (DRES) {
                 V8 r = d;
                 if (p.dres_accum) {
                     const V8 e = ld8(p.dres + m * p.lddres + c);
@@ -694,7 +712,22 @@ extern "C" int ryolo_bn_act_fwd(const BnActParams* pp, hipStream_t stream)
 {
     if (!pp || check_bnact(*pp) || !pp->z) return RY_ERR_ARG;
     if (pp->M == 0) return RY_OK;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_rows(pp->M, pp->C)), dim3(256), 0, stream, *pp);
+    {
+        const BnActParams& p = *pp;
+        const dim3 g(grid_rows(p.M, p.C)), b(256);
+#define RY_FWD(ACT)                                                                                                   \
+    if (p.y2 && p.res) hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, true, true>), g, b, 0, stream, p);                  \
+    else if (p.y2) hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, true, false>), g, b, 0, stream, p);                     \
+    else if (p.res) hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, false, true>), g, b, 0, stream, p);                    \
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<ACT, false, false>), g, b, 0, stream, p);
+        switch (p.act) {
+            case ACT_MISH: RY_FWD(ACT_MISH) break;
+            case ACT_LEAKY: RY_FWD(ACT_LEAKY) break;
+            case ACT_SILU: RY_FWD(ACT_SILU) break;
+            default: RY_FWD(ACT_LINEAR) break;
+        }
+#undef RY_FWD
+    }
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -725,12 +758,35 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     p.rows_per_block = rpb;
     p.bco = bco;
     const int K = p.y2 ? 3 : 2;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, p);
+#define RY_RED(ACT)                                                                                              \
+    if (p.y2) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, true>), dim3(nblk), dim3(256), 0, stream, p);        \
+    else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, false>), dim3(nblk), dim3(256), 0, stream, p);
+    switch (p.act) {
+        case ACT_MISH: RY_RED(ACT_MISH) break;
+        case ACT_LEAKY: RY_RED(ACT_LEAKY) break;
+        case ACT_SILU: RY_RED(ACT_SILU) break;
+        default: RY_RED(ACT_LINEAR) break;
+    }
+#undef RY_RED
     int frows = nblk;
     const float* fpart = fold_rows(p.partial, frows, K * p.C, p.partial + (int64_t)nblk * K * p.C, stream);   // caller allocates nblk + 64 rows
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, fpart, frows, K, p.C,
-                       (double)p.M, frozen, bco, dgamma1, dbeta1, dgamma2, dbeta2);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_rows(p.M, p.C)), dim3(256), 0, stream, p);
+                       (double)p.M, frozen, p.co1, p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2);
+    {
+        const dim3 g(grid_rows(p.M, p.C)), b(256);
+#define RY_APP(ACT)                                                                                                   \
+    if (p.y2 && p.dres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, true, true>), g, b, 0, stream, p);           \
+    else if (p.y2) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, true, false>), g, b, 0, stream, p);               \
+    else if (p.dres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, false, true>), g, b, 0, stream, p);             \
+    else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, false, false>), g, b, 0, stream, p);
+        switch (p.act) {
+            case ACT_MISH: RY_APP(ACT_MISH) break;
+            case ACT_LEAKY: RY_APP(ACT_LEAKY) break;
+            case ACT_SILU: RY_APP(ACT_SILU) break;
+            default: RY_APP(ACT_LINEAR) break;
+        }
+#undef RY_APP
+    }
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
