@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling); 64 = the reference nominal batch (train.py:150)")
     ap.add_argument("--size", type=int, default=800)
     ap.add_argument("--ver", default="yolov7")
     ap.add_argument("--mode", default="kfiou")

@@ -129,6 +129,7 @@ int ryolo_im2col(const float* img, int NB, int Cin, int H, int W, int kh, int kw
 /* detection head tail: pre [M][ldp] fp32 (conv + bias) [* ImplicitM] -> [B, na, gs, gs, attrs] (yololayer.py:25 fused) */
 int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
                           ryolo_stream_t stream);
+/* scratch >= B*na*ceil(gs*gs/64)*attrs floats; dpre pad columns (>= na*attrs) must be pre-zeroed by the caller */
 int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
                           bf16_t* dpre, int ldd, float* dmul, float* scratch, ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */

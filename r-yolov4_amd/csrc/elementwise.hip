@@ -504,31 +504,50 @@ __global__ void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, c
     out[i] = v;
 }
 
-// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand, zero padded to ldd) and per-block
-// partial sums of dout*pre for dImplicitM
+// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand; columns >= na*attrs stay zero from allocation)
+// and, with ImplicitM, per-workgroup partial sums of dout*pre.  One workgroup = (image, anchor, 64 cells): the dout slab
+// it reads is ONE contiguous run of 64*attrs floats; dpre/pre rows are attrs-float segments.
 __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, int ldp,
                                                               const float* __restrict__ mul, int B, int gs, int na, int attrs,
                                                               bf16_t* __restrict__ dpre, int ldd, float* __restrict__ dmul_partial,
-                                                              int rows_per_block)
+                                                              int cells_per_block)
 {
-    const int nch = na * attrs;
-    const int64_t M = (int64_t)B * gs * gs;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int ch = threadIdx.x; ch < ldd; ch += 256) {
-        float acc = 0.f;
-        const int a = ch / attrs, at = ch - a * attrs;
-        for (int64_t m = r0; m < r1; m++) {
-            float g = 0.f;
-            if (ch < nch) {
-                const int b = (int)(m / (gs * gs));
-                const int cell = (int)(m - (int64_t)b * gs * gs);
-                const float d = dout[((((int64_t)b * na + a) * gs * gs) + cell) * attrs + at];
-                if (mul) { acc += d * pre[m * ldp + ch]; g = d * mul[ch]; } else g = d;
-            }
-            dpre[m * ldd + ch] = f2bf(g);
-        }
-        if (dmul_partial && ch < nch) dmul_partial[(int64_t)blockIdx.x * nch + ch] = acc;
+    extern __shared__ float sacc[];                       // [attrs] partial sums of dout*pre
+    const int cells = gs * gs;
+    const int ncb = (cells + cells_per_block - 1) / cells_per_block;
+    const int cb = blockIdx.x % ncb;
+    const int ba = blockIdx.x / ncb;                      // b*na + a
+    const int a = ba % na, b = ba / na;
+    const int c0 = cb * cells_per_block;
+    const int ncell = min(cells_per_block, cells - c0);
+    if (mul) { for (int i = threadIdx.x; i < attrs; i += 256) sacc[i] = 0.f; __syncthreads(); }
+    const float* src = dout + ((int64_t)ba * cells + c0) * attrs;
+    const int total = ncell * attrs;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int cell = i / attrs, at = i - cell * attrs;
+        const int ch = a * attrs + at;
+        const int64_t m = (int64_t)b * cells + c0 + cell;
+        const float d = src[i];
+        float g = d;
+        if (mul) { atomicAdd(&sacc[at], d * pre[m * ldp + ch]); g = d * mul[ch]; }
+        dpre[m * ldd + ch] = f2bf(g);
     }
+    if (mul) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < attrs; i += 256) dmul_partial[(int64_t)blockIdx.x * attrs + i] = sacc[i];
+    }
+}
+
+// dmul[a*attrs + at] += sum over (b, cell block) of partial[((b*na + a)*ncb + cb)*attrs + at]
+__global__ void head_dmul_reduce_kernel(const float* __restrict__ partial, int B, int na, int ncb, int attrs, float* __restrict__ dmul)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na * attrs) return;
+    const int a = i / attrs, at = i - a * attrs;
+    double s = 0.0;
+    for (int b = 0; b < B; b++)
+        for (int cb = 0; cb < ncb; cb++) s += (double)partial[(((int64_t)b * na + a) * ncb + cb) * attrs + at];
+    dmul[i] += (float)s;
 }
 
 // out[c] += sum_r partial[r][c]
@@ -844,19 +863,20 @@ extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul
     return RY_OK;
 }
 
-// dmul (ImplicitM grad, may be null) is accumulated; scratch needs nblk*na*attrs floats where nblk = ceil(M/64)
+// dmul (ImplicitM grad, may be null) is accumulated; scratch needs B*na*ceil(gs*gs/64)*attrs floats; dpre columns
+// >= na*attrs must have been zeroed once by the caller (they are never written)
 extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
                                      bf16_t* dpre, int ldd, float* dmul, float* scratch, hipStream_t stream)
 {
     if (!dout || !pre || !dpre || (mul && (!dmul || !scratch))) return RY_ERR_ARG;
-    const int64_t M = (int64_t)B * gs * gs;
-    if (M == 0) return RY_OK;
-    const int rpb = 64;
-    const int nblk = (int)ry_cdiv(M, rpb);
-    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd,
-                       mul ? scratch : nullptr, rpb);
+    if ((int64_t)B * gs * gs == 0) return RY_OK;
+    const int cpb = 64;
+    const int ncb = (int)ry_cdiv((int64_t)gs * gs, cpb);
+    const int nblk = B * na * ncb;
+    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(nblk), dim3(256), mul ? attrs * sizeof(float) : 0, stream, dout, pre, ldp, mul, B, gs, na,
+                       attrs, dpre, ldd, mul ? scratch : nullptr, cpb);
     if (mul)
-        hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(na * attrs, 256)), dim3(256), 0, stream, scratch, nblk, na * attrs, na * attrs, dmul);
+        hipLaunchKernelGGL(head_dmul_reduce_kernel, dim3((unsigned)ry_cdiv(na * attrs, 256)), dim3(256), 0, stream, scratch, B, na, ncb, attrs, dmul);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -450,10 +450,10 @@ class Graph:
         if self.training:
             dout = self.f32(x.N, na, x.H, x.W, attrs)
             rec["dout"] = dout
-            dpre = torch.empty((M, coutp), dtype=BF16, device=self.dev)
+            dpre = torch.zeros((M, coutp), dtype=BF16, device=self.dev)       # pad columns stay zero
             self.keep.append(dpre)
-            nblk = (M + 63) // 64
-            scratch = self.f32(max(nblk * cout, ((M + 255) // 256) * max(coutp, x.C)))
+            nblk = x.N * na * ((x.H * x.W + 63) // 64)
+            scratch = self.f32(max(nblk * attrs, ((M + 1023) // 1024) * max(coutp, x.C)))
 
             class _G:                      # geometry shim so dpre can be used as a gathered operand
                 N, H, W, ld = x.N, x.H, x.W, coutp
