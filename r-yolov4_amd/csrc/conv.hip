@@ -59,7 +59,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 #define RY_STAGES 3
 
-template <int BM, int BN, int WM, int WN, int PIPE>
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 64 == 0, "tile config");
     constexpr int WTM = BM / WM, WTN = BN / WN;               // rows x cols of one wave's output block
     constexpr int EP_LD = WTN + 8;                            // staging row stride (bf16), 16-byte aligned, breaks bank aliasing
-    constexpr int MAINLOOP_ELEMS = (PIPE == 2 ? 3 : (PIPE ? RY_STAGES : 2)) * (BM + BN) * BK, EPI_ELEMS = 4 * WTM * EP_LD;
+    static_assert(KB == 32 || (KB == 64 && PIPE == 1), "64-channel stages exist for the flat LDS-DMA ring only");
+    constexpr int NSTG = KB == 64 ? 2 : RY_STAGES;             // 64-channel stages are twice as large: 2-deep ring, same LDS
+    constexpr int MAINLOOP_ELEMS = (PIPE == 2 ? 3 : (PIPE ? NSTG : 2)) * (BM + BN) * KB, EPI_ELEMS = 4 * WTM * EP_LD;
     constexpr int TAPTAB = 64;                                // 32 ints after the tiles: per-tap (dh, dw, widx) for the DMA loop
     __shared__ __attribute__((aligned(16))) bf16_t smem[(MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS) + TAPTAB];
 #define sA_(b) (smem + (b) * (BM + BN) * BK)
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    const int cchunks = p.Cin / BK;
+    const int cchunks = p.Cin / KB;
     const int nk = tc.ntaps * cchunks;
     if constexpr (PIPE == 0) {
         // ---- per-thread gather bookkeeping -----------------------------------------------------------------
@@ -180,23 +182,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 
 
     } else if constexpr (PIPE == 1) {
-        // ---- LDS-DMA ring: RY_STAGES stages of (BM + BN) x 32 bf16, filled by global_load_lds_dwordx4 (no VGPR staging) ----
-        // One wave instruction moves 1 KiB = 16 rows x 64 B into a lane-linear LDS image, so the bank swizzle of the
-        // fragment reads (slot ^= (row>>2)&3) is applied on the SOURCE side: lane l of a piece lands in physical slot l&3
-        // of row l>>2 and therefore fetches logical k-slot (l&3) ^ ((row>>2)&3).  Padded / out-of-range rows read p.zeros.
-        constexpr int STG = (BM + BN) * BK;                     // elements per stage
-        constexpr int PCS_A = BM / 16, PCS_B = BN / 16;         // 1-KiB pieces per stage
+        // ---- LDS-DMA ring: NSTG stages of (BM + BN) x KB bf16, filled by global_load_lds_dwordx4 (no VGPR staging) ----
+        // One wave instruction moves 1 KiB = RPP rows x (2*KB) bytes into a lane-linear LDS image, so the bank swizzle of the
+        // fragment reads is applied on the SOURCE side.  KB = 64 fetches whole 128-byte lines per pixel row (the KB = 32 gather
+        // issues two 64-byte half-line requests per line and was L2/TA request-rate bound: ablation in profiles/ + DESIGN.md).
+        //   KB = 32: 4 slots/row, phys = slot ^ ((row >> 2) & 3);   KB = 64: 8 slots/row, phys = slot ^ ((row >> 1) & 7)
+        constexpr int SPR = KB / 8;                             // 16-byte slots per row
+        constexpr int RPP = 64 / SPR;                           // rows per 1-KiB piece
+        constexpr int STG = (BM + BN) * KB;                     // elements per stage
+        constexpr int PCS_A = BM / RPP, PCS_B = BN / RPP;       // pieces per stage
         constexpr int NPA = (PCS_A + 3) / 4, NPB = (PCS_B + 3) / 4;   // pieces per wave
-        // Per-row state is hoisted out of the K loop: a 64-bit base pointer per DMA piece (row pixel at tap (0,0), k-slot already
-        // swizzled) — inside the loop a stage's source is base + ONE wave-uniform scalar offset (tap shift + channel chunk), so the
-        // loop carries no 64-bit multiplies and no divisions (the first version of this loop was instruction-issue bound on them).
+        auto swz = [](int row) { return KB == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
         int a_ih0[NPA], a_iw0[NPA];
         const bf16_t* a_ptr[NPA];
         bool a_ok[NPA];
 #pragma unroll
         for (int u = 0; u < NPA; u++) {
             const int piece = wave + 4 * u;
-            const int r = piece * 16 + (lane >> 2);
+            const int r = piece * RPP + lane / SPR;
             const int64_t m = m0 + r;
             a_ok[u] = piece < PCS_A && m < M;
             const int64_t mm = a_ok[u] ? m : 0;
@@ -205,16 +208,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             const int oh = rem / p.OW, ow = rem - oh * p.OW;
             a_ih0[u] = oh * p.sh;
             a_iw0[u] = ow * p.sw;
-            a_ptr[u] = p.A + ((int64_t)img * p.IH * p.IW + (int64_t)a_ih0[u] * p.IW + a_iw0[u]) * p.ldA + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+            a_ptr[u] = p.A + ((int64_t)img * p.IH * p.IW + (int64_t)a_ih0[u] * p.IW + a_iw0[u]) * p.ldA + ((lane % SPR) ^ swz(r)) * 8;
         }
         const bf16_t* b_ptr[NPB];
         bool b_ok[NPB];
 #pragma unroll
         for (int u = 0; u < NPB; u++) {
             const int piece = wave + 4 * u;
-            const int r = piece * 16 + (lane >> 2);
+            const int r = piece * RPP + lane / SPR;
             b_ok[u] = piece < PCS_B && (n0 + r) < p.Nout;
-            b_ptr[u] = p.W + (int64_t)(n0 + r) * p.wtaps * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+            b_ptr[u] = p.W + (int64_t)(n0 + r) * p.wtaps * p.Cin + ((lane % SPR) ^ swz(r)) * 8;
         }
         // tap table -> LDS (ONE __shared__ object; an ordinary VMEM load inside the loop would make hipcc drain vmcnt(0))
         int* taptab = reinterpret_cast<int*>(smem + (MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS));
@@ -225,11 +228,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             const int packed = __builtin_amdgcn_readfirstlane(taptab[is_t]);         // wave-uniform -> scalar registers
             const int dh = (int)(signed char)(packed & 0xff), dw = (int)(signed char)((packed >> 8) & 0xff), wi = (packed >> 16) & 0xff;
             const int c0 = is_c0;
-            is_c0 += BK;
+            is_c0 += KB;
             if (is_c0 >= p.Cin) { is_c0 = 0; is_t++; }
             const int64_t a_off = ((int64_t)dh * p.IW + dw) * p.ldA + c0;            // scalar
             const int64_t b_off = (int64_t)wi * p.Cin + c0;                          // scalar
-            bf16_t* stage = smem + (step % RY_STAGES) * STG;
+            bf16_t* stage = smem + (step % NSTG) * STG;
 #pragma unroll
             for (int u = 0; u < NPA; u++) {
                 const int piece = wave + 4 * u;
@@ -244,37 +247,37 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 const int piece = wave + 4 * u;
                 if (piece < PCS_B) {
                     const bf16_t* src = b_ok[u] ? b_ptr[u] + b_off : p.zeros;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + BM * BK + piece * 512), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + BM * KB + piece * 512), 16, 0, 0);
                 }
             }
         };
         constexpr int LPS = NPA + NPB;                                        // DMA instructions per wave per stage (upper bound)
 #pragma unroll
-        for (int st = 0; st < RY_STAGES - 1; st++)
+        for (int st = 0; st < NSTG - 1; st++)
             if (st < nk) issue(st);
         for (int k = 0; k < nk; k++) {
             // stages allowed to stay in flight while stage k is consumed
-            const int pend = min(RY_STAGES - 2, nk - 1 - k);
-            if (pend >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            else if (pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            const int pend = min(NSTG - 2, nk - 1 - k);
+            if (NSTG >= 4 && pend >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (NSTG >= 3 && pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                     // stage k visible to all waves; stage k-1 fully consumed
-            if (k + RY_STAGES - 1 < nk) issue(k + RY_STAGES - 1);
-            const bf16_t* sa = smem + (k % RY_STAGES) * STG;
-            const bf16_t* sb = sa + BM * BK;
+            if (k + NSTG - 1 < nk) issue(k + NSTG - 1);
+            const bf16_t* sa = smem + (k % NSTG) * STG;
+            const bf16_t* sb = sa + BM * KB;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
+            for (int ks = 0; ks < KB / 16; ks++) {
                 bf16x8 af[TM], bfr[TN];
                 const int sl = ks * 2 + (lane >> 5);
 #pragma unroll
                 for (int i = 0; i < TM; i++) {
                     const int r = wm * (BM / WM) + i * 32 + (lane & 31);
-                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
+                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (r * SPR + (sl ^ swz(r))) * 8);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
                     const int r = wn * (BN / WN) + j * 32 + (lane & 31);
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (r * 4 + (sl ^ ((r >> 2) & 3))) * 8);
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (r * SPR + (sl ^ swz(r))) * 8);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; i++)
@@ -754,13 +757,13 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-template <int BM, int BN, int WM, int WN, int PIPE>
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32>
 static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
 {
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 
@@ -783,7 +786,7 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         if (p.cls[c].ntaps < 1 || p.cls[c].ntaps > RY_MAX_TAPS) return RY_ERR_ARG;
     if (p.epi == EPI_STATS && (!p.stats || p.nclasses != 1)) return RY_ERR_ARG;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
-    if (p.pipe == 2) {
+    if ((p.pipe & 0xff) == 2) {
         if (p.a_bytes == 0 || p.w_bytes == 0) return RY_ERR_ARG;
         if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 2>(p, stream);
         if (p.Nout <= 64) return launch_gemm<256, 64, 4, 1, 2>(p, stream);
@@ -791,9 +794,12 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
     }
     if (p.pipe) {
         if (!p.zeros) return RY_ERR_ARG;
+        // 64-channel (full 128-byte line) stages: measured +1..5 % on 3x3 layers up to 256 channels, -4..-10 % on 1x1 / 512-channel
+        // layers (tools/bench_conv.py matrix in DESIGN.md); 0x100 forces 32-channel stages for A/B runs
+        const bool k64 = (p.Cin % 64 == 0) && p.cls[0].ntaps > 1 && p.Cin <= 256 && !(p.pipe & 0x100);
         if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 1>(p, stream);
-        if (p.Nout <= 64) return launch_gemm<128, 64, 2, 2, 1>(p, stream);
-        return launch_gemm<128, 128, 2, 2, 1>(p, stream);
+        if (p.Nout <= 64) return k64 ? launch_gemm<128, 64, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 64, 2, 2, 1>(p, stream);
+        return k64 ? launch_gemm<128, 128, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 128, 2, 2, 1>(p, stream);
     }
     if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 0>(p, stream);
     if (p.Nout <= 64) return launch_gemm<128, 64, 2, 2, 0>(p, stream);

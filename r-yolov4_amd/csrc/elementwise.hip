@@ -538,16 +538,31 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
     }
 }
 
-// dmul[a*attrs + at] += sum over (b, cell block) of partial[((b*na + a)*ncb + cb)*attrs + at]
-__global__ void head_dmul_reduce_kernel(const float* __restrict__ partial, int B, int na, int ncb, int attrs, float* __restrict__ dmul)
+// dmul[a*attrs + at] += sum over (b, cell block) of partial[((b*na + a)*ncb + cb)*attrs + at].
+// One workgroup per anchor: 256 threads = 32 attr lanes x 8 row lanes, LDS tree over the row lanes, double accumulation.
+__global__ __launch_bounds__(256) void head_dmul_reduce_kernel(const float* __restrict__ partial, int B, int na, int ncb, int attrs,
+                                                               float* __restrict__ dmul)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= na * attrs) return;
-    const int a = i / attrs, at = i - a * attrs;
-    double s = 0.0;
-    for (int b = 0; b < B; b++)
-        for (int cb = 0; cb < ncb; cb++) s += (double)partial[(((int64_t)b * na + a) * ncb + cb) * attrs + at];
-    dmul[i] += (float)s;
+    __shared__ double red[8][32];
+    const int a = blockIdx.x;
+    const int al = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int nrows = B * ncb;
+    for (int a0 = 0; a0 < attrs; a0 += 32) {
+        const int at = a0 + al;
+        double s = 0.0;
+        if (at < attrs)
+            for (int r = rl; r < nrows; r += 8) {
+                const int b = r / ncb, cb = r - b * ncb;
+                s += (double)partial[(((int64_t)b * na + a) * ncb + cb) * attrs + at];
+            }
+        __syncthreads();
+        red[rl][al] = s;
+        __syncthreads();
+        if (rl == 0 && at < attrs) {
+            for (int k = 1; k < 8; k++) s += red[k][al];
+            dmul[a * attrs + at] += (float)s;
+        }
+    }
 }
 
 // out[c] += sum_r partial[r][c]
@@ -876,7 +891,7 @@ extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ld
     hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(nblk), dim3(256), mul ? attrs * sizeof(float) : 0, stream, dout, pre, ldp, mul, B, gs, na,
                        attrs, dpre, ldd, mul ? scratch : nullptr, cpb);
     if (mul)
-        hipLaunchKernelGGL(head_dmul_reduce_kernel, dim3((unsigned)ry_cdiv(na * attrs, 256)), dim3(256), 0, stream, scratch, B, na, ncb, attrs, dmul);
+        hipLaunchKernelGGL(head_dmul_reduce_kernel, dim3(na), dim3(256), 0, stream, scratch, B, na, ncb, attrs, dmul);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -266,6 +266,7 @@ class Graph:
         kp = pk["CinP"]
         col = self.new(self.B, OH, OW, kp)
         self._call(self.fwd, "ryolo_im2col", self.img.data_ptr(), self.B, 3, self.Hin, self.Win, k, k, s, pad, OH, OW, kp, col.ptr())
+        self._img_slot = len(self.fwd) - 1         # tape entry whose first argument (the image pointer) is patched per call
         cout = conv.out_channels
         y = self.new(self.B, OH, OW, cout)
         stats = None
@@ -462,6 +463,7 @@ class Graph:
             def backward():
                 self._call(self.bwd, "ryolo_head_finish_bwd", dout.data_ptr(), pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs,
                            dpre.data_ptr(), coutp, rt.grad_ptr(implicit_m) if implicit_m is not None else None, scratch.data_ptr())
+                rec["dout_slot"] = len(self.bwd) - 1   # first argument (dout pointer) is patched per call when the caller's grad is usable as is
                 self._call(self.bwd, "ryolo_colsum_bf16", dpre.data_ptr(), coutp, M, coutp, cout, rt.grad_ptr(conv.bias), scratch.data_ptr())
                 self._wgrad(conv, _G, dpre.data_ptr(), coutp, xin)
                 self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, xin)
@@ -475,6 +477,17 @@ class Graph:
                                      (), "implicit_a_grad_copy"))
             self._pending_bwd.append(backward)
         return out
+
+    def set_image(self, imgs):
+        """Use the caller's [B,3,S,S] fp32 tensor in place (no staging copy) when it is contiguous."""
+        fn, args, name = self.fwd[self._img_slot]
+        self.fwd[self._img_slot] = (fn, (imgs.data_ptr(),) + args[1:], name)
+        self._img_ref = imgs                        # keep alive until the next call
+
+    def set_head_grad(self, rec, grad):
+        fn, args, name = self.bwd[rec["dout_slot"]]
+        self.bwd[rec["dout_slot"]] = (fn, (grad.data_ptr(),) + args[1:], name)
+        rec["dout_ref"] = grad
 
     # ------------------------------------------------------------------ plan assembly
     def begin(self):

@@ -150,7 +150,11 @@ class NetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, imgs, anchor, rt, g):
-        g.img.copy_(imgs)
+        if imgs.dtype == torch.float32 and imgs.is_contiguous():
+            g.set_image(imgs)
+        else:
+            g.img.copy_(imgs)
+            g.set_image(g.img)
         rt.pack()
         g.run(g.fwd, g.timer)
         if g.batch_stats:
@@ -165,8 +169,12 @@ class NetFunction(torch.autograd.Function):
         for h, go in zip(g.heads, grads):
             if go is None:
                 h["dout"].zero_()
+                g.set_head_grad(h, h["dout"])
+            elif go.dtype == torch.float32 and go.is_contiguous() and go.shape == h["dout"].shape:
+                g.set_head_grad(h, go)                    # read the loss gradient in place
             else:
                 h["dout"].copy_(go)
+                g.set_head_grad(h, h["dout"])
         g.run(g.bwd, g.timer)
         if rt.model._grad_hook is not None:
             rt.model._grad_hook(rt)

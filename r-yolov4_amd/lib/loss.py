@@ -24,7 +24,8 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         g = ctx.grads
-        return (None, None) + tuple(gi * go for gi in g)
+        # d(total)/d(logits) was produced by the fused kernel; scale in place by the incoming gradient (a [1] tensor)
+        return (None, None) + tuple(gi.mul_(go) for gi in g)
 
 
 class _ComputeLossBase:
