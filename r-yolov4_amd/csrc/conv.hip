@@ -24,6 +24,7 @@
 #include "common.h"
 #include "params.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
@@ -815,7 +816,8 @@ static int wgrad_geometry(WgradParams& p, int& bm, int& gx, int& gy)
     bm = p.Cout <= 64 ? 64 : 128;
     gx = (int)ry_cdiv(p.Cout, bm);
     gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), 4);
-    int64_t want = ry_cdiv(1536, (int64_t)gx * gy);                  // ~6 workgroups per CU
+    static const int target = getenv("RYOLO_WGRAD_BLOCKS") ? atoi(getenv("RYOLO_WGRAD_BLOCKS")) : 768;   // = 3 resident workgroups x 256 CUs (measured best of 768/1024/1536/2560); env knob for A/B runs
+    int64_t want = ry_cdiv(target, (int64_t)gx * gy);                // one full wave of resident workgroups by default
     int64_t maxsplit = ry_cdiv(M, 16 * BK);                          // at least 16 K-steps per split
     int64_t sk = want > maxsplit ? maxsplit : want;
     if (sk < 1) sk = 1;
