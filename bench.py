@@ -100,24 +100,30 @@ def main():
     ap.add_argument("--nc", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo only for plumbing tests")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
     from ryolov4_amd import parallel
-    rank, local, world = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local)
+    local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)                       # before the communicator is created: one process per GPU
     dev = torch.device("cuda", local)
-    ge.build()
+    rank, _, world = parallel.init_from_env(backend=args.backend)
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if rank == 0:
+        ge.build()                                     # one rank checks/builds the shared library, the others wait
+    if world > 1:
+        dist.barrier()
 
     from ryolov4_amd.lib.general import _nms_sorted_batched
     from ryolov4_amd.lib.loss import ComputeCSLLoss, ComputeKFIoULoss
     from ryolov4_amd.model.yolo import Yolo
     from ryolov4_amd.synth import CFG, HYP, synth_batch, synth_nms_boxes
-    import torch.distributed as dist
 
     torch.manual_seed(42)              # train.py:20-25
     model = Yolo(args.nc, CFG, args.mode, args.ver)
