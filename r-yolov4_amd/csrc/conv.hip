@@ -39,11 +39,12 @@ enum { ACT_LINEAR = 0, ACT_MISH = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
 
 __device__ __forceinline__ float act_fwd(float u, int act)
 {
-    if (act == ACT_SILU) return u / (1.f + __expf(-u));
+    if (act == ACT_SILU) return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));
     if (act == ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
     if (act == ACT_MISH) {
-        const float sp = u > 20.f ? u : log1pf(__expf(u));
-        return u * tanhf(sp);
+        if (u > 20.f) return u;
+        const float n = __expf(u), w = n * (n + 2.f);       // tanh(softplus(u)) = (n^2 + 2n) / (n^2 + 2n + 2)
+        return u * w * __builtin_amdgcn_rcpf(w + 2.f);
     }
     return u;
 }
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #pragma unroll
     for (int j = 0; j < TN; j++) { csum[j] = 0.f; csq[j] = 0.f; }
 
-    if (p.epi == EPI_F32_BIAS || p.epi == EPI_AFFINE_ACT) {
-        // small / rare outputs (detection heads, fused eval epilogue): direct per-element stores
+    if (p.epi == EPI_F32_BIAS) {
+        // small outputs (detection heads): direct per-element fp32 stores
 #pragma unroll
         for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -434,13 +435,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                     const int n = n0 + wn * WTN + j * 32 + (lane & 31);
                     if (n >= p.Nout) continue;
                     float v = acc[i][j][e];
-                    if (p.epi == EPI_F32_BIAS) {
-                        if (p.bias) v += p.bias[n];
-                        reinterpret_cast<float*>(p.out)[pix * p.ldC + n] = v;
-                    } else {
-                        v = act_fwd(v * p.scale[n] + p.shift[n], p.act);
-                        reinterpret_cast<bf16_t*>(p.out)[pix * p.ldC + n] = f2bf(v);
-                    }
+                    if (p.bias) v += p.bias[n];
+                    reinterpret_cast<float*>(p.out)[pix * p.ldC + n] = v;
                 }
             }
         }
@@ -448,6 +444,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         // bf16 outputs: stage the wave's WTM x WTN block in LDS, then write whole 16-byte row segments (8 channels per lane)
         __syncthreads();                                       // every wave is done reading the operand tiles
         bf16_t* stage = smem + wave * WTM * EP_LD;
+        // eval-mode fusion (EPI_AFFINE_ACT): folded BatchNorm (running statistics) + activation applied to the fp32 accumulator,
+        // so inference writes the activation once instead of y -> (read) -> z
+        float esc[TN], esh[TN];
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+            const bool fuse = p.epi == EPI_AFFINE_ACT && n < p.Nout;
+            esc[j] = fuse ? p.scale[n] : 1.f;
+            esh[j] = fuse ? p.shift[n] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -455,7 +461,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    const bf16_t b = f2bf(acc[i][j][e]);
+                    float av = acc[i][j][e];
+                    if (p.epi == EPI_AFFINE_ACT) av = act_fwd(av * esc[j] + esh[j], p.act);
+                    const bf16_t b = f2bf(av);
                     stage[r * EP_LD + j * 32 + (lane & 31)] = b;
                     if (p.epi == EPI_STATS) {
                         const bool live = (m0 + wm * WTM + r) < M;          // rows past M are zero anyway (zero-filled A rows)

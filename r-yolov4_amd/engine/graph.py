@@ -233,22 +233,23 @@ class Graph:
         self._wgrads.append(p)
         self._call(self.bwd, "ryolo_conv_wgrad", p)
 
-    def conv_raw(self, conv, x, want_stats):
-        """Emit the forward conv; returns (y TRef [M, Cout] raw bf16, stats tensor or None, backward-emitter)."""
+    def conv_raw(self, conv, x, want_stats, fused=None):
+        """Emit the forward conv; returns (y TRef [M, Cout] raw bf16, stats tensor or None, backward-emitter).
+        fused = (coeffs [4][Cout], act code, z TRef): eval-mode epilogue writes act(bn(conv)) straight into z (no raw y)."""
         rt = self.rt
         pk = rt.packed(conv)
         k, s, pad, OH, OW = self._conv_geom(conv, x)
         cout = conv.out_channels
-        y = self.new(x.N, OH, OW, cout)
+        y = fused[2] if fused else self.new(x.N, OH, OW, cout)
         M = y.M
         stats = None
         if want_stats:
             rows = S.I()
             hip.call("ryolo_conv_gemm_stats_rows", M, cout, rt.gemm_pipe, rows)
             stats = self.f32(rows.value + 64, 2, cout)[:rows.value]      # +64 rows: fold scratch of ryolo_bn_finalize
-        epi = S.EPI_STATS if want_stats else S.EPI_RAW
+        epi = S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW)
         self._gemm(self.fwd, x, x.ptr(), pk["wf"], cout, k * k, conv.in_channels, OH, OW, s, [(_taps_fwd(k, pad), 0, 0)], epi, y.ptr(),
-                   y.ld, stats=stats)
+                   y.ld, stats=stats, coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
 
         def backward(need_dx=True):
             self._wgrad(conv, y, y.gptr(), cout, x)
@@ -256,7 +257,7 @@ class Graph:
                 self._dgrad(conv, pk, y, y.gptr(), cout, x)
         return y, stats, backward
 
-    def stem_raw(self, conv, want_stats):
+    def stem_raw(self, conv, want_stats, fused=None):
         """First layer (Cin=3): explicit im2col of the fp32 NCHW image + single-tap GEMM (K padded to a multiple of 32)."""
         rt = self.rt
         pk = rt.packed(conv)
@@ -268,14 +269,15 @@ class Graph:
         self._call(self.fwd, "ryolo_im2col", self.img.data_ptr(), self.B, 3, self.Hin, self.Win, k, k, s, pad, OH, OW, kp, col.ptr())
         self._img_slot = len(self.fwd) - 1         # tape entry whose first argument (the image pointer) is patched per call
         cout = conv.out_channels
-        y = self.new(self.B, OH, OW, cout)
+        y = fused[2] if fused else self.new(self.B, OH, OW, cout)
         stats = None
         if want_stats:
             rows = S.I()
             hip.call("ryolo_conv_gemm_stats_rows", y.M, cout, rt.gemm_pipe, rows)
             stats = self.f32(rows.value + 64, 2, cout)[:rows.value]
-        self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)], S.EPI_STATS if want_stats else S.EPI_RAW,
-                   y.ptr(), y.ld, stats=stats)
+        self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)],
+                   S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW), y.ptr(), y.ld, stats=stats,
+                   coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
 
         def backward(need_dx=False):
             scratch = self.f32(cout, kp)
@@ -298,6 +300,19 @@ class Graph:
         bstat = self.batch_stats
         actc = S.ACT[act]
         cout = conv.out_channels
+        if not train and residual is None:
+            # inference: BatchNorm folded to scale/shift (running statistics) + activation inside the GEMM epilogue
+            co = self.f32(4, cout)
+            self._call(self.fwd, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                       bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
+            k_, s_, pad_ = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            H_, W_ = (self.Hin, self.Win) if stem else (x.H, x.W)
+            OH_, OW_ = (H_ + 2 * pad_ - k_) // s_ + 1, (W_ + 2 * pad_ - k_) // s_ + 1
+            z = out if out is not None else self.new(self.B if stem else x.N, OH_, OW_, cout)
+            fused = (co, actc, z)
+            (self.stem_raw(conv, False, fused) if stem else self.conv_raw(conv, x, False, fused))
+            self.debug[id(conv)] = (z, z, x)
+            return z
         y, stats, conv_bwd = (self.stem_raw(conv, bstat) if stem else self.conv_raw(conv, x, bstat))
         co = self.f32(4, cout)
         if bstat:

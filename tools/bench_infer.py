@@ -1,0 +1,53 @@
+"""Inference throughput of the hot path's eval branch (test.py:188-191 / detect.py:57-61): model(imgs, training=False)
+followed by post_process.  Reports img/s for forward only and forward + post_process; B and SZ from the environment."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from ryolov4_amd.lib.general import post_process
+from ryolov4_amd.model.yolo import Yolo
+from ryolov4_amd.synth import CFG, synth_batch
+
+dev = torch.device("cuda:0")
+out = {}
+for B in [int(b) for b in os.environ.get("B", "1,8,64").split(",")]:
+    SZ = int(os.environ.get("SZ", 800))
+    model = Yolo(16, CFG, "kfiou", "yolov7")
+    model.apply(bench.weights_init_normal)
+    model.to(dev).eval()
+    imgs, _ = synth_batch(B, SZ, 16, False, seed=42)
+    imgs = imgs.to(dev)
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def fwd():
+        with torch.no_grad():
+            return model(imgs, training=False)
+
+    def full():
+        with torch.no_grad():
+            _, inf = model(imgs, training=False)
+            return post_process(inf, 0.25, 0.45)
+
+    n = max(5, 200 // B)
+    t_f, t_a = timed(fwd, n), timed(full, n)
+    out[f"b{B}"] = {"fwd_ms": round(t_f, 3), "fwd_img_s": round(B / t_f * 1e3, 1), "fwd_pp_ms": round(t_a, 3),
+                    "fwd_pp_img_s": round(B / t_a * 1e3, 1)}
+    print(B, out[f"b{B}"], flush=True)
+    del model
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/infer.json", "w"), indent=1)
