@@ -98,6 +98,9 @@ int ryolo_pp_emit(const float* dets, const int64_t* keep, const int32_t* num_kee
 int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
 /* number of [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem under mainloop variant `pipe` */
 int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows);
+/* which kernel ryolo_conv_gemm runs for *p (0 generic implicit GEMM, 1 the 3x3 stride-1 halo-patch kernel, enabled by pipe bit
+ * 0x200 for eligible layers) and the number of partial-statistics rows its epilogue 1 writes; `kernel` may be null */
+int ryolo_conv_gemm_plan(const ConvGemmParams* p, int* stats_rows, int* kernel);
 /* weight gradient: split-K over output pixels into p->partial ([splitk][Cout][taps*Cin] fp32, size from _plan), then a
  * deterministic reduction that accumulates into the torch-layout .grad [Cout][Cin][kh*kw] (no float atomics). */
 int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_bytes);

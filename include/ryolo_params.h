@@ -30,8 +30,9 @@ typedef struct ConvGemmParams {
     const float* scale; const float* shift; int act; // EPI_AFFINE_ACT
     const float* bias;                              // EPI_F32_BIAS (may be null)
     const bf16_t* zeros;                            // >= 64 zero bytes in device memory: source of padded / out-of-range rows (LDS-DMA path)
-    int pipe;                                       // 0: register-staged double buffer, 1: LDS-DMA ring (flat), 2: buffer-DMA ring, 256-row tiles
-    unsigned a_bytes, w_bytes;                      // byte extents of A / W for the buffer descriptors (pipe 2; both < 2^31)
+    int pipe;                                       // bits 0-7 mainloop of the generic kernel: 0 register-staged double buffer, 1 LDS-DMA ring;
+                                                    // 0x100 force 32-channel stages; 0x200 3x3 stride-1 layers with >= 512 tiles run the halo-patch kernel (conv3x3.hip), 0x400 also smaller ones
+    unsigned a_bytes, w_bytes;                      // byte extents of A / W (informational; reserved for buffer-descriptor addressing)
 } ConvGemmParams;
 
 typedef struct WgradParams {

@@ -21,44 +21,14 @@
 //     so the A tile gathered by one workgroup is re-used from L2 by its n-neighbours.
 //   * weight gradient: K = output pixels (split over blockIdx.z, fp32 atomics into the torch-layout .grad),
 //     both operands staged pixel-major and read transposed from LDS.
-#include "common.h"
-#include "params.h"
+#include "conv_internal.h"
 #include <type_traits>
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define BK 32
 
-
-
-enum { EPI_RAW = 0, EPI_STATS = 1, EPI_AFFINE_ACT = 2, EPI_F32_BIAS = 3, EPI_ACCUM = 4 };
-enum { ACT_LINEAR = 0, ACT_MISH = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
-
-__device__ __forceinline__ float act_fwd(float u, int act)
-{
-    if (act == ACT_SILU) return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));
-    if (act == ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
-    if (act == ACT_MISH) {
-        if (u > 20.f) return u;
-        const float n = __expf(u), w = n * (n + 2.f);       // tanh(softplus(u)) = (n^2 + 2n) / (n^2 + 2n + 2)
-        return u * w * __builtin_amdgcn_rcpf(w + 2.f);
-    }
-    return u;
-}
-
-// bijective XCD remap (cdna guide T1): workgroup b runs on XCD b%8; give each XCD a contiguous tile range
-__device__ __forceinline__ int xcd_remap(int bid, int nwg)
-{
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-}
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 #define RY_STAGES 3
 
 template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32>
@@ -71,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     constexpr int EP_LD = WTN + 8;                            // staging row stride (bf16), 16-byte aligned, breaks bank aliasing
     static_assert(KB == 32 || (KB == 64 && PIPE == 1), "64-channel stages exist for the flat LDS-DMA ring only");
     constexpr int NSTG = KB == 64 ? 2 : RY_STAGES;             // 64-channel stages are twice as large: 2-deep ring, same LDS
-    constexpr int MAINLOOP_ELEMS = (PIPE == 2 ? 3 : (PIPE ? NSTG : 2)) * (BM + BN) * KB, EPI_ELEMS = 4 * WTM * EP_LD;
+    constexpr int MAINLOOP_ELEMS = (PIPE ? NSTG : 2) * (BM + BN) * KB, EPI_ELEMS = 4 * WTM * EP_LD;
     constexpr int TAPTAB = 64;                                // 32 ints after the tiles: per-tap (dh, dw, widx) for the DMA loop
     __shared__ __attribute__((aligned(16))) bf16_t smem[(MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS) + TAPTAB];
 #define sA_(b) (smem + (b) * (BM + BN) * BK)
@@ -176,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 for (int i = 0; i < TM; i++)
     #pragma unroll
                     for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
             if (k + 1 < nk) sstore(buf ^ 1);
             __syncthreads();
@@ -226,37 +196,51 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         if (tid < tc.ntaps) taptab[tid] = (tc.dh[tid] & 0xff) | ((tc.dw[tid] & 0xff) << 8) | ((tc.widx[tid] & 0xff) << 16);
         __syncthreads();
         int is_t = 0, is_c0 = 0;                                  // (tap, channel chunk) of the next stage to issue
-        auto issue = [&](int step) {
+        int cur_dh = 0, cur_dw = 0;
+        int64_t cur_a_off = 0, cur_b_off = 0;
+        bf16_t* cur_stage = smem;
+        auto issue_prep = [&](int step) {                         // scalar part of a stage issue
             const int packed = __builtin_amdgcn_readfirstlane(taptab[is_t]);         // wave-uniform -> scalar registers
-            const int dh = (int)(signed char)(packed & 0xff), dw = (int)(signed char)((packed >> 8) & 0xff), wi = (packed >> 16) & 0xff;
+            cur_dh = (int)(signed char)(packed & 0xff);
+            cur_dw = (int)(signed char)((packed >> 8) & 0xff);
+            const int wi = (packed >> 16) & 0xff;
             const int c0 = is_c0;
             is_c0 += KB;
             if (is_c0 >= p.Cin) { is_c0 = 0; is_t++; }
-            const int64_t a_off = ((int64_t)dh * p.IW + dw) * p.ldA + c0;            // scalar
-            const int64_t b_off = (int64_t)wi * p.Cin + c0;                          // scalar
-            bf16_t* stage = smem + (step % NSTG) * STG;
-#pragma unroll
-            for (int u = 0; u < NPA; u++) {
+            cur_a_off = ((int64_t)cur_dh * p.IW + cur_dw) * p.ldA + c0;
+            cur_b_off = (int64_t)wi * p.Cin + c0;
+            cur_stage = smem + (step % NSTG) * STG;
+        };
+        auto issue_item = [&](int it) {                           // one 1-KiB DMA piece: it < NPA -> A piece, else B piece
+            if (it < NPA) {
+                const int u = it;
                 const int piece = wave + 4 * u;
                 if (piece < PCS_A) {                                          // wave-uniform
-                    const bool ok = a_ok[u] && (unsigned)(a_ih0[u] + dh) < (unsigned)p.IH && (unsigned)(a_iw0[u] + dw) < (unsigned)p.IW;
-                    const bf16_t* src = ok ? a_ptr[u] + a_off : p.zeros;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + piece * 512), 16, 0, 0);
+                    const bool ok = a_ok[u] && (unsigned)(a_ih0[u] + cur_dh) < (unsigned)p.IH && (unsigned)(a_iw0[u] + cur_dw) < (unsigned)p.IW;
+                    const bf16_t* src = ok ? a_ptr[u] + cur_a_off : p.zeros;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(cur_stage + piece * 512), 16, 0, 0);
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < NPB; u++) {
+            } else {
+                const int u = it - NPA;
                 const int piece = wave + 4 * u;
                 if (piece < PCS_B) {
-                    const bf16_t* src = b_ok[u] ? b_ptr[u] + b_off : p.zeros;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + BM * KB + piece * 512), 16, 0, 0);
+                    const bf16_t* src = b_ok[u] ? b_ptr[u] + cur_b_off : p.zeros;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(cur_stage + BM * KB + piece * 512), 16, 0, 0);
                 }
             }
         };
         constexpr int LPS = NPA + NPB;                                        // DMA instructions per wave per stage (upper bound)
+        // NOTE: vmcnt counts issued instructions; pieces skipped by the wave-uniform `piece < PCS` test are skipped by every
+        // stage alike, and the counted waits below use the upper bound LPS only where at least that many were issued
+        // (PCS_A, PCS_B multiples of 4 for every instantiated tile except BN = 32, where the wait is simply a little stricter).
 #pragma unroll
         for (int st = 0; st < NSTG - 1; st++)
-            if (st < nk) issue(st);
+            if (st < nk) {
+                issue_prep(st);
+#pragma unroll
+                for (int it = 0; it < LPS; it++) issue_item(it);
+            }
+        constexpr int KS = KB / 16, NMF = KS * TM * TN;
         for (int k = 0; k < nk; k++) {
             // stages allowed to stay in flight while stage k is consumed
             const int pend = min(NSTG - 2, nk - 1 - k);
@@ -264,213 +248,105 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             else if (NSTG >= 3 && pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                     // stage k visible to all waves; stage k-1 fully consumed
-            if (k + NSTG - 1 < nk) issue(k + NSTG - 1);
+            const bool do_issue = k + NSTG - 1 < nk;
+            if (do_issue) issue_prep(k + NSTG - 1);
             const bf16_t* sa = smem + (k % NSTG) * STG;
             const bf16_t* sb = sa + BM * KB;
+            // every fragment of the stage is read up front into its own registers (hipcc otherwise re-uses one register set per
+            // 16-channel sub-step and exposes an LDS round trip between the MFMA groups), then the MFMAs run with the next stage's
+            // DMA instructions spread in their shadow (an LDS-DMA issue next to ds_reads costs 100-185 cycles, guide price table)
+            bf16x8 af[KS][TM], bfr[KS][TN];
 #pragma unroll
-            for (int ks = 0; ks < KB / 16; ks++) {
-                bf16x8 af[TM], bfr[TN];
+            for (int ks = 0; ks < KS; ks++) {
                 const int sl = ks * 2 + (lane >> 5);
 #pragma unroll
                 for (int i = 0; i < TM; i++) {
                     const int r = wm * (BM / WM) + i * 32 + (lane & 31);
-                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (r * SPR + (sl ^ swz(r))) * 8);
+                    af[ks][i] = *reinterpret_cast<const bf16x8*>(sa + (r * SPR + (sl ^ swz(r))) * 8);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
                     const int r = wn * (BN / WN) + j * 32 + (lane & 31);
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (r * SPR + (sl ^ swz(r))) * 8);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    else {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the kernel stub; __amdgpu_buffer_rsrc_t exists on the device side only
-        // ---- v3 mainloop: 3-stage LDS ring, `buffer_load_dwordx4 ... lds` DMA, loop unrolled by the ring size ------------------
-        // What the PMC runs showed about the first LDS-DMA loop (profiles/): the kernel was INSTRUCTION-ISSUE bound
-        // (SQ_ACTIVE_INST_ANY 41 % of wave cycles, MFMA pipe 20 % busy, ~19 non-MFMA instructions per MFMA) and occupancy bound
-        // (4 stages x 16 KiB -> 2 workgroups per CU).  Hence:
-        //   * larger per-wave tiles (TM x TN up to 4 x 2 MFMA tiles): twice the MFMAs per fragment read / DMA / loop overhead;
-        //   * buffer addressing: per-row 32-bit byte offsets computed once; per stage ONE v_add (tap shift) + ONE v_cndmask per
-        //     piece; the channel-chunk offset rides in the scalar soffset; padded / out-of-range rows set voffset = 0x80000000 and
-        //     the buffer bounds check returns zeros (hardware zero-fill, no select on pointers, no zero page);
-        //   * A stages and B stages live in two LDS regions so every fragment read is `base VGPR + immediate` (ds_read_b128
-        //     offset:imm) plus one scalar-operand add for the ring slot.
-        constexpr int NST = 3;
-        constexpr int A_ST = BM * BK, B_ST = BN * BK;             // elements per stage
-        bf16_t* const ldsA = smem;
-        bf16_t* const ldsB = smem + NST * A_ST;
-        constexpr int PCS_A = BM / 16, PCS_B = BN / 16;
-        constexpr int NPA = (PCS_A + 3) / 4, NPB = (PCS_B + 3) / 4;
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
-        unsigned a_voff[NPA], a_vmask[NPA], b_voff[NPB];
-#pragma unroll
-        for (int u = 0; u < NPA; u++) {
-            const int piece = wave + 4 * u;
-            const int r = piece * 16 + (lane >> 2);
-            const int64_t m = m0 + r;
-            const bool live = piece < PCS_A && m < M;
-            const int64_t mm = live ? m : 0;
-            const int img = (int)(mm / ((int64_t)p.OH * p.OW));
-            const int rem = (int)(mm - (int64_t)img * p.OH * p.OW);
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            const int ih0 = oh * p.sh, iw0 = ow * p.sw;
-            a_voff[u] = (unsigned)((((int64_t)img * p.IH * p.IW + (int64_t)ih0 * p.IW + iw0) * p.ldA + ((lane & 3) ^ ((r >> 2) & 3)) * 8) * 2);
-            unsigned vm = 0;                                       // bit t: tap t reads inside the image for this row
-            for (int t = 0; t < tc.ntaps; t++)
-                if (live && (unsigned)(ih0 + tc.dh[t]) < (unsigned)p.IH && (unsigned)(iw0 + tc.dw[t]) < (unsigned)p.IW) vm |= 1u << t;
-            a_vmask[u] = vm;
-        }
-#pragma unroll
-        for (int u = 0; u < NPB; u++) {
-            const int piece = wave + 4 * u;
-            const int r = piece * 16 + (lane >> 2);
-            const bool live = piece < PCS_B && (n0 + r) < p.Nout;
-            b_voff[u] = live ? (unsigned)((((int64_t)(n0 + r) * p.wtaps) * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8) * 2) : 0x80000000u;
-        }
-        // per-tap scalars -> LDS table (read with ds_read, never with VMEM inside the loop)
-        int* taptab = reinterpret_cast<int*>(smem + (MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS));
-        if (tid < tc.ntaps) {
-            taptab[2 * tid] = (int)((((int64_t)tc.dh[tid] * p.IW + tc.dw[tid]) * p.ldA) * 2);     // A byte shift of the tap
-            taptab[2 * tid + 1] = (int)(((int64_t)tc.widx[tid] * p.Cin) * 2);                     // W byte offset of the tap
-        }
-        __syncthreads();
-        int is_t = 0, is_c0 = 0;
-        auto issue = [&](int st) {                                     // st: ring slot (wave-uniform scalar)
-            const int a_tap = __builtin_amdgcn_readfirstlane(taptab[2 * is_t]);
-            const int w_tap = __builtin_amdgcn_readfirstlane(taptab[2 * is_t + 1]);
-            const unsigned tbit = 1u << is_t;
-            const int c_off = is_c0 * 2;                               // scalar byte offset of the channel chunk
-            is_c0 += BK;
-            if (is_c0 >= p.Cin) { is_c0 = 0; is_t++; }
-            bf16_t* const da = ldsA + st * A_ST;
-            bf16_t* const db = ldsB + st * B_ST;
-#pragma unroll
-            for (int u = 0; u < NPA; u++) {
-                const int piece = wave + 4 * u;
-                if (piece < PCS_A) {
-                    const unsigned vo = (a_vmask[u] & tbit) ? a_voff[u] + (unsigned)a_tap : 0x80000000u;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(da + piece * 512), 16, vo, c_off, 0, 0);
+                    bfr[ks][j] = *reinterpret_cast<const bf16x8*>(sb + (r * SPR + (sl ^ swz(r))) * 8);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            int issued = 0;
 #pragma unroll
-            for (int u = 0; u < NPB; u++) {
-                const int piece = wave + 4 * u;
-                if (piece < PCS_B)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(db + piece * 512), 16, b_voff[u], w_tap + c_off, 0, 0);
+            for (int q = 0; q < NMF; q++) {
+                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
+                // A operand = weights, B operand = pixels: the accumulator holds the transposed tile (see the epilogue)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int it = 0; it < LPS; it++)
+                    if (it == issued && it * NMF < (q + 1) * LPS) {           // compile-time after unrolling: spread evenly
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (do_issue) issue_item(it);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issued++;
+                    }
             }
-        };
-        // fragment read addresses (loop invariant): [ks][tile] -> element offset inside a stage
-        int fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int sl = ks * 2 + (lane >> 5);
-#pragma unroll
-            for (int i = 0; i < TM; i++) { const int r = wm * WTM + i * 32 + (lane & 31); fa[ks][i] = (r * 4 + (sl ^ ((r >> 2) & 3))) * 8; }
-#pragma unroll
-            for (int j = 0; j < TN; j++) { const int r = wn * WTN + j * 32 + (lane & 31); fb[ks][j] = (r * 4 + (sl ^ ((r >> 2) & 3))) * 8; }
-        }
-        constexpr int LPS = NPA + NPB;
-        issue(0);
-        if (nk > 1) issue(1);
-        int st = 0;                                                    // ring slot of stage k
-        for (int k = 0; k < nk; k++) {
-            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");     // stage k landed, stage k+1 may fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // visible to all waves; slot (k-1)%3 fully consumed
-            if (k + 2 < nk) issue(st == 0 ? 2 : st - 1);               // (k+2)%3 == (k-1)%3
-            const bf16_t* sa = ldsA + st * A_ST;
-            const bf16_t* sb = ldsB + st * B_ST;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                bf16x8 af[TM], bfr[TN];
-#pragma unroll
-                for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const bf16x8*>(sa + fa[ks][i]);
-#pragma unroll
-                for (int j = 0; j < TN; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + fb[ks][j]);
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-            st = st == 2 ? 0 : st + 1;
         }
         __syncthreads();
-#endif
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // The MFMAs ran with A = weights, B = pixels, so acc[i][j] is the TRANSPOSED 32x32 tile: column = lane & 31 = pixel
+    // i*32 + (lane & 31), row = channel j*32 + (e & 3) + 8*(e >> 2) + 4*(lane >> 5).  A lane therefore owns 4 consecutive
+    // channels of ONE pixel per register quad: one 8-byte LDS store (or one 16-byte fp32 store) instead of four 2-byte ones.
     const bool identity = (p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && tc.oh_add == 0 && tc.ow_add == 0);
-    float csum[TN], csq[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++) { csum[j] = 0.f; csq[j] = 0.f; }
+    const int h = lane >> 5;
+    auto out_pixel = [&](int64_t m) -> int64_t {
+        if (identity) return m;
+        const int img = (int)(m / ((int64_t)p.OH * p.OW));
+        const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        return ((int64_t)img * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
+    };
 
     if (p.epi == EPI_F32_BIAS) {
-        // small outputs (detection heads): direct per-element fp32 stores
+        // small outputs (detection heads): direct fp32 stores, 4 consecutive channels per lane
 #pragma unroll
         for (int i = 0; i < TM; i++) {
+            const int64_t m = m0 + wm * WTM + i * 32 + (lane & 31);
+            if (m >= M) continue;
+            float* orow = reinterpret_cast<float*>(p.out) + out_pixel(m) * p.ldC;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int64_t m = m0 + row;
-                if (m >= M) continue;
-                int64_t pix = m;
-                if (!identity) {
-                    const int img = (int)(m / ((int64_t)p.OH * p.OW));
-                    const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
-                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    pix = ((int64_t)img * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
-                }
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-                    if (n >= p.Nout) continue;
-                    float v = acc[i][j][e];
-                    if (p.bias) v += p.bias[n];
-                    reinterpret_cast<float*>(p.out)[pix * p.ldC + n] = v;
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int n = n0 + wn * WTN + j * 32 + 8 * g4 + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (n + q >= p.Nout) continue;
+                        float v = acc[i][j][4 * g4 + q];
+                        if (p.bias) v += p.bias[n + q];
+                        orow[n + q] = v;
+                    }
                 }
-            }
         }
     } else {
-        // bf16 outputs: stage the wave's WTM x WTN block in LDS, then write whole 16-byte row segments (8 channels per lane)
+        // bf16 outputs: stage the wave's WTM x WTN block in LDS (8-byte packed stores), then write whole 16-byte row segments
         __syncthreads();                                       // every wave is done reading the operand tiles
         bf16_t* stage = smem + wave * WTM * EP_LD;
-        // eval-mode fusion (EPI_AFFINE_ACT): folded BatchNorm (running statistics) + activation applied to the fp32 accumulator,
-        // so inference writes the activation once instead of y -> (read) -> z
-        float esc[TN], esh[TN];
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-            const bool fuse = p.epi == EPI_AFFINE_ACT && n < p.Nout;
-            esc[j] = fuse ? p.scale[n] : 1.f;
-            esh[j] = fuse ? p.shift[n] : 0.f;
-        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    float av = acc[i][j][e];
-                    if (p.epi == EPI_AFFINE_ACT) av = act_fwd(av * esc[j] + esh[j], p.act);
-                    const bf16_t b = f2bf(av);
-                    stage[r * EP_LD + j * 32 + (lane & 31)] = b;
-                    if (p.epi == EPI_STATS) {
-                        const bool live = (m0 + wm * WTM + r) < M;          // rows past M are zero anyway (zero-filled A rows)
-                        const float rv = live ? bf2f(b) : 0.f;              // statistics of the values actually stored
-                        csum[j] += rv;
-                        csq[j] += rv * rv;
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int c0 = j * 32 + 8 * g4 + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = acc[i][j][4 * g4 + q];
+                    if (p.epi == EPI_AFFINE_ACT) {
+                        // inference: folded BatchNorm (running statistics) + activation on the fp32 accumulator
+                        const int n = n0 + wn * WTN + c0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (n + q < p.Nout) v[q] = act_fwd(v[q] * p.scale[n + q] + p.shift[n + q], p.act);
                     }
+                    *reinterpret_cast<uint2*>(stage + (i * 32 + (lane & 31)) * EP_LD + c0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
         // (same-wave LDS hand-off: no workgroup barrier needed, only the wave's own ds_write -> ds_read ordering)
         constexpr int CH = WTN / 8;                            // 16-byte chunks per row
@@ -482,13 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             const int r = it * RPI + r0;
             const int64_t m = m0 + wm * WTM + r;
             if (m >= M || n >= p.Nout) continue;
-            int64_t pix = m;
-            if (!identity) {
-                const int img = (int)(m / ((int64_t)p.OH * p.OW));
-                const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                pix = ((int64_t)img * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
-            }
+            const int64_t pix = out_pixel(m);
             uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
             bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
             if (p.epi == EPI_ACCUM) {
@@ -504,29 +374,47 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             }
             *reinterpret_cast<uint4*>(o) = v;
         }
-    }
-    if (p.epi == EPI_STATS) {
-        // column sums: combine the two half-waves, then the WM waves that share a column block (through LDS)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);          // [WM][2][BN]
+        if (p.epi == EPI_STATS) {
+            // BatchNorm batch statistics of the values actually stored (bf16-rounded), read back from the staged block:
+            // lane -> (4-channel quad, row group); rows past M were zero-filled A rows and contribute exact zeros
+            constexpr int NQ = WTN / 4, RG = 64 / NQ;
+            const int cq = lane % NQ, rg = lane / NQ;
+            float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
-            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
-            if (lane < 32) {
-                const int col = wn * (BN / WN) + j * 32 + lane;
-                red[(wm * 2 + 0) * BN + col] = s;
-                red[(wm * 2 + 1) * BN + col] = q;
+            for (int k = 0; k < WTM / RG; k++) {
+                const uint2 w = *reinterpret_cast<const uint2*>(stage + (rg + RG * k) * EP_LD + cq * 4);
+                const float f0 = __uint_as_float(w.x << 16), f1 = __uint_as_float(w.x & 0xffff0000u);
+                const float f2 = __uint_as_float(w.y << 16), f3 = __uint_as_float(w.y & 0xffff0000u);
+                ssum[0] += f0; ssq[0] += f0 * f0;
+                ssum[1] += f1; ssq[1] += f1 * f1;
+                ssum[2] += f2; ssq[2] += f2 * f2;
+                ssum[3] += f3; ssq[3] += f3 * f3;
             }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.Nout) {
-            float s = 0.f, q = 0.f;
+            __syncthreads();                                   // staging blocks dead: LDS becomes the cross-wave reduction buffer
+            float* red = reinterpret_cast<float*>(smem);          // [WM][2][BN]
 #pragma unroll
-            for (int w = 0; w < WM; w++) { s += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
-            float* st = p.stats + (int64_t)mb * 2 * p.Nout;
-            st[n0 + tid] = s;
-            st[p.Nout + n0 + tid] = q;
+            for (int q = 0; q < 4; q++) {
+                float sm = ssum[q], sq = ssq[q];
+#pragma unroll
+                for (int o = NQ; o < 64; o <<= 1) {
+                    sm += __shfl_xor(sm, o, 64);
+                    sq += __shfl_xor(sq, o, 64);
+                }
+                if (lane < NQ) {
+                    const int col = wn * WTN + cq * 4 + q;
+                    red[(wm * 2 + 0) * BN + col] = sm;
+                    red[(wm * 2 + 1) * BN + col] = sq;
+                }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Nout) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; w++) { sm += red[(w * 2 + 0) * BN + tid]; sq += red[(w * 2 + 1) * BN + tid]; }
+                float* st = p.stats + (int64_t)mb * 2 * p.Nout;
+                st[n0 + tid] = sm;
+                st[p.Nout + n0 + tid] = sq;
+            }
         }
     }
 }
@@ -780,28 +668,51 @@ extern "C" int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* ro
 {
     // number of [2][Nout] partial-statistics rows the EPI_STATS epilogue writes (== gridM of the chosen tile)
     if (!rows) return RY_ERR_ARG;
-    *rows = (int)ry_cdiv(M, (pipe == 2 || Nout <= 32) ? 256 : 128);
+    (void)pipe;
+    *rows = (int)ry_cdiv(M, Nout <= 32 ? 256 : 128);
     return RY_OK;
+}
+
+static int gemm_check(const ConvGemmParams& p)
+{
+    if (!p.A || !p.W || !p.out || p.Cin <= 0 || p.Cin % BK || p.ldA % 8 || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4)
+        return RY_ERR_ARG;
+    return RY_OK;
+}
+
+// Which kernel ryolo_conv_gemm will run for these parameters and how many [2][Nout] partial-statistics rows its EPI_STATS
+// epilogue writes (= number of M tiles).  kernel: 0 generic implicit GEMM (conv.hip), 1 3x3 halo-patch kernel (conv3x3.hip,
+// selected by pipe bit 0x200 when the layer is eligible).
+extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, int* kernel)
+{
+    if (!pp || !stats_rows) return RY_ERR_ARG;
+    const ConvGemmParams& p = *pp;
+    if (p.Cin <= 0 || p.Cin % BK || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4) return RY_ERR_ARG;
+    P3Geom g;
+    if ((p.pipe & 0x200) && p3_geometry(p, g)) {
+        *stats_rows = (int)g.gm;
+        if (kernel) *kernel = 1;
+        return RY_OK;
+    }
+    if (kernel) *kernel = 0;
+    return ryolo_conv_gemm_stats_rows((int64_t)p.NB * p.OH * p.OW, p.Nout, p.pipe & 0xff, stats_rows);
 }
 
 extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
 {
     if (!pp) return RY_ERR_ARG;
     const ConvGemmParams& p = *pp;
-    if (!p.A || !p.W || !p.out || p.Cin <= 0 || p.Cin % BK || p.ldA % 8 || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4)
-        return RY_ERR_ARG;
+    if (gemm_check(p)) return RY_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) return RY_ERR_ARG;
     for (int c = 0; c < p.nclasses; c++)
         if (p.cls[c].ntaps < 1 || p.cls[c].ntaps > RY_MAX_TAPS) return RY_ERR_ARG;
     if (p.epi == EPI_STATS && (!p.stats || p.nclasses != 1)) return RY_ERR_ARG;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
-    if ((p.pipe & 0xff) == 2) {
-        if (p.a_bytes == 0 || p.w_bytes == 0) return RY_ERR_ARG;
-        if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 2>(p, stream);
-        if (p.Nout <= 64) return launch_gemm<256, 64, 4, 1, 2>(p, stream);
-        return launch_gemm<256, 128, 2, 2, 2>(p, stream);
+    if (p.pipe & 0x200) {
+        P3Geom g;
+        if (p3_geometry(p, g)) return p3_launch(p, g, stream);
     }
-    if (p.pipe) {
+    if (p.pipe & 0xff) {
         if (!p.zeros) return RY_ERR_ARG;
         // 64-channel (full 128-byte line) stages: measured +1..5 % on 3x3 layers up to 256 channels, -4..-10 % on 1x1 / 512-channel
         // layers (tools/bench_conv.py matrix in DESIGN.md); 0x100 forces 32-channel stages for A/B runs

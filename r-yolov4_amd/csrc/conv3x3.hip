@@ -1,0 +1,455 @@
+// 3x3 stride-1 convolution (forward and data gradient) as an implicit GEMM over a HALO PATCH held in LDS — gfx950 only.
+// Reference rows served: SURVEY.md §8a M1/M2 (`Conv`, model/utils.py:6-32, every 3x3 s1 conv of the ELAN / CSP / SPPCSPC
+// blocks: 54 % of the conv FLOPs of yolov7 @800^2) and their data gradients.
+//
+// Why a second kernel: the generic conv_gemm loop (conv.hip) gathers a fresh (pixels x 32 channels) A tile for each of the
+// 9 taps, so the same input bytes cross L2 -> TA -> LDS nine times and the loop is bound by the number of LDS-DMA
+// instructions per MFMA (PMC + ablations in DESIGN.md §4.1).  Here a workgroup owns 256 output pixels and 64 / 128 output
+// channels; per 32-channel chunk it brings the input pixels those outputs touch ONCE (the tile plus its halo: 324 ... 450
+// rows instead of 9 x 256) and all 9 taps read shifted rows of that patch:
+//   * tile = TH x TW output pixels of one image (2-D mode, patch (TH+2) x (TW+2)) or a flat run of 256 consecutive
+//     output pixels (run mode, patch = run + one image row + 1 on both sides; zero tile waste on small maps);
+//   * A-fragment row of output pixel m for tap (dh, dw) = patch row base(m) + (dh+1)*PW + (dw+1): one scalar add per tap;
+//     padding (and, in run mode, wrap-around into the neighbouring row / image) is a per-lane 9-bit mask that redirects
+//     the read to a 64-byte zero row — no zero-filled copies, no per-tap DMA;
+//   * the patch of chunk c+1 streams in one 1-KiB piece per wave per tap step while chunk c is consumed (double buffer);
+//     weights use a 3-slot ring, one (tap, chunk) tile of BN x 32 per step; counted `s_waitcnt vmcnt(N)` + ONE s_barrier
+//     per step, nothing is drained to zero inside the loop;
+//   * 4 waves, 128 x 64 per wave for BN = 128 (16 MFMA per 12 ds_read_b128 per step and per-lane DMA cost / MFMA 0.18 vs
+//     0.5 in the generic loop), 64 x 64 for BN = 64; two workgroups per CU (<= 80 KiB LDS each);
+//   * LDS images are lane-linear DMA targets; the bank swizzle (slot ^= (row >> 2) & 3, conflict-free ds_read_b128) is keyed
+//     on the PATCH row and applied on the source address, the reader recomputes it per tap (3 VALU);
+//   * epilogues as in conv.hip: raw bf16, training BatchNorm statistics, folded BN + activation (inference), accumulate.
+#include "conv_internal.h"
+
+#define P3_BM 256
+
+extern __shared__ __attribute__((aligned(1024))) unsigned char p3_lds[];
+
+// exact n / d for 0 <= n < 2^16, 1 <= d < 2^16 with a precomputed float reciprocal (prologue index math; hipcc's generic
+// 32-bit division is ~40 instructions)
+__device__ __forceinline__ int small_div(int n, int d, float rd)
+{
+    int q = (int)((float)n * rd);
+    if (q * d > n) q--;
+    if ((q + 1) * d <= n) q++;
+    return q;
+}
+
+template <int K> __device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+}
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmParams p, const P3Geom g)
+{
+    constexpr int BM = P3_BM, TM = BM / WM / 32, TN = BN / WN / 32, WTM = BM / WM, WTN = BN / WN;
+    constexpr int NPB = BN / 64;                               // weight pieces (16 rows x 64 B) per wave per step
+    constexpr int WSLOT = BN * 64;                             // bytes of one weight ring slot
+    static_assert(WM * WN == 4 && TM % 2 == 0 && (BN == 64 || BN == 128), "tile config");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5;
+    const int H = p.OH, W = p.OW;
+    const int64_t HW = (int64_t)H * W, M = (int64_t)p.NB * HW;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mb = tile / g.gn, nb = tile - mb * g.gn;
+    const int n0 = nb * BN;
+
+    const unsigned patch_bytes = (unsigned)g.P * 1024u;
+    const unsigned wring_off = 2u * patch_bytes;
+    const unsigned zrow_off = wring_off + 3u * WSLOT;
+    int* const tab = reinterpret_cast<int*>(p3_lds + zrow_off + 64);
+
+    // ---- tile origin --------------------------------------------------------------------------------------------------
+    int img0 = 0, oh0 = 0, ow0 = 0;
+    int64_t p0 = 0;
+    if (g.mode == 1) {
+        img0 = mb / g.tilesPerImg;
+        const int rem = mb - img0 * g.tilesPerImg;
+        const int th = rem / g.tilesW;
+        oh0 = th * g.TH;
+        ow0 = (rem - th * g.tilesW) * g.TW;
+    } else {
+        p0 = (int64_t)mb * BM;
+    }
+
+    // ---- patch DMA sources -> LDS table ptab[u][tid]: piece (wave + 4u) = patch rows 16*piece ... +15, lane -> (row, slot) ---------
+    // (element offset / 8 into A; ~0u -> zero page).  Kept in LDS, not in 9 VGPRs: the main loop stays rolled and lean.
+    unsigned* const ptab = reinterpret_cast<unsigned*>(p3_lds + zrow_off + 128);
+    for (int u = 0; u < g.TP; u++) {
+        const int pc = min(wave + 4 * u, g.P - 1);
+        const int j = pc * 16 + (lane >> 2);
+        bool ok = j < g.R;
+        int64_t pix;
+        if (g.mode == 1) {
+            const int pr = small_div(j, g.PW, g.rPW), pcx = j - pr * g.PW;
+            const int ih = oh0 - 1 + pr, iw = ow0 - 1 + pcx;
+            ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            pix = ((int64_t)img0 * H + ih) * W + iw;
+        } else {
+            pix = p0 - W - 1 + j;
+            ok = ok && pix >= 0 && pix < M;
+        }
+        const int sl = (lane & 3) ^ ((j >> 2) & 3);
+        ptab[u * 256 + tid] = ok ? (unsigned)((pix * p.ldA + sl * 8) >> 3) : 0xffffffffu;
+    }
+    // ---- weight DMA sources --------------------------------------------------------------------------------------------
+    unsigned b_ofs[NPB];                                        // element offset into W (< 2^31: checked on the host), ~0u -> zero page
+#pragma unroll
+    for (int u = 0; u < NPB; u++) {
+        const int r = (wave + 4 * u) * 16 + (lane >> 2);
+        b_ofs[u] = (n0 + r) < p.Nout ? (unsigned)((int64_t)(n0 + r) * p.wtaps * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8) : 0xffffffffu;
+    }
+    // ---- per-tap scalars through LDS (a VMEM kernarg byte load inside the loop would drain vmcnt) + the zero row ----------
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+        if (tid == t) tab[t] = ((g.tdh[t] + 1) * g.PW + (g.tdw[t] + 1)) | (g.twi[t] << 16);
+    if (tid >= 64 && tid < 80) reinterpret_cast<unsigned*>(p3_lds + zrow_off)[tid - 64] = 0u;
+    // ---- A fragment rows: patch row of output pixel m (tap (−1,−1)) and the 9-bit validity mask -----------------------------
+    int run_oh = 0, run_ow = 0;
+    const float rH = 1.0f / (float)H;
+    if (g.mode != 1) {
+        const int rem = (int)(p0 % HW);                           // wave-uniform: scalar division
+        run_oh = rem / W;
+        run_ow = rem - run_oh * W;
+    }
+    int abase[TM];
+    unsigned amask[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mrow = wm * WTM + i * 32 + (lane & 31);
+        bool live;
+        int oh, ow;
+        if (g.mode == 1) {
+            const int r = small_div(mrow, g.TW, g.rTW), c = mrow - r * g.TW;
+            live = mrow < g.TH * g.TW;
+            oh = oh0 + r;
+            ow = ow0 + c;
+            abase[i] = live ? r * g.PW + c : 0;
+        } else {
+            const int64_t pp = p0 + mrow;
+            live = pp < M;
+            // (oh, ow) of a flat pixel index: the run starts at (roh, row_) — computed once per workgroup with scalar math below
+            int o = run_ow + mrow, orow = run_oh;
+            const int wraps = small_div(o, W, g.rPW);               // PW == W for flat runs
+            o -= wraps * W;
+            orow += wraps;
+            orow -= small_div(orow, H, rH) * H;                      // next image(s): row index modulo H
+            oh = orow;
+            ow = o;
+            abase[i] = mrow;
+        }
+        // tap t reads input (oh + dh, ow + dw): 3 row bits x 3 column bits, combined per tap from scalar (dh, dw)
+        const unsigned rowok = ((oh >= 1) ? 1u : 0u) | 2u | ((oh + 1 < H) ? 4u : 0u);
+        const unsigned colok = ((ow >= 1) ? 1u : 0u) | 2u | ((ow + 1 < W) ? 4u : 0u);
+        unsigned vm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+            vm |= ((rowok >> (g.tdh[t] + 1)) & (colok >> (g.tdw[t] + 1)) & 1u) << t;
+        if (!live) vm = 0;
+        amask[i] = vm;
+    }
+    unsigned fb[TN];                                            // B fragment byte offset inside a ring slot for ks = 0 (ks = 1: ^ 32)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int r = wn * WTN + j * 32 + (lane & 31);
+        fb[j] = (unsigned)(r * 64 + ((h ^ ((r >> 2) & 3)) << 4));
+    }
+    __syncthreads();
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const int cchunks = p.Cin >> 5;
+    const int nsteps = cchunks * 9;
+    auto issue_patch = [&](int u, int cc, unsigned buf_off) {
+        const unsigned ofs = ptab[u * 256 + tid];
+        const int pc = min(wave + 4 * u, g.P - 1);
+        const bf16_t* src = ofs != 0xffffffffu ? p.A + ((int64_t)ofs << 3) + cc * 32 : p.zeros;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + buf_off + pc * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](int t, int cc, int slot) {
+        const int wi = __builtin_amdgcn_readfirstlane(tab[t]) >> 16;
+        const int off = wi * p.Cin + cc * 32;
+#pragma unroll
+        for (int u = 0; u < NPB; u++) {
+            const bf16_t* src = b_ofs[u] != 0xffffffffu ? p.W + b_ofs[u] + off : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + wring_off + slot * WSLOT + (wave + 4 * u) * 1024), 16, 0, 0);
+        }
+    };
+    // prologue: the whole patch of chunk 0, weights of steps 0 and 1
+    for (int u = 0; u < g.TP; u++) issue_patch(u, 0, 0u);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+
+    int s = 0;
+    for (int cc = 0; cc < cchunks; cc++) {
+        const bool more = cc + 1 < cchunks;
+        const unsigned pbuf = (cc & 1) ? patch_bytes : 0u;
+        const unsigned nbuf = (cc & 1) ? 0u : patch_bytes;
+        int slot = 0;                                          // ring slot of step (cc, t) = t % 3 (9 taps per chunk)
+        for (int t = 0; t < 9; t++, s++) {
+            // DMA instructions this wave issued AFTER the ones step s depends on may stay in flight:
+            //   step s-1 issued [its patch piece (if any)] + [weights of step s+1]; a new chunk (t == 0) needs every patch piece
+            const bool prev_piece = t != 0 && (t - 1) < g.TP && more;
+            if (s + 1 >= nsteps) wait_vm<0>();
+            else if (prev_piece) wait_vm<NPB + 1>();
+            else wait_vm<NPB>();
+            __builtin_amdgcn_s_barrier();               // step s operands visible to every wave; step s-1 fully consumed
+            const bool do_patch = more && t < g.TP;
+            const bool do_w = s + 2 < nsteps;
+            const int t2 = t + 2 >= 9 ? t - 7 : t + 2;
+            const int w_off = (__builtin_amdgcn_readfirstlane(tab[t2]) >> 16) * p.Cin + (cc + (t + 2 >= 9 ? 1 : 0)) * 32;
+            const unsigned w_dst = wring_off + (slot == 0 ? 2 : slot - 1) * WSLOT;       // slot of step s + 2
+            const int toff = __builtin_amdgcn_readfirstlane(tab[t]) & 0xffff;
+            unsigned aaddr[TM];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const unsigned prow = (unsigned)(abase[i] + toff);
+                const unsigned a = pbuf + (prow << 6) + ((((prow >> 2) & 3u) ^ (unsigned)h) << 4);
+                aaddr[i] = (amask[i] >> t) & 1u ? a : zrow_off;
+            }
+            const unsigned wb = wring_off + slot * WSLOT;
+            // all 2*(TM+TN) fragment reads of the step are issued back to back into distinct registers BEFORE the first MFMA
+            // (left alone, hipcc funnels every A fragment through one register quad: read -> lgkmcnt(0) -> 2 MFMA, eight exposed
+            // LDS round trips per step — seen in the ISA, 3x the step time)
+            bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(p3_lds + wb + (fb[j] ^ (unsigned)(ks << 5)));
+#pragma unroll
+                for (int i = 0; i < TM; i++) af[ks][i] = *reinterpret_cast<const bf16x8*>(p3_lds + (aaddr[i] ^ (unsigned)(ks << 5)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // MFMAs with the step's DMA instructions (1 patch piece + NPB weight pieces per wave) spread between them: an LDS-DMA
+            // issue costs 100-185 cycles next to ds_reads but hides in the shadow of the matrix pipe (guide's price table).
+            // Operands are swapped (A = weights, B = pixels): the accumulator holds the TRANSPOSED tile, so a lane owns 4
+            // consecutive channels of one pixel — 8-byte packed stores in the epilogue.
+            constexpr int NMF = 2 * TM * TN, NIT = NPB + 1, GAP = NMF / (NIT + 1);
+#pragma unroll
+            for (int q = 0; q < NMF; q++) {
+                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                if ((q + 1) % GAP == 0 && (q + 1) / GAP <= NIT) {
+                    const int item = (q + 1) / GAP - 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (item == 0) {
+                        if (do_patch) issue_patch(t, cc + 1, nbuf);
+                    } else if (do_w) {
+                        const int u = item - 1;
+                        const bf16_t* src = b_ofs[u] != 0xffffffffu ? p.W + b_ofs[u] + w_off : p.zeros;
+                        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + w_dst + (wave + 4 * u) * 1024), 16, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    __syncthreads();                                           // operand tiles dead: LDS is reused for the output staging
+
+    // ---- epilogue.  acc[i][j] is the transposed 32x32 tile: column = lane & 31 = pixel i*32 + (lane & 31), row = channel
+    // j*32 + (e & 3) + 8*(e >> 2) + 4*(lane >> 5): 4 consecutive channels per lane per register quad -> one 8-byte LDS store
+    // each (32 per wave instead of the 128 two-byte stores of the untransposed layout), then 16-byte row segments to HBM.
+    constexpr int EP_LD = WTN + 8;                             // staging row stride (bf16): 16-byte aligned, breaks bank aliasing
+    bf16_t* const stage = reinterpret_cast<bf16_t*>(p3_lds) + wave * 64 * EP_LD;      // 64 pixel rows per pass
+    constexpr int CH = WTN / 8;                                // 16-byte chunks per staged row
+    constexpr int RPI = 64 / CH;                               // rows per store iteration
+    const int ch = lane % CH, r0 = lane / CH;
+    const int ncol = n0 + wn * WTN + ch * 8;
+    const int cq = lane & 15, rg = lane >> 4;                  // statistics: 4 channels x every 4th row per lane
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int half = 0; half < TM / 2; half++) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int i = half * 2 + ii;
+                    const int c0 = j * 32 + 8 * g4 + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = acc[i][j][4 * g4 + q];
+                    if (p.epi == EPI_AFFINE_ACT) {
+                        const int n = n0 + wn * WTN + c0;
+                        if (n < p.Nout) {
+                            const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+                            const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
+                            v[0] = act_fwd(v[0] * sc.x + sh.x, p.act);
+                            v[1] = act_fwd(v[1] * sc.y + sh.y, p.act);
+                            v[2] = act_fwd(v[2] * sc.z + sh.z, p.act);
+                            v[3] = act_fwd(v[3] * sc.w + sh.w, p.act);
+                        }
+                    }
+                    const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(stage + (ii * 32 + (lane & 31)) * EP_LD + c0) = w;
+                }
+        // (same-wave LDS hand-off: the wave's own ds_write -> ds_read ordering is enough, no workgroup barrier)
+        if (p.epi == EPI_STATS) {
+            // BatchNorm batch statistics of the values actually stored (bf16-rounded); dead rows hold exact zeros
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint2 w = *reinterpret_cast<const uint2*>(stage + (rg + 4 * k) * EP_LD + cq * 4);
+                const float f0 = __uint_as_float(w.x << 16), f1 = __uint_as_float(w.x & 0xffff0000u);
+                const float f2 = __uint_as_float(w.y << 16), f3 = __uint_as_float(w.y & 0xffff0000u);
+                ssum[0] += f0; ssq[0] += f0 * f0;
+                ssum[1] += f1; ssq[1] += f1 * f1;
+                ssum[2] += f2; ssq[2] += f2 * f2;
+                ssum[3] += f3; ssq[3] += f3 * f3;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; it++) {
+            const int r = it * RPI + r0;
+            const int mrow = wm * WTM + half * 64 + r;
+            int64_t pix;
+            bool live;
+            if (g.mode == 1) {
+                const int rr = small_div(mrow, g.TW, g.rTW), c = mrow - rr * g.TW;
+                live = mrow < g.TH * g.TW;
+                pix = ((int64_t)img0 * H + oh0 + rr) * W + ow0 + c;
+            } else {
+                pix = p0 + mrow;
+                live = pix < M;
+            }
+            if (!live || ncol >= p.Nout) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
+            bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + ncol;
+            if (p.epi == EPI_ACCUM) {
+                const uint4 old = *reinterpret_cast<const uint4*>(o);
+                const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                const unsigned* b = reinterpret_cast<const unsigned*>(&old);
+                unsigned w[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
+                                    __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(o) = v;
+        }
+    }
+    if (p.epi == EPI_STATS) {
+        // fold the 4 row groups of the wave, then the WM waves that share a column block (through LDS)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(p3_lds);          // [WM][2][BN]
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float sm = ssum[q], sq = ssq[q];
+            sm += __shfl_xor(sm, 16, 64);
+            sq += __shfl_xor(sq, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (lane < 16) {
+                const int col = wn * WTN + cq * 4 + q;
+                red[(wm * 2 + 0) * BN + col] = sm;
+                red[(wm * 2 + 1) * BN + col] = sq;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Nout) {
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; w++) { sm += red[(w * 2 + 0) * BN + tid]; sq += red[(w * 2 + 1) * BN + tid]; }
+            float* st = p.stats + (int64_t)mb * 2 * p.Nout;
+            st[n0 + tid] = sm;
+            st[p.Nout + n0 + tid] = sq;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- host side
+static unsigned p3_lds_bytes(int P, int BN) { return 2u * P * 1024u + 3u * BN * 64u + 128u + (unsigned)ry_cdiv(P, 4) * 1024u; }
+
+bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
+{
+    g = P3Geom{};
+    const TapClass& tc = p.cls[0];
+    if (p.nclasses != 1 || tc.ntaps != 9 || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
+    if (p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || tc.oh_add || tc.ow_add) return false;
+    if (p.Cin % 32 || p.Nout < 64 || p.Nout % 8 || p.ldA % 8 || p.ldC % 8 || !p.zeros) return false;
+    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT && p.epi != EPI_ACCUM) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; t++) {
+        if (tc.dh[t] < -1 || tc.dh[t] > 1 || tc.dw[t] < -1 || tc.dw[t] > 1 || tc.widx[t] < 0 || tc.widx[t] >= p.wtaps) return false;
+        seen |= 1u << ((tc.dh[t] + 1) * 3 + tc.dw[t] + 1);
+    }
+    if (seen != 0x1ffu) return false;
+    const int H = p.OH, W = p.OW;
+    const int64_t M = (int64_t)p.NB * H * W;
+    if (M * (int64_t)p.ldA >= (1ll << 34) || (int64_t)p.Nout * p.wtaps * p.Cin >= (1ll << 31)) return false;   // 32-bit DMA source offsets
+    g.BN = p.Nout <= 64 ? 64 : 128;
+    g.gn = (int)ry_cdiv(p.Nout, g.BN);
+    const unsigned budget = 80u * 1024u;                          // two workgroups per CU
+    // flat runs: no tile waste; the patch carries one image row of halo on both sides
+    const int Rrun = P3_BM + 2 * W + 2;
+    const int Prun = (int)ry_cdiv(Rrun, 16);
+    int best_th = 0, best_tw = 0;
+    for (int tw = 1; tw <= W && tw <= P3_BM; tw++) {
+        if (W % tw) continue;
+        for (int th = 1; th <= H && th * tw <= P3_BM; th++) {
+            if (H % th) continue;
+            const int area = th * tw, barea = best_th * best_tw;
+            if (area > barea || (area == barea && (th + 2) * (tw + 2) < (best_th + 2) * (best_tw + 2))) { best_th = th; best_tw = tw; }
+        }
+    }
+    const int R2 = (best_th + 2) * (best_tw + 2);
+    const int P2 = (int)ry_cdiv(R2, 16);
+    const bool ok2 = best_th * best_tw >= 224 && P2 <= 36 && p3_lds_bytes(P2, g.BN) <= budget;
+    const bool okr = Prun <= 36 && p3_lds_bytes(Prun, g.BN) <= budget;
+    if (!ok2 && !okr) return false;
+    // cost per useful output pixel ~ (patch rows / 9 + weight rows) / live pixels; flat runs have no dead rows
+    const double c2 = ok2 ? (R2 / 9.0 + g.BN) / (best_th * best_tw) : 1e30;
+    const double cr = okr ? (Rrun / 9.0 + g.BN) / (double)P3_BM : 1e30;
+    if (c2 < cr) {
+        g.mode = 1;
+        g.TH = best_th; g.TW = best_tw; g.PW = best_tw + 2; g.R = R2; g.P = P2;
+        g.tilesW = W / best_tw;
+        g.tilesPerImg = (H / best_th) * g.tilesW;
+        g.gm = (int64_t)p.NB * g.tilesPerImg;
+    } else {
+        g.mode = 2;
+        g.PW = W; g.R = Rrun; g.P = Prun;
+        g.gm = ry_cdiv(M, P3_BM);
+    }
+    g.TP = (int)ry_cdiv(g.P, 4);
+    for (int t = 0; t < 9; t++) { g.tdh[t] = tc.dh[t]; g.tdw[t] = tc.dw[t]; g.twi[t] = tc.widx[t]; }
+    g.rPW = 1.0f / (float)g.PW;
+    g.rTW = g.TW ? 1.0f / (float)g.TW : 0.f;
+    g.lds_bytes = p3_lds_bytes(g.P, g.BN);
+    if (g.gm * g.gn > 0x7fffffff || g.gm <= 0) { g.mode = 0; return false; }
+    // 256-pixel tiles need a grid that fills the chip (2 workgroups x 256 CUs); smaller problems stay on the generic kernel's
+    // 128-pixel tiles (measured: 8 x 100^2 x 128 -> 128 is 0.7x on this kernel, 64 x ... is 1.25-1.3x).  0x400 forces it (tests).
+    if (g.gm * g.gn < 512 && !(p.pipe & 0x400)) { g.mode = 0; return false; }
+    return true;
+}
+
+template <int BN, int WM, int WN> static int p3_launch_t(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return RY_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes, stream, p, g);
+    return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
+}
+
+int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
+{
+    if (g.BN == 64) return p3_launch_t<64, 4, 1>(p, g, stream);
+    return p3_launch_t<128, 2, 2>(p, g, stream);
+}

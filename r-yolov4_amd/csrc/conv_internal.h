@@ -1,0 +1,50 @@
+// Pieces shared by the convolution translation units (conv.hip, conv3x3.hip): epilogue / activation codes, MFMA vector
+// types, the XCD-aware tile order.  Internal to libryolo_hip.so.
+#pragma once
+#include "common.h"
+#include "params.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+enum { EPI_RAW = 0, EPI_STATS = 1, EPI_AFFINE_ACT = 2, EPI_F32_BIAS = 3, EPI_ACCUM = 4 };
+enum { ACT_LINEAR = 0, ACT_MISH = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
+
+__device__ __forceinline__ float act_fwd(float u, int act)
+{
+    if (act == ACT_SILU) return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));
+    if (act == ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
+    if (act == ACT_MISH) {
+        if (u > 20.f) return u;
+        const float n = __expf(u), w = n * (n + 2.f);       // tanh(softplus(u)) = (n^2 + 2n) / (n^2 + 2n + 2)
+        return u * w * __builtin_amdgcn_rcpf(w + 2.f);
+    }
+    return u;
+}
+
+// bijective XCD remap (cdna guide T1): workgroup b runs on XCD b%8; give each XCD a contiguous tile range
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// ---- 3x3 stride-1 halo-patch kernel (conv3x3.hip) -------------------------------------------------------------------
+// geometry chosen on the host; `mode` 0 = not eligible, 1 = 2-D tiles (TH x TW output pixels of one image),
+// 2 = flat runs of 256 consecutive output pixels
+struct P3Geom {
+    int mode, BN;
+    int TH, TW, PW;            // tile rows / cols (2-D), patch row pitch in pixels (TW + 2, or the image width for flat runs)
+    int R, P, TP;              // patch rows, 16-row DMA pieces, tap steps that carry one piece per wave (= ceil(P / 4))
+    int tilesW, tilesPerImg;   // 2-D tiling of one image
+    int gn;
+    int64_t gm;
+    unsigned lds_bytes;
+    int tdh[9], tdw[9], twi[9];   // taps as scalars (kernarg dwords: read with s_load, unlike the byte arrays of TapClass)
+    float rPW, rTW;            // reciprocals for the prologue's small exact divisions
+};
+bool p3_geometry(const ConvGemmParams& p, P3Geom& g);
+int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream);

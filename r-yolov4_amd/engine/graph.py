@@ -131,6 +131,10 @@ class Graph:
             fl = 0
             for c in range(p.nclasses):
                 fl += 2 * p.NB * p.OH * p.OW * p.Nout * p.cls[c].ntaps * p.Cin
+            kern = S.I()
+            hip.call("ryolo_conv_gemm_plan", p, S.I(), kern)
+            if kern.value == 1:
+                return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl)
             tile = "256x32" if p.Nout <= 32 else ("128x64" if p.Nout <= 64 else "128x128")
             return (f"conv_gemm_kernel<{tile}>", fl)
         if name == "ryolo_conv_wgrad":
@@ -161,8 +165,10 @@ class Graph:
                 raise RuntimeError(f"{name} failed with code {rc}")
 
     # ------------------------------------------------------------------ convolution
-    def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None, stats=None,
+    def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,
               coeffs=None, act=0, bias=None):
+        """Emit one ryolo_conv_gemm launch.  For epi == EPI_STATS the partial-statistics buffer is sized by the library's plan
+        (one [2][Nout] row per M tile of the kernel it will run) and returned."""
         p = S.ConvGemmParams()
         p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = Aptr, A.N, A.H, A.W, gemm_cin, A.ld
         p.W, p.Nout, p.wtaps = W.data_ptr(), Nout, wtaps
@@ -175,7 +181,6 @@ class Graph:
         for i, (taps, oa, wa) in enumerate(classes):
             _fill_class(p.cls[i], taps, oa, wa)
         p.epi, p.out, p.ldC = epi, out_ptr, ldC
-        p.stats = stats.data_ptr() if stats is not None else None
         if coeffs is not None:
             Cn = coeffs.shape[1]
             p.scale, p.shift = coeffs.data_ptr() + 2 * Cn * 4, coeffs.data_ptr() + 3 * Cn * 4
@@ -183,8 +188,15 @@ class Graph:
         p.bias = bias
         p.zeros = self.rt.zeros.data_ptr()
         p.a_bytes, p.w_bytes = A.span_bytes, W.numel() * 2
-        p.pipe = self.rt.gemm_pipe if max(p.a_bytes, p.w_bytes) < (1 << 31) else 1
+        p.pipe = self.rt.gemm_pipe
+        stats = None
+        if epi == S.EPI_STATS:
+            rows = S.I()
+            hip.call("ryolo_conv_gemm_plan", p, rows, None)
+            stats = self.f32(rows.value + 64, 2, Nout)[:rows.value]       # +64 rows: fold scratch of ryolo_bn_finalize
+            p.stats = stats.data_ptr()
         self._call(tape, "ryolo_conv_gemm", p)
+        return stats
 
     def _conv_geom(self, conv, x):
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -241,15 +253,9 @@ class Graph:
         k, s, pad, OH, OW = self._conv_geom(conv, x)
         cout = conv.out_channels
         y = fused[2] if fused else self.new(x.N, OH, OW, cout)
-        M = y.M
-        stats = None
-        if want_stats:
-            rows = S.I()
-            hip.call("ryolo_conv_gemm_stats_rows", M, cout, rt.gemm_pipe, rows)
-            stats = self.f32(rows.value + 64, 2, cout)[:rows.value]      # +64 rows: fold scratch of ryolo_bn_finalize
         epi = S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW)
-        self._gemm(self.fwd, x, x.ptr(), pk["wf"], cout, k * k, conv.in_channels, OH, OW, s, [(_taps_fwd(k, pad), 0, 0)], epi, y.ptr(),
-                   y.ld, stats=stats, coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
+        stats = self._gemm(self.fwd, x, x.ptr(), pk["wf"], cout, k * k, conv.in_channels, OH, OW, s, [(_taps_fwd(k, pad), 0, 0)], epi,
+                           y.ptr(), y.ld, coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
 
         def backward(need_dx=True):
             self._wgrad(conv, y, y.gptr(), cout, x)
@@ -270,14 +276,9 @@ class Graph:
         self._img_slot = len(self.fwd) - 1         # tape entry whose first argument (the image pointer) is patched per call
         cout = conv.out_channels
         y = fused[2] if fused else self.new(self.B, OH, OW, cout)
-        stats = None
-        if want_stats:
-            rows = S.I()
-            hip.call("ryolo_conv_gemm_stats_rows", y.M, cout, rt.gemm_pipe, rows)
-            stats = self.f32(rows.value + 64, 2, cout)[:rows.value]
-        self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)],
-                   S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW), y.ptr(), y.ld, stats=stats,
-                   coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
+        stats = self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)],
+                           S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW), y.ptr(), y.ld,
+                           coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
 
         def backward(need_dx=False):
             scratch = self.f32(cout, kp)

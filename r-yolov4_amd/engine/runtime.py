@@ -27,7 +27,9 @@ class Runtime:
         self._graphs = {}
         self.momentum_buf = None
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)       # source of padded rows for the LDS-DMA GEMM loop
-        self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", "1"))          # 2: buffer-DMA ring + 256-row tiles, 1: flat LDS-DMA ring, 0: register staged
+        # bits 0-7: generic mainloop (1 LDS-DMA ring [default], 0 register staged);
+        # 0x200: 3x3 stride-1 layers run the halo-patch kernel (csrc/conv3x3.hip)
+        self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200)), 0)
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):

@@ -61,6 +61,7 @@ _PTR = C.POINTER
 for _name, _sig in {
     "ryolo_conv_gemm": [_PTR(ConvGemmParams), P],
     "ryolo_conv_gemm_stats_rows": [L, I, I, _PTR(I)],
+    "ryolo_conv_gemm_plan": [_PTR(ConvGemmParams), _PTR(I), _PTR(I)],
     "ryolo_conv_wgrad": [_PTR(WgradParams), P],
     "ryolo_conv_wgrad_plan": [_PTR(WgradParams), _PTR(I), _PTR(Z)],
     "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
