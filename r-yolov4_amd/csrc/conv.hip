@@ -438,11 +438,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
-    const int i0 = blockIdx.x * BM;                    // output-channel block
-    const int q0 = blockIdx.y * 4;                     // first 32-wide column chunk (tap-major, then cin)
+    // XCD-aware order (1-D grid): all (output-channel, column) tiles of one pixel range get consecutive remapped ids, i.e. run on
+    // ONE XCD at about the same time, so the dY / X rows they all read are fetched into that XCD's L2 once.  With the plain 3-D
+    // grid the sibling tiles were dealt round-robin to the 8 XCDs and every L2 fetched the same rows again: 9x the HBM /
+    // Infinity-Cache traffic for a 3x3 layer — the kernel ran at the speed of its loads (ablation in DESIGN.md).
     const int cchunks = p.Cin / BK;
     const int nchunks = p.ntaps * cchunks;
-    const int64_t kbeg = (int64_t)blockIdx.z * p.kchunk;
+    const int gx = (p.Cout + BM - 1) / BM, gy = (nchunks + 3) / 4;
+    const int t_id = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t_id % gx, by = (t_id / gx) % gy, bz = t_id / (gx * gy);
+    const int i0 = bx * BM;                            // output-channel block
+    const int q0 = by * 4;                             // first 32-wide column chunk (tap-major, then cin)
+    const int64_t kbeg = (int64_t)bz * p.kchunk;
     const int64_t kend = min(M, kbeg + p.kchunk);
     if (kbeg >= kend) return;
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
@@ -451,7 +458,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     constexpr int APP = BM / 8;                        // pieces per pixel row
     constexpr int PA = BK * APP / 256;                 // 2 (BM=128) or 1 (BM=64)
     // B pieces: 4 chunks x BK pixels x 4 slots = 512 -> 2 per thread
-    uint4 ra[PA], rb[2];
+    // register-staged global -> LDS pipeline, THREE K steps deep: a step's loads are issued three steps before they are stored
+    // to LDS (one step of lead left every wave waiting a full HBM latency per 8 MFMAs: 16 % of the MFMA peak)
+    struct RegSet { uint4 a[PA]; uint4 b[2]; unsigned ok; };   // ok: bit u = A piece u valid, bit 8+u = B piece u valid
+    RegSet R0, R1, R2;
     int b_tap[2], b_c0[2];
     bool b_chunk_ok[2];
 #pragma unroll
@@ -491,26 +501,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         b_ow = rem - b_oh * p.OW;
     }
     int64_t m_step = kbeg;                                   // first pixel of the step being loaded
-    auto gload = [&](int step) {
-        (void)step;
+    auto gload = [&](RegSet& rs) {
+        // loads are UNCONDITIONAL (invalid pieces read a safe address and are zeroed when stored): a branch around a load makes
+        // hipcc fall back to s_waitcnt vmcnt(0) at the join, which would serialise the three-deep pipeline again
+        unsigned ok = 0;
 #pragma unroll
         for (int u = 0; u < PA; u++) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m_step + a_px[u] < kend && a_chan_ok[u]) v = *reinterpret_cast<const uint4*>(a_ptr[u]);
-            ra[u] = v;
+            const bool v = m_step + a_px[u] < kend && a_chan_ok[u];
+            rs.a[u] = *reinterpret_cast<const uint4*>(v ? a_ptr[u] : p.dY);
+            ok |= v ? (1u << u) : 0u;
             a_ptr[u] += (int64_t)BK * p.ldY;
         }
         const bool pix_ok = m_step + b_px < kend;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (pix_ok && b_chunk_ok[u]) {
-                const int ih = b_oh * p.sh + b_dh[u], iw = b_ow * p.sw + b_dw[u];
-                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
-                    v = *reinterpret_cast<const uint4*>(p.X + (((int64_t)b_img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0[u]);
-            }
-            rb[u] = v;
+            const int ih = b_oh * p.sh + b_dh[u], iw = b_ow * p.sw + b_dw[u];
+            const bool v = pix_ok && b_chunk_ok[u] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            const bf16_t* src = v ? p.X + (((int64_t)b_img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0[u] : p.X;
+            rs.b[u] = *reinterpret_cast<const uint4*>(src);
+            ok |= v ? (0x100u << u) : 0u;
         }
+        rs.ok = ok;
         m_step += BK;
         b_ow += BK;
         while (b_ow >= p.OW) {
@@ -518,18 +529,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             if (++b_oh >= p.OH) { b_oh = 0; b_img++; }
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const RegSet& rs) {
 #pragma unroll
         for (int u = 0; u < PA; u++) {
             const int id = tid + 256 * u;
             const int px = id / APP, pc = id % APP;
-            *reinterpret_cast<uint4*>(wA_(buf) + px * WG_LD + pc * 8) = ra[u];
+            *reinterpret_cast<uint4*>(wA_(buf) + px * WG_LD + pc * 8) = (rs.ok >> u) & 1u ? rs.a[u] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int id = tid + 256 * u;
             const int ch = id >> 7, px = (id & 127) >> 2, sl = id & 3;
-            *reinterpret_cast<uint4*>(wB_(buf) + px * WG_LD + ch * 32 + sl * 8) = rb[u];
+            *reinterpret_cast<uint4*>(wB_(buf) + px * WG_LD + ch * 32 + sl * 8) = (rs.ok >> (8 + u)) & 1u ? rs.b[u] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -541,72 +552,84 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int k = 0; k < nk; k++) {
-        const int buf = k & 1;
-        if (k + 1 < nk) gload(k + 1);
+    auto compute = [&](int buf) {
+        // Transposed fragment reads (gfx950 ds_read_b64_tr_b16): the tiles are pixel-major [pixel][channel] as they come
+        // from HBM, the MFMA wants 8 consecutive pixels (K) per lane for ONE channel.  Within each 16-lane group the
+        // instruction transposes a 4(pixel) x 16(channel) block: lane s supplies the address of pixel (s>>2), channels
+        // 4*(s&3)..+3 and receives channel s for the 4 pixels.  Two reads (pixels +0..3, +4..7) build one operand.
+        // All reads of the K step (both 16-pixel halves) are issued before the first MFMA, through the compiler builtin so
+        // hipcc counts them (lgkmcnt) and overlaps the tail of the reads with the first MFMAs.
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const int s16 = lane & 15, grp = lane >> 4;
+        bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            // Transposed fragment reads (gfx950 ds_read_b64_tr_b16): the tiles are pixel-major [pixel][channel] as they come
-            // from HBM, the MFMA wants 8 consecutive pixels (K) per lane for ONE channel.  Within each 16-lane group the
-            // instruction transposes a 4(pixel) x 16(channel) block: lane s supplies the address of pixel (s>>2), channels
-            // 4*(s&3)..+3 and receives channel s for the 4 pixels.  Two reads (pixels +0..3, +4..7) build one operand.
-            const int s16 = lane & 15, grp = lane >> 4;
             const int prow = ks * 16 + (grp >> 1) * 8 + (s16 >> 2);
             const int pcol = 16 * (grp & 1) + 4 * (s16 & 3);
-            bf16x8 af[TM], bfr[TN];
-            unsigned long long lo[TM + TN], hi[TM + TN];
-            unsigned addr[TM + TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++)
-                addr[i] = (unsigned)(size_t)(wA_(buf) + prow * WG_LD + wm * (BM / WM) + i * 32 + pcol);
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                addr[TM + j] = (unsigned)(size_t)(wB_(buf) + prow * WG_LD + wn * (BN / WN) + j * 32 + pcol);
-            // all reads and their wait in ONE asm statement (hipcc does not count asm LDS reads): early-clobber outputs
-            if constexpr (TM + TN == 4) {
-                asm volatile(
-                    "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
-                    "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
-                    "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
-                    "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:%12\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
-                    : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(4 * WG_LD * 2)
-                    : "memory");
-            } else {
-                static_assert(TM + TN == 3, "fragment count");
-                asm volatile(
-                    "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:%9\n\t"
-                    "ds_read_b64_tr_b16 %2, %7\n\tds_read_b64_tr_b16 %3, %7 offset:%9\n\t"
-                    "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:%9\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2])
-                    : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "i"(4 * WG_LD * 2)
-                    : "memory");
+            for (int i = 0; i < TM; i++) {
+                const bf16_t* a = wA_(buf) + prow * WG_LD + wm * (BM / WM) + i * 32 + pcol;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * WG_LD));
+                af[ks][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
-            __builtin_amdgcn_sched_barrier(0);
-            typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
 #pragma unroll
-            for (int i = 0; i < TM; i++) { u64x2 t = {lo[i], hi[i]}; af[i] = __builtin_bit_cast(bf16x8, t); }
+            for (int j = 0; j < TN; j++) {
+                const bf16_t* b = wB_(buf) + prow * WG_LD + wn * (BN / WN) + j * 32 + pcol;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + 4 * WG_LD));
+                bfr[ks][j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < TN; j++) { u64x2 t = {lo[TM + j], hi[TM + j]}; bfr[j] = __builtin_bit_cast(bf16x8, t); }
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (k + 1 < nk) sstore(buf ^ 1);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    gload(R0);
+    if (nk > 1) gload(R1);
+    if (nk > 2) gload(R2);
+    sstore(0, R0);
+    __syncthreads();
+    // step k: `cur` held step k (already in LDS) and is free -> receives step k+3; `nxt` holds step k+1 -> goes to the other buffer
+    auto step = [&](auto steady, int k, RegSet& cur, const RegSet& nxt) {
+        const int buf = k & 1;
+        // the steady-state body is branch free: a conditional load or store is a control-flow join, and at joins hipcc's
+        // waitcnt pass gives up the counted vmcnt(N) and drains to 0 (seen in the ISA) — which would undo the pipeline
+#ifndef WG_NO_LOAD
+        if (decltype(steady)::value || k + 3 < nk) gload(cur);
+#endif
+#ifndef WG_NO_COMPUTE
+        compute(buf);
+#endif
+#ifndef WG_NO_STORE
+        if (decltype(steady)::value || k + 1 < nk) sstore(buf ^ 1, nxt);
+#endif
         __syncthreads();
+    };
+    int k = 0;
+    for (; k + 5 < nk; k += 3) {
+        step(std::true_type{}, k, R0, R1);
+        step(std::true_type{}, k + 1, R1, R2);
+        step(std::true_type{}, k + 2, R2, R0);
+    }
+    for (; k < nk; k += 3) {
+        step(std::false_type{}, k, R0, R1);
+        if (k + 1 < nk) step(std::false_type{}, k + 1, R1, R2);
+        if (k + 2 < nk) step(std::false_type{}, k + 2, R2, R0);
     }
 
     // split-K partial tile -> workspace [z][Cout][ntaps*Cin] (GEMM layout; 128-byte row segments per store instruction).
     // No float atomics: the reduction over z is a separate deterministic pass.
     const int NK = p.ntaps * p.Cin;
-    float* part = p.partial + (int64_t)blockIdx.z * p.Cout * NK;
+    float* part = p.partial + (int64_t)bz * p.Cout * NK;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int col = wn * (BN / WN) + j * 32 + (lane & 31);
@@ -768,9 +791,9 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     if (rc) return rc;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
     if (bm == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3(gx, gy, p.splitk), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<128>), dim3(gx, gy, p.splitk), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, p.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
     RY_CHECK_LAUNCH();
     return RY_OK;
