@@ -105,6 +105,8 @@ int ryolo_conv_gemm_plan(const ConvGemmParams* p, int* stats_rows, int* kernel);
  * deterministic reduction that accumulates into the torch-layout .grad [Cout][Cin][kh*kw] (no float atomics). */
 int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_bytes);
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
+/* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K, 1 the 3x3 stride-1 halo-ring kernel (needs p->zeros) */
+int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
 
 /* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] (the buffer must have
  * room for 64 more rows: fold scratch for big layers) -> coeffs [4][C] =

@@ -43,6 +43,7 @@ typedef struct WgradParams {
     float* dW;                                       // torch layout [Cout][Cin][ntaps] fp32, atomically accumulated
     int splitk; int64_t kchunk;                      // pixels per split (multiple of BK) — filled by the library
     float* partial;                                  // split-K workspace [splitk][Cout][ntaps*Cin] fp32 (ryolo_conv_wgrad_plan)
+    const bf16_t* zeros;                             // >= 64 zero bytes in device memory (LDS-DMA source of padding rows); null: generic kernel only
 } WgradParams;
 
 typedef struct BnActParams {

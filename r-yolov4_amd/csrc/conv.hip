@@ -561,7 +561,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         // hipcc counts them (lgkmcnt) and overlaps the tail of the reads with the first MFMAs.
         typedef __attribute__((ext_vector_type(4))) short s16x4;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
         const int s16 = lane & 15, grp = lane >> 4;
         bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
@@ -776,8 +775,19 @@ extern "C" int ryolo_conv_wgrad_plan(const WgradParams* pp, int* splitk, size_t*
     int bm, gx, gy;
     const int rc = wgrad_geometry(p, bm, gx, gy);
     if (rc) return rc;
+    W3Geom g3;
+    if (w3_geometry(p, g3)) p.splitk = g3.splitk;              // 3x3 stride-1 layers: halo-ring kernel (conv3x3.hip)
     *splitk = p.splitk;
     *workspace_bytes = (size_t)p.splitk * p.Cout * p.ntaps * p.Cin * sizeof(float);
+    return RY_OK;
+}
+
+// 0: generic split-K kernel (conv.hip), 1: 3x3 stride-1 halo-ring kernel (conv3x3.hip) — what ryolo_conv_wgrad will launch
+extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
+{
+    if (!pp || !kernel) return RY_ERR_ARG;
+    W3Geom g3;
+    *kernel = w3_geometry(*pp, g3) ? 1 : 0;
     return RY_OK;
 }
 
@@ -790,6 +800,14 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     const int rc = wgrad_geometry(p, bm, gx, gy);
     if (rc) return rc;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
+    W3Geom g3;
+    if (w3_geometry(p, g3)) {
+        const int rc3 = w3_launch(p, g3, stream);
+        if (rc3) return rc3;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, g3.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
+        RY_CHECK_LAUNCH();
+        return RY_OK;
+    }
     if (bm == 64)
         hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
     else

@@ -453,3 +453,223 @@ int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
     if (g.BN == 64) return p3_launch_t<64, 4, 1>(p, g, stream);
     return p3_launch_t<128, 2, 2>(p, g, stream);
 }
+
+// =====================================================================================================================
+// 3x3 stride-1 WEIGHT GRADIENT: dW[co][tap][ci] = sum_p dY[p][co] * X[p + tap][ci]
+//
+// The generic split-K kernel (conv.hip) gives every (tap, 32-channel chunk) column tile its own workgroup, so the dY rows
+// are re-read 9*Cin/128 times and the X rows 9 times, from HBM / Infinity Cache (the sibling tiles drift apart and miss in
+// L2): the kernel runs at the speed of its loads (~6.5 TB/s; ablation in DESIGN.md §4.2).  Here one workgroup owns
+// 128 output channels x 32 input channels x ALL 9 taps for a range of pixels:
+//   * K (pixels) runs over PADDED coordinates — each image framed by one zero pixel — so tap (dh, dw) is the constant row
+//     offset dh*(W+2)+dw into ONE ring of input rows; padding rows are DMA'd from a zero page: no masks, no per-tap loads;
+//   * per 32-pixel K step a workgroup brings 32 new ring rows (64 B each) and the 32 x 128 dY tile: 10 KiB for 72 MFMAs
+//     (generic: 16 KiB for 32), X crosses L2 once per 128 output channels instead of 9 times;
+//   * both operands sit in LDS as contiguous 64-byte pixel rows: lane-linear LDS-DMA targets AND conflict-free for the
+//     transposed fragment reads (ds_read_b64_tr_b16: a 32-lane group reads 4 rows x 64 B = one full bank sweep);
+//   * wave w owns output channels [32w, 32w+32): 9 accumulator tiles (one per tap), 18 MFMAs per 20 fragments per step;
+//   * 3-stage dY ring + sliding X ring, counted vmcnt, one barrier per step; split-K slabs + the deterministic reduce of
+//     conv.hip; XCD-aware order keeps the tiles that share a pixel range on one L2.
+#define W3_NS 3
+
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams p, const W3Geom g)
+{
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t_id = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t_id % g.gx, bc = (t_id / g.gx) % g.gc, bz = t_id / (g.gx * g.gc);
+    const int i0 = bx * 128, ci0 = bc * 32;
+    const int64_t kbeg = (int64_t)bz * g.kchunk;
+    const int64_t kend = min(g.Mp, kbeg + g.kchunk);
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg + 31) >> 5);
+    const int H = p.OH, W = p.OW, PWp = g.PWp, HPp = g.HPp;
+    const int HALO = PWp + 1;
+    const unsigned rmask = (unsigned)g.RX - 1u;
+    unsigned char* const dyst = p3_lds;                            // [W3_NS][4 waves][32 px][64 B]
+    unsigned char* const xring = p3_lds + W3_NS * 8192;             // [RX][64 B]
+
+    // ---- DMA bookkeeping.  A 1-KiB piece = 16 pixel rows x 64 B; lane -> (row = lane >> 2, 16-byte slot = lane & 3).
+    // dY: wave w stages the two 16-row halves of ITS OWN 32-channel quarter; X: waves 0/1 stage the two halves of the 32 new rows.
+    // Loop-carried padded coordinates (img, ihp, iwp) per lane: no division inside the loop.
+    const int prow_l = lane >> 2, slot = lane & 3;
+    auto decomp = [&](int64_t qa, int& img, int& ihp, int& iwp) {
+        const int64_t per = (int64_t)HPp * PWp;
+        int64_t q = qa < 0 ? 0 : qa;
+        img = (int)(q / per);
+        const int rem = (int)(q - (int64_t)img * per);
+        ihp = rem / PWp;
+        iwp = rem - ihp * PWp;
+    };
+    auto advance = [&](int& img, int& ihp, int& iwp, int by) {
+        iwp += by;
+        while (iwp >= PWp) {
+            iwp -= PWp;
+            if (++ihp >= HPp) { ihp = 0; img++; }
+        }
+    };
+    // dY rows of step s, half u: padded pixel kbeg + 32 s + 16 u + prow_l
+    int64_t dq[2];
+    int dimg[2], dih[2], diw[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        dq[u] = kbeg + 16 * u + prow_l;
+        decomp(dq[u], dimg[u], dih[u], diw[u]);
+    }
+    const bool d_chan_ok = (i0 + 32 * wave + slot * 8) < p.CoutPad;
+    auto issue_dy = [&](int stage) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const bool ok = d_chan_ok && dq[u] < kend && dih[u] >= 1 && dih[u] <= H && diw[u] >= 1 && diw[u] <= W && dimg[u] < p.NB;
+            const bf16_t* src = ok ? p.dY + (((int64_t)dimg[u] * H + (dih[u] - 1)) * W + (diw[u] - 1)) * p.ldY + i0 + 32 * wave + slot * 8 : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * 8192 + wave * 2048 + u * 1024), 16, 0, 0);
+            dq[u] += 32;
+            advance(dimg[u], dih[u], diw[u], 32);
+        }
+    };
+    // X ring: slot of padded row q = q mod RX (q may be negative before the first image: two's-complement masking).  Pieces are
+    // 16 aligned rows.  Prologue: every wave stages 16 rows per iteration over [x0, xend) (a multiple of 64 rows covering the rows
+    // of steps 0 and 1 with their halos); steady state: waves 0 and 1 append the next 32 rows each step (for step s + 2).
+    const int64_t x0 = ((kbeg - HALO) >> 5) << 5;                    // aligned down to 32 (arithmetic shift: also for negatives)
+    const int pro_iters = (int)((kbeg + 64 + HALO - x0 + 63) >> 6);
+    int64_t xq = x0 + 16 * wave + prow_l;                            // this lane's row in its current piece
+    int ximg = 0, xih = 0, xiw = 0;
+    if (xq >= 0) decomp(xq, ximg, xih, xiw);
+    auto issue_x = [&]() {
+        const bool ok = xq >= 0 && xq < g.Mp && xih >= 1 && xih <= H && xiw >= 1 && xiw <= W;
+        const bf16_t* src = ok ? p.X + (((int64_t)ximg * H + (xih - 1)) * W + (xiw - 1)) * p.ldX + ci0 + slot * 8 : p.zeros;
+        const unsigned row0 = (unsigned)(int)(xq - prow_l) & rmask;   // wave-uniform, 16-aligned
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring + row0 * 64), 16, 0, 0);
+    };
+    auto step_x = [&](int by) {
+        const int64_t nq = xq + by;
+        if (xq < 0) { if (nq >= 0) decomp(nq, ximg, xih, xiw); }
+        else advance(ximg, xih, xiw, by);
+        xq = nq;
+    };
+    for (int it = 0; it < pro_iters; it++) {
+        issue_x();
+        step_x(64);
+    }
+    // now xq = x0 + 64 * pro_iters + 16 * wave + prow_l: exactly where waves 0 and 1 continue
+    issue_dy(0);
+    if (nk > 1) issue_dy(1);
+
+    // ---- fragment addressing: transposed reads, lane -> (pixel row, channel) inside a 16-lane group (see conv.hip)
+    const int s16 = lane & 15, grp = lane >> 4;
+    const int fr_row = (grp >> 1) * 8 + (s16 >> 2);                  // + ks*16 (+4 for the second half)
+    const int fr_col = (16 * (grp & 1) + 4 * (s16 & 3)) * 2;         // byte offset inside the 64-byte row
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    const unsigned kb32 = (unsigned)(int)kbeg;                        // low bits are all the ring index needs
+    for (int s = 0; s < nk; s++) {
+        // DMA this wave issued during step s-1 (operands of step s+1) may stay in flight: 2 dY pieces (+1 ring piece on waves 0, 1);
+        // step 0 follows the prologue, whose last two instructions are dY(1)
+        if (s + 1 >= nk) wait_vm<0>();
+        else if (s == 0 || wave >= 2) wait_vm<2>();
+        else wait_vm<3>();
+        __builtin_amdgcn_s_barrier();                                 // step s operands visible; step s-1 fully consumed
+        if (s + 2 < nk) {
+            if (wave < 2) { issue_x(); step_x(32); }
+            issue_dy((s + 2) % W3_NS);
+        }
+        const unsigned char* da = dyst + (s % W3_NS) * 8192 + wave * 2048;
+        const unsigned q0 = kb32 + 32u * (unsigned)s;                 // padded index (mod 2^32) of the step's first pixel
+        // 18 (16-pixel half, tap) MFMAs per step; the B fragment of MFMA i+PF is read while MFMA i runs (a software pipeline PF
+        // fragments deep: all-reads-first exposes the LDS latency once per half and needs 36 live registers, the compiler's own
+        // schedule double-buffers by one fragment and waits on every MFMA)
+        auto read_a = [&](int ks) {
+            const unsigned char* a = da + (ks * 16 + fr_row) * 64 + fr_col;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        auto read_b = [&](int i) {
+            const int ks = i / 9, t = i % 9;
+            const unsigned qq = q0 + (unsigned)(g.toff[t] + ks * 16 + fr_row);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xring + (qq & rmask) * 64 + fr_col));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xring + ((qq + 4u) & rmask) * 64 + fr_col));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        constexpr int PF = 4;
+        bf16x8 af[2], bq[18];
+        af[0] = read_a(0);
+#pragma unroll
+        for (int i = 0; i < PF; i++) bq[i] = read_b(i);
+        af[1] = read_a(1);
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + PF < 18) bq[i + PF] = read_b(i + PF);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- split-K partial tile -> workspace [z][Cout][9*Cin] (GEMM layout; 128-byte row segments per store)
+    const int NK = 9 * p.Cin;
+    float* part = p.partial + (int64_t)bz * p.Cout * NK;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int kc = t * p.Cin + ci0 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[t][e];
+        }
+    }
+}
+
+bool w3_geometry(const WgradParams& p, W3Geom& g)
+{
+    g = W3Geom{};
+    if (!p.zeros || p.ntaps != 9 || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
+    if (p.Cin % 32 || p.ldX % 8 || p.ldY % 8 || p.CoutPad % 8 || p.CoutPad < p.Cout || p.CoutPad > p.ldY) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; t++) {
+        if (p.dh[t] < -1 || p.dh[t] > 1 || p.dw[t] < -1 || p.dw[t] > 1) return false;
+        seen |= 1u << ((p.dh[t] + 1) * 3 + p.dw[t] + 1);
+    }
+    if (seen != 0x1ffu) return false;
+    g.PWp = p.OW + 2;
+    g.HPp = p.OH + 2;
+    g.Mp = (int64_t)p.NB * g.HPp * g.PWp;
+    const int need = 2 * (g.PWp + 1) + 160;
+    int rx = 256;
+    while (rx < need) rx <<= 1;
+    if (rx > 512) return false;                                   // two workgroups per CU; wider maps stay on the generic kernel
+    g.RX = rx;
+    g.gx = (int)ry_cdiv(p.Cout, 128);
+    g.gc = p.Cin / 32;
+    if (g.Mp < 32 * 1024 || g.Mp >= (1ll << 31)) return false;   // small problems: the generic kernel's finer tiles fill the chip better
+    int64_t sk = ry_cdiv(512, (int64_t)g.gx * g.gc);             // 2 resident workgroups x 256 CUs
+    const int64_t maxsplit = ry_cdiv(g.Mp, 32 * 32);              // at least 32 K-steps per split
+    if (sk > maxsplit) sk = maxsplit;
+    if (sk < 1) sk = 1;
+    g.kchunk = ry_cdiv(ry_cdiv(g.Mp, sk), 32) * 32;
+    g.splitk = (int)ry_cdiv(g.Mp, g.kchunk);
+    for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
+    g.lds_bytes = W3_NS * 8192u + (unsigned)g.RX * 64u;
+    g.ok = 1;
+    return true;
+}
+
+int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return RY_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<0>), dim3((unsigned)((int64_t)g.gx * g.gc * g.splitk)), dim3(256), g.lds_bytes, stream, p, g);
+    return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
+}

@@ -48,3 +48,20 @@ struct P3Geom {
 };
 bool p3_geometry(const ConvGemmParams& p, P3Geom& g);
 int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream);
+
+// ---- 3x3 stride-1 weight gradient over a sliding halo ring (conv3x3.hip) ------------------------------------------------
+// K runs over PADDED pixel coordinates (image framed by one zero pixel on every side), so every tap is a constant row
+// offset into one ring of input rows and no per-element masks exist.
+struct W3Geom {
+    int ok;
+    int PWp, HPp;              // padded width / height (W + 2, H + 2)
+    int64_t Mp;                // padded pixels = NB * HPp * PWp
+    int RX;                    // ring rows (power of two)
+    int gx, gc;                // output-channel tiles of 128, input-channel chunks of 32
+    int splitk;
+    int64_t kchunk;            // padded pixels per split (multiple of 32)
+    int toff[9];               // dh * PWp + dw per tap (caller's tap order)
+    unsigned lds_bytes;
+};
+bool w3_geometry(const WgradParams& p, W3Geom& g);
+int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);

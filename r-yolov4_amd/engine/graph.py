@@ -139,7 +139,12 @@ class Graph:
             return (f"conv_gemm_kernel<{tile}>", fl)
         if name == "ryolo_conv_wgrad":
             p = args[0]
-            return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin)
+            fl = 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin
+            kern = S.I()
+            hip.call("ryolo_conv_wgrad_kernel", p, kern)
+            if kern.value == 1:
+                return ("conv3x3_wgrad_kernel<128x9x32>", fl)
+            return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl)
         return (name, 0)
 
     def run(self, tape, timer=None):
@@ -239,6 +244,7 @@ class Graph:
         self._emit_wgrad(p)
 
     def _emit_wgrad(self, p):
+        p.zeros = self.rt.zeros.data_ptr()
         sk, need = S.I(), S.Z()
         hip.call("ryolo_conv_wgrad_plan", p, sk, need)
         self._wgrad_ws_bytes = max(self._wgrad_ws_bytes, need.value)

@@ -26,7 +26,7 @@ class WgradParams(C.Structure):
     _fields_ = [("dY", P), ("ldY", I), ("Cout", I), ("CoutPad", I),
                 ("X", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldX", I),
                 ("OH", I), ("OW", I), ("sh", I), ("sw", I), ("ntaps", I), ("dh", C.c_byte * MAX_TAPS), ("dw", C.c_byte * MAX_TAPS),
-                ("dW", P), ("splitk", I), ("kchunk", L), ("partial", P)]
+                ("dW", P), ("splitk", I), ("kchunk", L), ("partial", P), ("zeros", P)]
 
 
 class BnActParams(C.Structure):
@@ -64,6 +64,7 @@ for _name, _sig in {
     "ryolo_conv_gemm_plan": [_PTR(ConvGemmParams), _PTR(I), _PTR(I)],
     "ryolo_conv_wgrad": [_PTR(WgradParams), P],
     "ryolo_conv_wgrad_plan": [_PTR(WgradParams), _PTR(I), _PTR(Z)],
+    "ryolo_conv_wgrad_kernel": [_PTR(WgradParams), _PTR(I)],
     "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
     "ryolo_bn_eval_coeffs": [P, P, P, P, F, I, P, P],
     "ryolo_bn_act_fwd": [_PTR(BnActParams), P],

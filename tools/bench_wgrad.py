@@ -22,6 +22,8 @@ for r in range(k):
     for s in range(k):
         p.dh[r * k + s], p.dw[r * k + s] = r - pad, s - pad
 p.dW = dw.data_ptr()
+zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+if os.environ.get('W3', '1') == '1': p.zeros = zeros.data_ptr()
 sk, ws = S.I(), S.Z()
 hip.call("ryolo_conv_wgrad_plan", p, sk, ws)
 work = torch.empty(ws.value, dtype=torch.uint8, device=dev)
