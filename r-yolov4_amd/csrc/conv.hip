@@ -49,6 +49,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+#ifdef GEMM_TIMING
+    const unsigned long long T0 = __builtin_readcyclecounter();
+    unsigned long long T1 = 0, T2 = 0, T3 = 0;
+#endif
     const TapClass& tc = p.cls[blockIdx.z];
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int gridN = (p.Nout + BN - 1) / BN;
@@ -168,19 +172,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         int a_ih0[NPA], a_iw0[NPA];
         const bf16_t* a_ptr[NPA];
         bool a_ok[NPA];
+        // (img, oh, ow) of the tile's first row with ONE wave-uniform 64-bit division; rows inside the tile (< 256 further) by
+        // small exact reciprocal divisions — the per-lane 64-bit divisions of the first version cost ~3k cycles of an 8-step K loop
+        const int64_t HWo = (int64_t)p.OH * p.OW;
+        const int t_img = (int)(m0 / HWo);
+        const int t_rem = (int)(m0 - (int64_t)t_img * HWo);
+        const int t_oh = t_rem / p.OW, t_ow = t_rem - t_oh * p.OW;
+        const float rOW = 1.0f / (float)p.OW, rOH = 1.0f / (float)p.OH;
 #pragma unroll
         for (int u = 0; u < NPA; u++) {
             const int piece = wave + 4 * u;
             const int r = piece * RPP + lane / SPR;
             const int64_t m = m0 + r;
             a_ok[u] = piece < PCS_A && m < M;
-            const int64_t mm = a_ok[u] ? m : 0;
-            const int img = (int)(mm / ((int64_t)p.OH * p.OW));
-            const int rem = (int)(mm - (int64_t)img * p.OH * p.OW);
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int o = t_ow + r;
+            const int wr = small_div(o, p.OW, rOW);
+            const int ow = o - wr * p.OW;
+            const int orow = t_oh + wr;
+            const int wi = small_div(orow, p.OH, rOH);
+            const int oh = orow - wi * p.OH;
+            const int img = a_ok[u] ? t_img + wi : 0;
             a_ih0[u] = oh * p.sh;
             a_iw0[u] = ow * p.sw;
-            a_ptr[u] = p.A + ((int64_t)img * p.IH * p.IW + (int64_t)a_ih0[u] * p.IW + a_iw0[u]) * p.ldA + ((lane % SPR) ^ swz(r)) * 8;
+            a_ptr[u] = p.A + ((int64_t)img * p.IH * p.IW + (int64_t)(a_ok[u] ? a_ih0[u] : 0) * p.IW + (a_ok[u] ? a_iw0[u] : 0)) * p.ldA + ((lane % SPR) ^ swz(r)) * 8;
         }
         const bf16_t* b_ptr[NPB];
         bool b_ok[NPB];
@@ -240,6 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #pragma unroll
                 for (int it = 0; it < LPS; it++) issue_item(it);
             }
+#ifdef GEMM_TIMING
+        T1 = __builtin_readcyclecounter();
+#endif
         constexpr int KS = KB / 16, NMF = KS * TM * TN;
         for (int k = 0; k < nk; k++) {
             // stages allowed to stay in flight while stage k is consumed
@@ -290,6 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         __syncthreads();
     }
 
+#ifdef GEMM_TIMING
+    T2 = __builtin_readcyclecounter();
+#endif
     // ---- epilogue ----------------------------------------------------------------------------------------
     // The MFMAs ran with A = weights, B = pixels, so acc[i][j] is the TRANSPOSED 32x32 tile: column = lane & 31 = pixel
     // i*32 + (lane & 31), row = channel j*32 + (e & 3) + 8*(e >> 2) + 4*(lane >> 5).  A lane therefore owns 4 consecutive
@@ -374,6 +394,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             }
             *reinterpret_cast<uint4*>(o) = v;
         }
+#ifdef GEMM_TIMING
+        T3 = __builtin_readcyclecounter();
+#endif
         if (p.epi == EPI_STATS) {
             // BatchNorm batch statistics of the values actually stored (bf16-rounded), read back from the staged block:
             // lane -> (4-channel quad, row group); rows past M were zero-filled A rows and contribute exact zeros
@@ -417,6 +440,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             }
         }
     }
+#ifdef GEMM_TIMING
+    if (p.bias && tid == 0 && p.epi != EPI_F32_BIAS) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + (size_t)blockIdx.x * 4;
+        dbg[0] = T1 - T0; dbg[1] = T2 - T1; dbg[2] = T3 - T2; dbg[3] = __builtin_readcyclecounter() - T3;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -776,7 +805,7 @@ extern "C" int ryolo_conv_wgrad_plan(const WgradParams* pp, int* splitk, size_t*
     const int rc = wgrad_geometry(p, bm, gx, gy);
     if (rc) return rc;
     W3Geom g3;
-    if (w3_geometry(p, g3)) p.splitk = g3.splitk;              // 3x3 stride-1 layers: halo-ring kernel (conv3x3.hip)
+    if (w3_geometry(p, g3)) p.splitk = g3.slabs;               // 3x3 stride-1 layers: halo-ring kernel (conv3x3.hip)
     *splitk = p.splitk;
     *workspace_bytes = (size_t)p.splitk * p.Cout * p.ntaps * p.Cin * sizeof(float);
     return RY_OK;
@@ -804,7 +833,7 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     if (w3_geometry(p, g3)) {
         const int rc3 = w3_launch(p, g3, stream);
         if (rc3) return rc3;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, g3.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, g3.slabs, p.Cout, p.Cin, p.ntaps, p.dW);
         RY_CHECK_LAUNCH();
         return RY_OK;
     }

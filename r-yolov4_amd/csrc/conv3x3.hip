@@ -21,20 +21,11 @@
 //     on the PATCH row and applied on the source address, the reader recomputes it per tap (3 VALU);
 //   * epilogues as in conv.hip: raw bf16, training BatchNorm statistics, folded BN + activation (inference), accumulate.
 #include "conv_internal.h"
+#include <stdlib.h>
 
 #define P3_BM 256
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char p3_lds[];
-
-// exact n / d for 0 <= n < 2^16, 1 <= d < 2^16 with a precomputed float reciprocal (prologue index math; hipcc's generic
-// 32-bit division is ~40 instructions)
-__device__ __forceinline__ int small_div(int n, int d, float rd)
-{
-    int q = (int)((float)n * rd);
-    if (q * d > n) q--;
-    if ((q + 1) * d <= n) q++;
-    return q;
-}
 
 template <int K> __device__ __forceinline__ void wait_vm()
 {
@@ -52,6 +43,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
+#ifdef P3_TIMING
+    const unsigned long long T0 = __builtin_readcyclecounter();
+#endif
     const int H = p.OH, W = p.OW;
     const int64_t HW = (int64_t)H * W, M = (int64_t)p.NB * HW;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -190,6 +184,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     issue_w(0, 0, 0);
     issue_w(1, 0, 1);
 
+#ifdef P3_TIMING
+    const unsigned long long T1 = __builtin_readcyclecounter();
+#endif
     int s = 0;
     for (int cc = 0; cc < cchunks; cc++) {
         const bool more = cc + 1 < cchunks;
@@ -218,43 +215,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                 aaddr[i] = (amask[i] >> t) & 1u ? a : zrow_off;
             }
             const unsigned wb = wring_off + slot * WSLOT;
-            // all 2*(TM+TN) fragment reads of the step are issued back to back into distinct registers BEFORE the first MFMA
-            // (left alone, hipcc funnels every A fragment through one register quad: read -> lgkmcnt(0) -> 2 MFMA, eight exposed
-            // LDS round trips per step — seen in the ISA, 3x the step time)
-            bf16x8 af[2][TM], bfr[2][TN];
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-                for (int j = 0; j < TN; j++) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(p3_lds + wb + (fb[j] ^ (unsigned)(ks << 5)));
-#pragma unroll
-                for (int i = 0; i < TM; i++) af[ks][i] = *reinterpret_cast<const bf16x8*>(p3_lds + (aaddr[i] ^ (unsigned)(ks << 5)));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // MFMAs with the step's DMA instructions (1 patch piece + NPB weight pieces per wave) spread between them: an LDS-DMA
+            // Software pipeline over the 2*TM "units" (16-channel half ks, A fragment i): the A fragment of unit u+PF is read while
+            // unit u's TN MFMAs run; B fragments of a half are read one unit before its first use.  (All-reads-first exposes the
+            // LDS latency once per step; hipcc's own schedule funnels every A fragment through one register quad and waits on each.)
+            // The step's DMA instructions (1 patch piece + NPB weight pieces per wave) are spread between the units: an LDS-DMA
             // issue costs 100-185 cycles next to ds_reads but hides in the shadow of the matrix pipe (guide's price table).
             // Operands are swapped (A = weights, B = pixels): the accumulator holds the TRANSPOSED tile, so a lane owns 4
             // consecutive channels of one pixel — 8-byte packed stores in the epilogue.
-            constexpr int NMF = 2 * TM * TN, NIT = NPB + 1, GAP = NMF / (NIT + 1);
+            constexpr int NU = 2 * TM, PF = 2, NIT = NPB + 1;
+            bf16x8 af[NU], bfr[2][TN];
+            auto read_a = [&](int u) { return *reinterpret_cast<const bf16x8*>(p3_lds + (aaddr[u % TM] ^ (unsigned)((u / TM) << 5))); };
+            auto read_b = [&](int ks) {
 #pragma unroll
-            for (int q = 0; q < NMF; q++) {
-                const int ks = q / (TM * TN), i = (q / TN) % TM, j = q % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-                if ((q + 1) % GAP == 0 && (q + 1) / GAP <= NIT) {
-                    const int item = (q + 1) / GAP - 1;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (item == 0) {
-                        if (do_patch) issue_patch(t, cc + 1, nbuf);
-                    } else if (do_w) {
-                        const int u = item - 1;
-                        const bf16_t* src = b_ofs[u] != 0xffffffffu ? p.W + b_ofs[u] + w_off : p.zeros;
-                        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + w_dst + (wave + 4 * u) * 1024), 16, 0, 0);
+                for (int j = 0; j < TN; j++) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(p3_lds + wb + (fb[j] ^ (unsigned)(ks << 5)));
+            };
+            read_b(0);
+#pragma unroll
+            for (int u = 0; u < PF; u++) af[u] = read_a(u);
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + PF == TM) read_b(1);                              // one unit before the second half starts... (PF units ahead)
+                if (u + PF < NU) af[u + PF] = read_a(u + PF);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[u % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u / TM][j], af[u], acc[u % TM][j], 0, 0, 0);
+                // DMA item k after unit (k + 1) * NU / (NIT + 1) - 1
+#pragma unroll
+                for (int item = 0; item < NIT; item++)
+                    if (u == (item + 1) * NU / (NIT + 1) - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (item == 0) {
+                            if (do_patch) issue_patch(t, cc + 1, nbuf);
+                        } else if (do_w) {
+                            const int uu = item - 1;
+                            const bf16_t* src = b_ofs[uu] != 0xffffffffu ? p.W + b_ofs[uu] + w_off : p.zeros;
+                            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + w_dst + (wave + 4 * uu) * 1024), 16, 0, 0);
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
+            __builtin_amdgcn_sched_barrier(0);
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
+#ifdef P3_TIMING
+    const unsigned long long T2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();                                           // operand tiles dead: LDS is reused for the output staging
 
     // ---- epilogue.  acc[i][j] is the transposed 32x32 tile: column = lane & 31 = pixel i*32 + (lane & 31), row = channel
@@ -367,6 +374,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
             st[p.Nout + n0 + tid] = sq;
         }
     }
+#ifdef P3_TIMING
+    if (p.bias && tid == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + (size_t)blockIdx.x * 4;
+        dbg[0] = T0; dbg[1] = T1; dbg[2] = T2; dbg[3] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
@@ -472,12 +485,19 @@ int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 //     conv.hip; XCD-aware order keeps the tiles that share a pixel range on one L2.
 #define W3_NS 3
 
-template <int DUMMY>
+// CO64: layers with <= 64 output channels.  Two waves cover the channels (32 each) and the wave PAIRS split every K step into
+// its two 16-pixel halves, each pair accumulating into its own split-K slab (the deterministic reduce adds them), so all four
+// waves stay busy; the dY stage shrinks to 64 channels and the ring may be 1024 rows (maps up to 430 pixels wide).
+template <bool CO64>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams p, const W3Geom g)
 {
+    constexpr int DYS = CO64 ? 4096 : 8192;                       // bytes of one dY stage: [quarters][32 px][64 B]
+    constexpr int NDY = CO64 ? 1 : 2;                             // dY pieces per wave per step
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cow = CO64 ? (wave & 1) : wave;                     // 32-channel quarter of this wave
+    const int kh = CO64 ? (wave >> 1) : 0;                        // CO64: the 16-pixel half of each K step this wave multiplies
     const int t_id = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = t_id % g.gx, bc = (t_id / g.gx) % g.gc, bz = t_id / (g.gx * g.gc);
     const int i0 = bx * 128, ci0 = bc * 32;
@@ -488,8 +508,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
     const int H = p.OH, W = p.OW, PWp = g.PWp, HPp = g.HPp;
     const int HALO = PWp + 1;
     const unsigned rmask = (unsigned)g.RX - 1u;
-    unsigned char* const dyst = p3_lds;                            // [W3_NS][4 waves][32 px][64 B]
-    unsigned char* const xring = p3_lds + W3_NS * 8192;             // [RX][64 B]
+    unsigned char* const dyst = p3_lds;                            // [W3_NS][quarters][32 px][64 B]
+    unsigned char* const xring = p3_lds + W3_NS * DYS;              // [RX][64 B]
 
     // ---- DMA bookkeeping.  A 1-KiB piece = 16 pixel rows x 64 B; lane -> (row = lane >> 2, 16-byte slot = lane & 3).
     // dY: wave w stages the two 16-row halves of ITS OWN 32-channel quarter; X: waves 0/1 stage the two halves of the 32 new rows.
@@ -511,20 +531,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
         }
     };
     // dY rows of step s, half u: padded pixel kbeg + 32 s + 16 u + prow_l
-    int64_t dq[2];
-    int dimg[2], dih[2], diw[2];
+    int64_t dq[NDY];
+    int dimg[NDY], dih[NDY], diw[NDY];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        dq[u] = kbeg + 16 * u + prow_l;
+    for (int u = 0; u < NDY; u++) {
+        dq[u] = kbeg + 16 * (CO64 ? kh : u) + prow_l;
         decomp(dq[u], dimg[u], dih[u], diw[u]);
     }
-    const bool d_chan_ok = (i0 + 32 * wave + slot * 8) < p.CoutPad;
+    const bool d_chan_ok = (i0 + 32 * cow + slot * 8) < p.CoutPad;
     auto issue_dy = [&](int stage) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NDY; u++) {
             const bool ok = d_chan_ok && dq[u] < kend && dih[u] >= 1 && dih[u] <= H && diw[u] >= 1 && diw[u] <= W && dimg[u] < p.NB;
-            const bf16_t* src = ok ? p.dY + (((int64_t)dimg[u] * H + (dih[u] - 1)) * W + (diw[u] - 1)) * p.ldY + i0 + 32 * wave + slot * 8 : p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * 8192 + wave * 2048 + u * 1024), 16, 0, 0);
+            const bf16_t* src = ok ? p.dY + (((int64_t)dimg[u] * H + (dih[u] - 1)) * W + (diw[u] - 1)) * p.ldY + i0 + 32 * cow + slot * 8 : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + cow * 2048 + (CO64 ? kh : u) * 1024), 16, 0, 0);
             dq[u] += 32;
             advance(dimg[u], dih[u], diw[u], 32);
         }
@@ -572,14 +592,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
         // DMA this wave issued during step s-1 (operands of step s+1) may stay in flight: 2 dY pieces (+1 ring piece on waves 0, 1);
         // step 0 follows the prologue, whose last two instructions are dY(1)
         if (s + 1 >= nk) wait_vm<0>();
-        else if (s == 0 || wave >= 2) wait_vm<2>();
-        else wait_vm<3>();
+        else if (s == 0 || wave >= 2) wait_vm<NDY>();
+        else wait_vm<NDY + 1>();
         __builtin_amdgcn_s_barrier();                                 // step s operands visible; step s-1 fully consumed
         if (s + 2 < nk) {
             if (wave < 2) { issue_x(); step_x(32); }
             issue_dy((s + 2) % W3_NS);
         }
-        const unsigned char* da = dyst + (s % W3_NS) * 8192 + wave * 2048;
+        const unsigned char* da = dyst + (s % W3_NS) * DYS + cow * 2048;
         const unsigned q0 = kb32 + 32u * (unsigned)s;                 // padded index (mod 2^32) of the step's first pixel
         // 18 (16-pixel half, tap) MFMAs per step; the B fragment of MFMA i+PF is read while MFMA i runs (a software pipeline PF
         // fragments deep: all-reads-first exposes the LDS latency once per half and needs 36 live registers, the compiler's own
@@ -598,30 +618,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
         constexpr int PF = 4;
-        bf16x8 af[2], bq[18];
-        af[0] = read_a(0);
+        if constexpr (!CO64) {
+            bf16x8 af[2], bq[18];
+            af[0] = read_a(0);
 #pragma unroll
-        for (int i = 0; i < PF; i++) bq[i] = read_b(i);
-        af[1] = read_a(1);
+            for (int i = 0; i < PF; i++) bq[i] = read_b(i);
+            af[1] = read_a(1);
 #pragma unroll
-        for (int i = 0; i < 18; i++) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + PF < 18) bq[i + PF] = read_b(i + PF);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
+            for (int i = 0; i < 18; i++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + PF < 18) bq[i + PF] = read_b(i + PF);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
+            }
+        } else {
+            bf16x8 bq[9];
+            const bf16x8 af = read_a(kh);
+#pragma unroll
+            for (int i = 0; i < PF; i++) bq[i] = read_b(kh * 9 + i);
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + PF < 9) bq[i + PF] = read_b(kh * 9 + i + PF);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[i], acc[i], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- split-K partial tile -> workspace [z][Cout][9*Cin] (GEMM layout; 128-byte row segments per store)
     const int NK = 9 * p.Cin;
-    float* part = p.partial + (int64_t)bz * p.Cout * NK;
+    float* part = p.partial + ((int64_t)bz * (CO64 ? 2 : 1) + kh) * p.Cout * NK;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int kc = t * p.Cin + ci0 + (lane & 31);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const int co = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int co = i0 + 32 * cow + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
             if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[t][e];
         }
     }
@@ -644,19 +678,25 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     const int need = 2 * (g.PWp + 1) + 160;
     int rx = 256;
     while (rx < need) rx <<= 1;
-    if (rx > 512) return false;                                   // two workgroups per CU; wider maps stay on the generic kernel
+    g.co64 = p.Cout <= 64 ? 1 : 0;
+    if (rx > (g.co64 ? 1024 : 512)) return false;                 // <= 80 KiB LDS: two workgroups per CU; wider maps stay on the generic kernel
     g.RX = rx;
     g.gx = (int)ry_cdiv(p.Cout, 128);
     g.gc = p.Cin / 32;
-    if (g.Mp < 32 * 1024 || g.Mp >= (1ll << 31)) return false;   // small problems: the generic kernel's finer tiles fill the chip better
+    if (g.Mp >= (1ll << 31)) return false;
     int64_t sk = ry_cdiv(512, (int64_t)g.gx * g.gc);             // 2 resident workgroups x 256 CUs
-    const int64_t maxsplit = ry_cdiv(g.Mp, 32 * 32);              // at least 32 K-steps per split
+    static const int minsteps = getenv("RYOLO_W3_MINSTEPS") ? atoi(getenv("RYOLO_W3_MINSTEPS")) : 24;   // measured 24 / 48 / 128: shorter splits fill the chip, the two-halo prologue still amortises
+    const int64_t maxsplit = g.Mp / ((int64_t)minsteps * 32);      // K-steps per split: the ring prologue (2 halos) must amortise
     if (sk > maxsplit) sk = maxsplit;
+    // small problems stay on the generic kernel, whose finer tiles fill the chip better (measured: 16 x 100^2 x 32 -> 64: 0.6x here)
+    static const bool force = getenv("RYOLO_W3_FORCE") != nullptr;   // A/B runs: ignore the size heuristic
     if (sk < 1) sk = 1;
+    if ((int64_t)g.gx * g.gc * sk < 128 && !force) return false;
     g.kchunk = ry_cdiv(ry_cdiv(g.Mp, sk), 32) * 32;
     g.splitk = (int)ry_cdiv(g.Mp, g.kchunk);
     for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
-    g.lds_bytes = W3_NS * 8192u + (unsigned)g.RX * 64u;
+    g.lds_bytes = W3_NS * (g.co64 ? 4096u : 8192u) + (unsigned)g.RX * 64u;
+    g.slabs = g.splitk * (g.co64 ? 2 : 1);
     g.ok = 1;
     return true;
 }
@@ -665,11 +705,17 @@ int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                hipSuccess)
             return RY_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<0>), dim3((unsigned)((int64_t)g.gx * g.gc * g.splitk)), dim3(256), g.lds_bytes, stream, p, g);
+    const dim3 grid((unsigned)((int64_t)g.gx * g.gc * g.splitk));
+    if (g.co64)
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<true>), grid, dim3(256), g.lds_bytes, stream, p, g);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<false>), grid, dim3(256), g.lds_bytes, stream, p, g);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }

@@ -32,6 +32,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// exact n / d for 0 <= n < 2^16, 1 <= d < 2^16 with a float reciprocal (prologue index math; hipcc's generic 32-bit
+// division is ~40 instructions, the 64-bit one several hundred)
+__device__ __forceinline__ int small_div(int n, int d, float rd)
+{
+    int q = (int)((float)n * rd);
+    if (q * d > n) q--;
+    if ((q + 1) * d <= n) q++;
+    return q;
+}
+
 // ---- 3x3 stride-1 halo-patch kernel (conv3x3.hip) -------------------------------------------------------------------
 // geometry chosen on the host; `mode` 0 = not eligible, 1 = 2-D tiles (TH x TW output pixels of one image),
 // 2 = flat runs of 256 consecutive output pixels
@@ -58,7 +68,7 @@ struct W3Geom {
     int64_t Mp;                // padded pixels = NB * HPp * PWp
     int RX;                    // ring rows (power of two)
     int gx, gc;                // output-channel tiles of 128, input-channel chunks of 32
-    int splitk;
+    int splitk, slabs, co64;   // K ranges; fp32 slabs written (2 per range for the <= 64 output-channel variant)
     int64_t kchunk;            // padded pixels per split (multiple of 32)
     int toff[9];               // dh * PWp + dw per tap (caller's tap order)
     unsigned lds_bytes;

@@ -36,6 +36,8 @@ except Exception:                                   # older library (A/B runs th
     hip.call("ryolo_conv_gemm_stats_rows", B * OH * OH, Cout, pipe & 0xff, rows)
 stats = torch.zeros(rows.value, 2, Cout, device=dev)
 p.stats = stats.data_ptr()
+dbg = torch.zeros(4 * 70000, dtype=torch.int64, device=dev)
+if os.environ.get('P3_TIMING') or os.environ.get('GEMM_TIMING'): p.bias = dbg.data_ptr()
 st = hip.stream()
 for _ in range(3): hip.call("ryolo_conv_gemm", p, st)
 torch.cuda.synchronize()
@@ -57,3 +59,14 @@ if epi == 1:
     yy = y.float()
     print("stats rel err", float((stats[:, 0].sum(0) - yy.sum(0)).norm() / yy.sum(0).norm()), float((stats[:, 1].sum(0) - (yy * yy).sum(0)).norm() / (yy * yy).sum(0).norm()))
 
+
+if os.environ.get('GEMM_TIMING'):
+    import numpy as np
+    torch.cuda.synchronize()
+    d = dbg.view(-1, 4).cpu().numpy(); d = d[d[:, 1] != 0]
+    print("blocks", len(d), "prologue", np.mean(d[:, 0]), "loop", np.mean(d[:, 1]), "stage+store", np.mean(d[:, 2]), "stats", np.mean(d[:, 3]))
+if os.environ.get('P3_TIMING'):
+    import numpy as np
+    torch.cuda.synchronize()
+    d = dbg.view(-1, 4).cpu().numpy(); d = d[d[:, 0] != 0]
+    print("blocks", len(d), "prologue", np.mean(d[:, 1] - d[:, 0]), "loop", np.mean(d[:, 2] - d[:, 1]), "epilogue", np.mean(d[:, 3] - d[:, 2]))
