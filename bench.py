@@ -59,6 +59,37 @@ def weights_init_normal(m):            # train.py:28-33
         torch.nn.init.constant_(m.bias.data, 0.0)
 
 
+PMC_CLASSES = {
+    "conv_gemm_kernel<128x128>": ("conv_gemm_kernel<128, 128, 2, 2, 1, 32>", "conv_gemm_kernel<128, 128, 2, 2, 1, 64>"),
+    "conv_gemm_kernel<128x64>": ("conv_gemm_kernel<128, 64, 2, 2, 1, 32>", "conv_gemm_kernel<128, 64, 2, 2, 1, 64>"),
+    "conv_gemm_kernel<256x32>": ("conv_gemm_kernel<256, 32, 4, 1, 1, 32>",),
+    "conv3x3_patch_kernel<256x128>": ("conv3x3_patch_kernel<128, 2, 2>",),
+    "conv3x3_patch_kernel<256x64>": ("conv3x3_patch_kernel<64, 4, 1>",),
+    "conv_wgrad_kernel<128>": ("conv_wgrad_kernel<128>",),
+    "conv_wgrad_kernel<64>": ("conv_wgrad_kernel<64>",),
+    "conv3x3_wgrad_kernel<128x9x32>": ("conv3x3_wgrad_kernel<false>", "conv3x3_wgrad_kernel<true>"),
+}
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of each timed kernel class from the committed rocprofv3 PMC profile of THIS workload
+    (profiles/r01_pmc_step_traffic.json, made by tools/pmc_step.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2
+    correction on FETCH_SIZE).  Counters cannot be read from inside the timed run; any other configuration reports null."""
+    if (args.ver, args.mode, args.size, args.nc, args.batch) != ("yolov7", "kfiou", 800, 16, 64):
+        return {}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_step_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    kern = json.load(open(path))["kernels"]
+    res = {}
+    for cls, names in PMC_CLASSES.items():
+        rows = [kern[n] for n in names if n in kern]
+        n = sum(r["launches"] for r in rows)
+        if n:
+            res[cls] = int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n)
+    return res
+
+
 def cpu_baseline(args, budget_s=25.0):
     """The oracle restatement (oracle/ref_model.py + ref_ops.py, pinned to the imported reference by the golden fixtures)
     doing the same training step on the host cores: fp32, SGD nesterov.  Bounded sample: batch 1, at most 2 steps."""
@@ -184,14 +215,21 @@ def main():
         out["mfma_roofline_frac_whole_step"] = round(value * gf * 1e9 / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
     if timer is not None:
         summ = timer.summary()
-        dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
-        k, v = dom
-        ach = v["flops"] / v["seconds"] / 1e12
-        out["roofline"] = {"kernel": k, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": v["launches"] // args.steps,
-                           "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
-                           "share_of_step": round(v["seconds"] / dt, 4)}
+        pmc = pmc_traffic(args)
+
+        def roof(k, v):
+            ach = v["flops"] / v["seconds"] / 1e12
+            return {"kernel": k, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc.get(k),
+                    "launches_per_step": v["launches"] // args.steps,
+                    "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
+                    "share_of_step": round(v["seconds"] / dt, 4)}
+        # dominant kernel class by time inside the timed region (HIP events on the launch stream)
+        out["roofline"] = roof(*max(summ.items(), key=lambda kv: kv[1]["seconds"]))
+        # BASELINE.json north_star quotes the MFMA fraction of the 3x3 convs separately: the halo-patch kernel (fwd + dgrad)
+        k33 = "conv3x3_patch_kernel<256x128>"
+        if k33 in summ:
+            out["roofline_3x3"] = roof(k33, summ[k33])
         out["kernels"] = {kk: {"tflops": round(vv["flops"] / vv["seconds"] / 1e12, 2), "ms_per_step": round(vv["seconds"] / args.steps * 1e3, 3),
                                "launches_per_step": vv["launches"] // args.steps} for kk, vv in summ.items()}
     # secondary metric of BASELINE.json: rotated-NMS latency at 10k boxes (device time, median of 30; clustered set, thr 0.65)
