@@ -52,6 +52,17 @@ int ryolo_box_iou_rotated(const float* b1, int n, const float* b2, int m, void* 
 /* out[i] = IoU(b1[i], b2[i]) — the element-wise SkewIoU score of the commented-out block lib/loss.py:233-245. */
 int ryolo_diag_iou_rotated(const float* b1, const float* b2, int n, float* out, ryolo_stream_t stream);
 
+/* mAP evaluation (test.py:102-149 `get_batch_statistics`): true-positive matrix for a whole batch in one launch.
+ * preds [npred,7] = (x, y, w, h, theta_rad, score, cls), images concatenated, each image score-descending (post_process order);
+ * pred_off / tgt_off [batch+1] row offsets (int64, device); targets [ntgt,7] = (img, cls, x, y, w, h, theta_rad) grouped by image in
+ * the caller's order; iouv [niou] ascending thresholds (device); tp [npred,niou] bytes out.  Class ids must be integers in
+ * [0, num_classes), num_classes <= 256.  Side effect of the reference kept: theta of preds becomes degrees in place for images
+ * that have both predictions and labels (test.py:126). */
+int ryolo_map_match_workspace_bytes(int64_t npred, int64_t ntgt, size_t* bytes);
+int ryolo_map_match(float* preds, const int64_t* pred_off, const float* targets, const int64_t* tgt_off, int batch, int64_t npred,
+                    int64_t ntgt, const float* iouv, int niou, int num_classes, unsigned char* tp, void* workspace, size_t workspace_bytes,
+                    ryolo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * YoloLayer — replaces model/yololayer.py:15-56 (YoloCSLLayer.forward) and :66-105 (YoloKFIoULayer.forward).
  * ------------------------------------------------------------------------------------------------------------ */

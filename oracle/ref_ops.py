@@ -276,3 +276,78 @@ def gaussian_label(angle_deg_plus90, num_class=180, u=0, sig=6.0):
     y = np.exp(-(x - u) ** 2 / (2 * sig ** 2))
     k = int(num_class / 2 - angle_deg_plus90)
     return np.concatenate([y[k:], y[:k]], axis=0)
+
+
+# ----------------------------------------------------------------------------------------------------------- mAP evaluation
+# test.py:16-164.  Test infrastructure like the rest of this package (header of __init__.py).
+def get_batch_statistics(outputs, targets, iouv, niou):
+    """test.py:102-149.  outputs: list of [n_i, 7] (x, y, w, h, theta_rad, score, cls) score-descending (post_process);
+    targets [nt, 7] = (img, cls, x, y, w, h, theta_rad) in pixels.  Returns the reference's list of
+    (tp bool [n_i, niou], scores, labels, target classes) — images with neither predictions nor labels are skipped
+    (:112-115).  Side effect kept: theta of `outputs[i]` becomes DEGREES in place when the image has labels (:126)."""
+    from . import pairwise_iou_rotated as _pair
+    stats = []
+    for si, pred in enumerate(outputs):
+        tar = targets[targets[:, 0] == si, 1:]                                   # copy (boolean mask), as in the reference
+        nl = len(tar)
+        tcls = tar[:, 0].tolist() if nl else []
+        if len(pred) == 0:
+            if nl:
+                stats.append((np.zeros((0, niou), dtype=bool), np.empty(0), np.empty(0), tcls))
+            continue
+        tp = torch.zeros(pred.shape[0], niou, dtype=torch.bool)
+        if nl:
+            labels = pred[:, 6]
+            pred[:, 4] = pred[:, 4] / np.pi * 180                                # :126 (in place on the caller's tensor)
+            tar[:, 5] = tar[:, 5] / np.pi * 180                                  # :127 (on the copy)
+            tl = tar[:, 0]
+            for c in torch.unique(tl):
+                ti = (c == tl).nonzero(as_tuple=False).view(-1)
+                pi = (c == labels).nonzero(as_tuple=False).view(-1)
+                if pi.shape[0]:
+                    m = torch.from_numpy(_pair(pred[pi, :5].numpy(), tar[ti, 1:6].numpy()))
+                    ious, i = m.max(1)                                           # first maximum on ties
+                    seen = set()
+                    for j in (ious > iouv[0]).nonzero(as_tuple=False).view(-1).tolist():
+                        d = int(ti[i[j]])
+                        if d not in seen:                                        # a prediction whose best target is taken stays FP
+                            seen.add(d)
+                            tp[pi[j]] = ious[j] > iouv
+        stats.append((tp, pred[:, 5].clone(), pred[:, 6].clone(), tcls))
+    return stats
+
+
+def compute_ap(recall, precision):
+    """test.py:73-99: sentinels, precision envelope, 101-point interpolation, trapezoid."""
+    mrec = np.concatenate(([0.0], recall, [recall[-1] + 0.01]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    x = np.linspace(0, 1, 101)
+    return np.trapz(np.interp(x, mrec, mpre), x), mpre, mrec
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls):
+    """test.py:16-70.  Returns (p, r, ap [nc, niou], f1, unique classes int32) at the max-mean-F1 confidence."""
+    i = np.argsort(-conf)
+    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
+    unique_classes = np.unique(target_cls)
+    nc = unique_classes.shape[0]
+    px = np.linspace(0, 1, 1000)
+    ap, p, r = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
+    for ci, c in enumerate(unique_classes):
+        i = pred_cls == c
+        n_l = (target_cls == c).sum()
+        n_p = i.sum()
+        if n_p == 0 or n_l == 0:
+            continue
+        fpc = (1 - tp[i]).cumsum(0)
+        tpc = tp[i].cumsum(0)
+        recall = tpc / (n_l + 1e-16)
+        r[ci] = np.interp(-px, -conf[i], recall[:, 0], left=0)
+        precision = tpc / (tpc + fpc)
+        p[ci] = np.interp(-px, -conf[i], precision[:, 0], left=1)
+        for j in range(tp.shape[1]):
+            ap[ci, j], _, _ = compute_ap(recall[:, j], precision[:, j])
+    f1 = 2 * p * r / (p + r + 1e-16)
+    i = f1.mean(0).argmax()
+    return p[:, i], r[:, i], ap, f1[:, i], unique_classes.astype("int32")

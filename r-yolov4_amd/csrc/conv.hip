@@ -413,27 +413,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 ssum[2] += f2; ssq[2] += f2 * f2;
                 ssum[3] += f3; ssq[3] += f3 * f3;
             }
-            __syncthreads();                                   // staging blocks dead: LDS becomes the cross-wave reduction buffer
-            float* red = reinterpret_cast<float*>(smem);          // [WM][2][BN]
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float sm = ssum[q], sq = ssq[q];
-#pragma unroll
-                for (int o = NQ; o < 64; o <<= 1) {
-                    sm += __shfl_xor(sm, o, 64);
-                    sq += __shfl_xor(sq, o, 64);
-                }
-                if (lane < NQ) {
-                    const int col = wn * WTN + cq * 4 + q;
-                    red[(wm * 2 + 0) * BN + col] = sm;
-                    red[(wm * 2 + 1) * BN + col] = sq;
-                }
-            }
+            __syncthreads();                                   // staging blocks dead: LDS becomes the reduction buffer
+            // every lane parks its 8 partial sums in LDS and one thread per column folds the RG x WM partials: the cross-lane
+            // shuffle tree this replaces (16 dependent ds_bpermute round trips) cost ~2 k cycles of a short-K workgroup
+            float* part = reinterpret_cast<float*>(smem);      // [wave][RG][2][WTN]
+            float* mine = part + ((wave * RG + rg) * 2) * WTN + cq * 4;
+            *reinterpret_cast<float4*>(mine) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+            *reinterpret_cast<float4*>(mine + WTN) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
             __syncthreads();
             if (tid < BN && n0 + tid < p.Nout) {
+                const int wn_c = tid / WTN, cc = tid % WTN;
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
-                for (int w = 0; w < WM; w++) { sm += red[(w * 2 + 0) * BN + tid]; sq += red[(w * 2 + 1) * BN + tid]; }
+                for (int w = 0; w < WM; w++)
+#pragma unroll
+                    for (int r = 0; r < RG; r++) {
+                        const float* src = part + (((w * WN + wn_c) * RG + r) * 2) * WTN + cc;
+                        sm += src[0];
+                        sq += src[WTN];
+                    }
                 float* st = p.stats + (int64_t)mb * 2 * p.Nout;
                 st[n0 + tid] = sm;
                 st[p.Nout + n0 + tid] = sq;

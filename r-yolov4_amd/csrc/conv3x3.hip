@@ -348,27 +348,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
         }
     }
     if (p.epi == EPI_STATS) {
-        // fold the 4 row groups of the wave, then the WM waves that share a column block (through LDS)
+        // every lane parks its 8 partial sums in LDS, one thread per column folds the 4 row groups x WM waves
+        // (a shuffle tree here is 16 dependent ds_bpermute round trips, ~2 k cycles)
         __syncthreads();
-        float* red = reinterpret_cast<float*>(p3_lds);          // [WM][2][BN]
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float sm = ssum[q], sq = ssq[q];
-            sm += __shfl_xor(sm, 16, 64);
-            sq += __shfl_xor(sq, 16, 64);
-            sm += __shfl_xor(sm, 32, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            if (lane < 16) {
-                const int col = wn * WTN + cq * 4 + q;
-                red[(wm * 2 + 0) * BN + col] = sm;
-                red[(wm * 2 + 1) * BN + col] = sq;
-            }
-        }
+        float* part = reinterpret_cast<float*>(p3_lds);          // [wave][4][2][WTN]
+        float* mine = part + ((wave * 4 + rg) * 2) * WTN + cq * 4;
+        *reinterpret_cast<float4*>(mine) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+        *reinterpret_cast<float4*>(mine + WTN) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
         __syncthreads();
         if (tid < BN && n0 + tid < p.Nout) {
+            const int wn_c = tid / WTN, cc = tid % WTN;
             float sm = 0.f, sq = 0.f;
 #pragma unroll
-            for (int w = 0; w < WM; w++) { sm += red[(w * 2 + 0) * BN + tid]; sq += red[(w * 2 + 1) * BN + tid]; }
+            for (int w = 0; w < WM; w++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float* src = part + (((w * WN + wn_c) * 4 + r) * 2) * WTN + cc;
+                    sm += src[0];
+                    sq += src[WTN];
+                }
             float* st = p.stats + (int64_t)mb * 2 * p.Nout;
             st[n0 + tid] = sm;
             st[p.Nout + n0 + tid] = sq;

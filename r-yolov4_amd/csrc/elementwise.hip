@@ -773,7 +773,7 @@ extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_pe
     const int cols = c8 < 256 ? c8 : 256;
     const int nrl = 256 / cols;
     int64_t blocks = ry_cdiv(M, (int64_t)nrl * 8);                  // >= 8 rows per row lane
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 4096) blocks = 4096;                               // (2048 blocks and no fold pass measured 3 ms/step slower: the reduce wants the occupancy)
     if (blocks < 1) blocks = 1;
     *rows_per_block = (int)ry_cdiv(M, blocks);
     *nblk = (int)ry_cdiv(M, *rows_per_block);

@@ -25,6 +25,8 @@ _SIGNATURES = {
     "ryolo_pp_score": [_P, _I, _L, _I, _F, _P, _P, _P, _P],
     "ryolo_pp_gather": [_P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _P, _P, _P],
     "ryolo_pp_emit": [_P, _P, _P, _I, _L, _L, _P, _P],
+    "ryolo_map_match_workspace_bytes": [_L, _L, ctypes.POINTER(_Z)],
+    "ryolo_map_match": [_P, _P, _P, _P, _I, _L, _L, _P, _I, _I, _P, _P, _Z, _P],
 }
 _lib = None
 

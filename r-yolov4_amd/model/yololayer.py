@@ -52,7 +52,8 @@ class _YoloLayerBase(nn.Module):
             for a in self.anchors[i]:
                 an += [float(a[0]), float(a[1]), float(a[2]) if len(a) > 2 else 0.0]
             arr = (hip._F * len(an))(*an)
-            hip.call("ryolo_decode", self.MODE, hip.ptr(out[i].contiguous()), hip.ptr(infer), bs, len(self.anchors[i]),
+            head = out[i].contiguous()                         # named: a temporary copy must outlive the launch
+            hip.call("ryolo_decode", self.MODE, hip.ptr(head), hip.ptr(infer), bs, len(self.anchors[i]),
                      out[i].size(2), self.nc, float(self.stride[i]), arr, off, sum(rows), st)
             off += rows[i]
         return out, infer
