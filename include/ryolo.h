@@ -119,6 +119,13 @@ int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
 /* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K, 1 the 3x3 stride-1 halo-ring kernel (needs p->zeros) */
 int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
 
+/* first layer, 3x3 stride 1 pad 1 on the fp32 NCHW image (Cin = 3, Cout <= 32), without the im2col round trip (csrc/stem.hip);
+ * _plan: partial-statistics rows of epilogue 1 and the weight-gradient workspace; _wgrad needs Cout == 32 and W % 16 == 0 and
+ * leaves dW in the [Cout][32] GEMM layout in p->scratch (ryolo_unpack_wgrad adds it to the torch-layout .grad). */
+int ryolo_stem3x3_plan(int NB, int H, int W, int Cout, int* stats_rows, size_t* wgrad_workspace_bytes);
+int ryolo_stem3x3_fwd(const StemParams* p, ryolo_stream_t stream);
+int ryolo_stem3x3_wgrad(const StemWgradParams* p, ryolo_stream_t stream);
+
 /* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] (the buffer must have
  * room for 64 more rows: fold scratch for big layers) -> coeffs [4][C] =
  * mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean/var updated in place (unbiased var). */
@@ -158,7 +165,7 @@ int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int Ci
 /* torch.optim.SGD(momentum, nesterov=True) of train.py:156 over flat buffers: buf = mu*buf + g; p -= lr*(g + mu*buf) */
 int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, float mu, float gscale, int zero_grad,
                        ryolo_stream_t stream);   /* g is scaled by gscale on read; zero_grad=1 clears it (optimizer.zero_grad fused) */
-int ryolo_struct_sizes(int* sizes /* [8] */);
+int ryolo_struct_sizes(int* sizes /* [10] */);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Loss — replaces ComputeCSLLoss.__call__/build_targets (lib/loss.py:191-331) and ComputeKFIoULoss (:368-492),

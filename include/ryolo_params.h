@@ -46,6 +46,23 @@ typedef struct WgradParams {
     const bf16_t* zeros;                             // >= 64 zero bytes in device memory (LDS-DMA source of padding rows); null: generic kernel only
 } WgradParams;
 
+/* first layer (3x3 stride 1, Cin = 3) computed directly from the fp32 NCHW image: csrc/stem.hip */
+typedef struct StemParams {
+    const float* img; int NB, H, W;                  // [NB, 3, H, W] fp32 (what train.py:186 hands over)
+    const bf16_t* wf; int Cout;                      // packed weights [Cout][32], k = (r*3 + s)*3 + c, zero padded 27 -> 32; Cout <= 32
+    int epi;                                         // 0 raw, 1 BatchNorm statistics, 2 folded BN + activation
+    bf16_t* out; int ldC;
+    float* stats;                                    // epi 1: [rows][2][Cout], rows from ryolo_stem3x3_plan
+    const float* scale; const float* shift; int act; // epi 2
+} StemParams;
+
+typedef struct StemWgradParams {
+    const float* img; int NB, H, W;
+    const bf16_t* dY; int ldY, Cout;                 // [NB*H*W][ldY] bf16, Cout == 32
+    float* scratch;                                  // out: dW in the GEMM layout [Cout][32] fp32 (overwritten; ryolo_unpack_wgrad adds it to .grad)
+    float* workspace;                                // ryolo_stem3x3_plan bytes
+} StemWgradParams;
+
 typedef struct BnActParams {
     const bf16_t* y1; int ld1; const float* co1;      // co = [4][C]: mean, invstd, scale, shift
     const bf16_t* y2; int ld2; const float* co2;      // optional second branch (RepConv rbr_1x1), summed before the activation

@@ -1,0 +1,257 @@
+// First layer of the backbones: 3x3 stride-1 convolution of the fp32 NCHW image, Cin = 3 -> 32 channels
+// (model/backbone.py:9,60 `Conv(3, 32, 3, 1)`), forward and weight gradient, DIRECT from the image.
+//
+// The generic route lowers this layer to an explicit im2col ([pixels][32] bf16, k = (r*3+s)*3+c padded 27 -> 32) followed by
+// a single-tap GEMM: at 800^2 x batch 64 that is 41 M pixels, a 2.6 GB im2col write, a 2.6 GB read back by the GEMM and
+// another 2.6 GB read by the weight-gradient GEMM — the layer is pure HBM traffic (K = 27), and the col tensor triples it.
+// Here both directions gather their 27 taps straight from the image (0.5 GB, L1/L2 resident per tile):
+//   forward   one wave = 32 consecutive pixels: the im2col row of a pixel is built in registers (16 scalar loads per lane, one
+//             lane = one pixel x 8 k-values of each K16 half), 2 MFMA 32x32x16 against the weight fragments held in registers;
+//             A = weights, B = pixels, so a lane ends with 4 consecutive channels of its pixel -> 8-byte stores; BatchNorm
+//             statistics accumulate in registers over the wave's tiles and leave as one partial row per workgroup;
+//   wgrad     K = pixels.  One wave = runs of 16 pixels of one image row: dY^T through a wave-private 1-KiB LDS-DMA piece +
+//             transposed reads (ds_read_b64_tr_b16), col^T needs 8 CONSECUTIVE pixels of one (tap, channel) per lane = 8
+//             consecutive floats of an image row: plain loads, no LDS.  Per-workgroup slab -> small deterministic fold.
+// Both are memory streams (0.5 + 2.6 GB each); nothing here is worth an LDS tile.
+#include "conv_internal.h"
+
+// k -> (channel, row tap, column tap) of the im2col ordering k = (r*3 + s)*3 + c
+__device__ __forceinline__ void stem_k(int k, int& c, int& r, int& s)
+{
+    const int tap = k / 3;
+    c = k - tap * 3;
+    r = tap / 3;
+    s = tap - r * 3;
+}
+
+__global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
+{
+    __shared__ float red[4][2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px_l = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    const int64_t M = (int64_t)p.NB * H * W;
+    const int64_t ntiles = (M + 31) >> 5;
+    // this lane's 16 k values: q*16 + h*8 + e  -> offsets relative to (n, c=0, oh, ow), tap coordinates, k < 27
+    int koff[16];
+    unsigned krs = 0, krs2 = 0, kval = 0;                         // (r | s << 2) in 4 bits per k: one word per K16 half; k < 27 bits
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int k = (i >> 3) * 16 + h * 8 + (i & 7);
+        int c, r, s;
+        stem_k(k < 27 ? k : 0, c, r, s);
+        koff[i] = (c * H + (r - 1)) * W + (s - 1);
+        const unsigned code = (unsigned)(r | (s << 2)) << (4 * (i & 7));
+        if (i < 8) krs |= code;
+        else krs2 |= code;
+        if (k < 27) kval |= 1u << i;
+    }
+    // weight fragments (A operand: row = output channel, k = h*8 + e): loaded once
+    bf16x8 wfrag[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (px_l < p.Cout) w = *reinterpret_cast<const uint4*>(p.wf + px_l * 32 + q * 16 + h * 8);
+        wfrag[q] = __builtin_bit_cast(bf16x8, w);
+    }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    const int HW = H * W;
+    for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+        const int64_t pix = tt * 32 + px_l;
+        const bool live = pix < M;
+        const int pp = (int)(live ? pix : 0);                     // M < 2^31 checked on the host
+        const int n = pp / HW;
+        const int rem = pp - n * HW;
+        const int oh = rem / W, ow = rem - oh * W;
+        const int base = (n * 3 * H + oh) * W + ow;
+        const unsigned rowok = (oh >= 1 ? 1u : 0u) | 2u | (oh + 1 < H ? 4u : 0u);
+        const unsigned colok = (ow >= 1 ? 1u : 0u) | 2u | (ow + 1 < W ? 4u : 0u);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            float v[8];
+            const unsigned rs = q ? krs2 : krs;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = q * 8 + e;
+                const unsigned r = (rs >> (4 * e)) & 3u, s = (rs >> (4 * e + 2)) & 3u;
+                const bool ok = live && ((kval >> i) & 1u) && ((rowok >> r) & 1u) && ((colok >> s) & 1u);
+                const float x = p.img[ok ? base + koff[i] : 0];   // unconditional load from a safe address, zeroed below
+                v[e] = ok ? x : 0.f;
+            }
+            const uint4 b = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[q], __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        }
+        // acc: column = this lane's pixel, rows = channels (e&3) + 8*(e>>2) + 4*h
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int c0 = 8 * g4 + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = acc[4 * g4 + q];
+            if (p.epi == EPI_AFFINE_ACT && c0 < p.Cout) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = act_fwd(v[q] * p.scale[c0 + q] + p.shift[c0 + q], p.act);
+            }
+            const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (live && c0 < p.Cout) *reinterpret_cast<uint2*>(p.out + pix * p.ldC + c0) = w;
+            if (p.epi == EPI_STATS && live) {
+                const float f0 = __uint_as_float(w.x << 16), f1 = __uint_as_float(w.x & 0xffff0000u);
+                const float f2 = __uint_as_float(w.y << 16), f3 = __uint_as_float(w.y & 0xffff0000u);
+                ssum[4 * g4 + 0] += f0; ssq[4 * g4 + 0] += f0 * f0;
+                ssum[4 * g4 + 1] += f1; ssq[4 * g4 + 1] += f1 * f1;
+                ssum[4 * g4 + 2] += f2; ssq[4 * g4 + 2] += f2 * f2;
+                ssum[4 * g4 + 3] += f3; ssq[4 * g4 + 3] += f3 * f3;
+            }
+        }
+    }
+    if (p.epi == EPI_STATS) {
+        // fold the 32 pixel lanes of each half-wave, then the 4 waves; one partial-statistics row per workgroup
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float a = ssum[e], b = ssq[e];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            if (px_l == 0) {
+                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                red[wave][0][c] = a;
+                red[wave][1][c] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * 32) {
+            const int c = tid & 31, which = tid >> 5;
+            if (c < p.Cout) p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- weight gradient
+__global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParams p, float* __restrict__ slabs)
+{
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    __shared__ __attribute__((aligned(1024))) unsigned char dyt[4][2][1024];     // wave-private double buffer: [16 px][32 ch] bf16
+    __shared__ float redw[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int64_t M = (int64_t)p.NB * HW;
+    const int64_t nsteps = M >> 4;                                 // W % 16 == 0: every 16-pixel run lies in one image row
+    const int h = lane >> 5, kk = lane & 31;
+    int c, r, s;
+    stem_k(kk < 27 ? kk : 0, c, r, s);
+    const bool kok = kk < 27;
+    const int koff = (c * H + (r - 1)) * W + (s - 1) + h * 8;      // this lane's 8 consecutive pixels start at ow0 + h*8 (+ s - 1)
+    // transposed-read addressing of the [16 px][32 ch] tile (see conv.hip / conv3x3.hip)
+    const int s16 = lane & 15, grp = lane >> 4;
+    const int fr_off = ((grp >> 1) * 8 + (s16 >> 2)) * 64 + (16 * (grp & 1) + 4 * (s16 & 3)) * 2;
+    const int d_row = lane >> 2, d_slot = lane & 3;                // DMA lane -> (pixel row, 16-byte slot)
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t ss = (int64_t)blockIdx.x * 4 + wave;
+    auto issue = [&](int64_t st, int buf) {
+        const bf16_t* src = p.dY + (st * 16 + d_row) * (int64_t)p.ldY + d_slot * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(&dyt[wave][buf][0]), 16, 0, 0);
+    };
+    if (ss < nsteps) issue(ss, 0);
+    int buf = 0;
+    for (; ss < nsteps; ss += stride, buf ^= 1) {
+        const int p0 = (int)(ss * 16);
+        const int n = p0 / HW;
+        const int rem = p0 - n * HW;
+        const int oh = rem / W, ow0 = rem - oh * W;
+        const int base = (n * 3 * H + oh) * W + ow0;
+        const bool rowok = kok && (unsigned)(oh + r - 1) < (unsigned)H;
+        const int iw0 = ow0 + h * 8 + s - 1;                       // column of this lane's first element
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const bool ok = rowok && (unsigned)(iw0 + e) < (unsigned)W;
+            const float x = p.img[ok ? base + koff + e : 0];
+            v[e] = ok ? x : 0.f;
+        }
+        const bool more = ss + stride < nsteps;
+        if (more) issue(ss + stride, buf ^ 1);
+        // the dY piece of THIS step was issued one iteration ago: everything but the piece just issued must have landed
+        if (more) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned char* a = &dyt[wave][buf][0] + fr_off;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
+        const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        const uint4 b = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    // acc[co][k]: column = lane & 31 = k, rows = co pattern.  Fold the 4 waves, one slab [32][32] per workgroup.
+#pragma unroll
+    for (int e = 0; e < 16; e++) redw[wave][(e & 3) + 8 * (e >> 2) + 4 * h][kk] = acc[e];
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int co = i >> 5, k = i & 31;
+        slabs[(int64_t)blockIdx.x * 1024 + i] = redw[0][co][k] + redw[1][co][k] + redw[2][co][k] + redw[3][co][k];
+    }
+}
+
+// out[g][1024] = sum of slabs g, g + G, g + 2G, ... (fixed order: deterministic); G = gridDim.x
+__global__ __launch_bounds__(1024) void stem_fold_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ out)
+{
+    const int i = threadIdx.x;                                     // (co, k) of the 32 x 32 slab
+    float s = 0.f;
+    for (int z = blockIdx.x; z < nslab; z += gridDim.x) s += slabs[(int64_t)z * 1024 + i];
+    out[(int64_t)blockIdx.x * 1024 + i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------- C ABI
+static int stem_blocks(int64_t M) { const int64_t t = ry_cdiv(M, 32 * 4 * 8); return (int)(t > 2048 ? 2048 : (t < 1 ? 1 : t)); }
+
+static bool stem_ok(int NB, int H, int W, int Cout)
+{
+    return NB > 0 && H > 0 && W > 0 && Cout > 0 && Cout <= 32 && Cout % 8 == 0 && (int64_t)NB * 3 * H * W < (1ll << 31);
+}
+
+extern "C" int ryolo_stem3x3_plan(int NB, int H, int W, int Cout, int* stats_rows, size_t* wgrad_workspace_bytes)
+{
+    if (!stem_ok(NB, H, W, Cout)) return RY_ERR_UNSUPPORTED;
+    const int nb = stem_blocks((int64_t)NB * H * W);
+    if (stats_rows) *stats_rows = nb;
+    if (wgrad_workspace_bytes) *wgrad_workspace_bytes = (size_t)(nb + 64) * 1024 * sizeof(float);
+    return RY_OK;
+}
+
+extern "C" int ryolo_stem3x3_fwd(const StemParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->img || !pp->wf || !pp->out) return RY_ERR_ARG;
+    const StemParams& p = *pp;
+    if (!stem_ok(p.NB, p.H, p.W, p.Cout) || p.ldC % 4) return RY_ERR_UNSUPPORTED;
+    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT) return RY_ERR_ARG;
+    if ((p.epi == EPI_STATS && !p.stats) || (p.epi == EPI_AFFINE_ACT && (!p.scale || !p.shift))) return RY_ERR_ARG;
+    hipLaunchKernelGGL(stem3x3_fwd_kernel, dim3((unsigned)stem_blocks((int64_t)p.NB * p.H * p.W)), dim3(256), 0, stream, p);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_stem3x3_wgrad(const StemWgradParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->img || !pp->dY || !pp->scratch || !pp->workspace) return RY_ERR_ARG;
+    const StemWgradParams& p = *pp;
+    if (!stem_ok(p.NB, p.H, p.W, p.Cout) || p.Cout != 32 || p.W % 16 || p.ldY % 8) return RY_ERR_UNSUPPORTED;
+    const int nb = stem_blocks((int64_t)p.NB * p.H * p.W);
+    hipLaunchKernelGGL(stem3x3_wgrad_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, p.workspace);
+    float* part = p.workspace + (size_t)nb * 1024;                 // two-level fold: 64 groups, then one
+    hipLaunchKernelGGL(stem_fold_kernel, dim3(64), dim3(1024), 0, stream, p.workspace, nb, part);
+    hipLaunchKernelGGL(stem_fold_kernel, dim3(1), dim3(1024), 0, stream, part, 64, p.scratch);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}

@@ -98,6 +98,7 @@ class Graph:
         self.keep = []                         # tensors/structs kept alive
         self.stream = None
         self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
+        self._img_slot, self._img_structs = None, []
         self.heads = []                        # per scale: dict(out=fp32 tensor, dout=fp32 tensor)
         self.debug = {}
         self.meta = {}                         # (tape id, index) -> (kernel class, algorithmic flops)
@@ -270,20 +271,48 @@ class Graph:
         return y, stats, backward
 
     def stem_raw(self, conv, want_stats, fused=None):
-        """First layer (Cin=3): explicit im2col of the fp32 NCHW image + single-tap GEMM (K padded to a multiple of 32)."""
+        """First layer (Cin = 3).  3x3 stride-1 stems (yolov4 / yolov7) run DIRECTLY on the fp32 NCHW image (csrc/stem.hip); other
+        shapes (yolov5's 6x6 stride 2) go through an explicit im2col + single-tap GEMM (K padded to a multiple of 32)."""
         rt = self.rt
         pk = rt.packed(conv)
         k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         OH = (self.Hin + 2 * pad - k) // s + 1
         OW = (self.Win + 2 * pad - k) // s + 1
         kp = pk["CinP"]
+        cout = conv.out_channels
+        y = fused[2] if fused else self.new(self.B, OH, OW, cout)
+        epi = S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW)
+        if (k, s, pad, conv.in_channels, cout, kp) == (3, 1, 1, 3, 32, 32) and self.Win % 16 == 0 and self.B * 3 * self.Hin * self.Win < 2 ** 31:
+            rows, wsb = S.I(), S.Z()
+            hip.call("ryolo_stem3x3_plan", self.B, self.Hin, self.Win, cout, rows, wsb)
+            p = S.StemParams()
+            p.img, p.NB, p.H, p.W = self.img.data_ptr(), self.B, self.Hin, self.Win
+            p.wf, p.Cout, p.epi, p.out, p.ldC = pk["wf"].data_ptr(), cout, epi, y.ptr(), y.ld
+            stats = None
+            if epi == S.EPI_STATS:
+                stats = self.f32(rows.value + 64, 2, cout)[:rows.value]
+                p.stats = stats.data_ptr()
+            if fused:
+                co = fused[0]
+                p.scale, p.shift, p.act = co.data_ptr() + 2 * cout * 4, co.data_ptr() + 3 * cout * 4, fused[1]
+            self._call(self.fwd, "ryolo_stem3x3_fwd", p)
+            self._img_structs.append(p)
+
+            def backward(need_dx=False):
+                scratch = self.f32(cout, kp)
+                ws = self.f32(wsb.value // 4)
+                q = S.StemWgradParams()
+                q.img, q.NB, q.H, q.W = self.img.data_ptr(), self.B, self.Hin, self.Win
+                q.dY, q.ldY, q.Cout = y.gptr(), y.ld, cout
+                q.scratch, q.workspace = scratch.data_ptr(), ws.data_ptr()
+                self._call(self.bwd, "ryolo_stem3x3_wgrad", q)
+                self._img_structs.append(q)
+                self._call(self.bwd, "ryolo_unpack_wgrad", scratch.data_ptr(), cout, 3, k * k, kp, rt.grad_ptr(conv.weight))
+            return y, stats, backward
         col = self.new(self.B, OH, OW, kp)
         self._call(self.fwd, "ryolo_im2col", self.img.data_ptr(), self.B, 3, self.Hin, self.Win, k, k, s, pad, OH, OW, kp, col.ptr())
         self._img_slot = len(self.fwd) - 1         # tape entry whose first argument (the image pointer) is patched per call
-        cout = conv.out_channels
-        y = fused[2] if fused else self.new(self.B, OH, OW, cout)
-        stats = self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)],
-                           S.EPI_AFFINE_ACT if fused else (S.EPI_STATS if want_stats else S.EPI_RAW), y.ptr(), y.ld,
+        stats = self._gemm(self.fwd, col, col.ptr(), pk["wf"], cout, 1, kp, OH, OW, 1, [([(0, 0, 0)], 0, 0)], epi, y.ptr(), y.ld,
                            coeffs=fused[0] if fused else None, act=fused[1] if fused else 0)
 
         def backward(need_dx=False):
@@ -502,8 +531,11 @@ class Graph:
 
     def set_image(self, imgs):
         """Use the caller's [B,3,S,S] fp32 tensor in place (no staging copy) when it is contiguous."""
-        fn, args, name = self.fwd[self._img_slot]
-        self.fwd[self._img_slot] = (fn, (imgs.data_ptr(),) + args[1:], name)
+        if self._img_slot is not None:
+            fn, args, name = self.fwd[self._img_slot]
+            self.fwd[self._img_slot] = (fn, (imgs.data_ptr(),) + args[1:], name)
+        for st in self._img_structs:                # direct stem: parameter blocks are passed by reference, patch them in place
+            st.img = imgs.data_ptr()
         self._img_ref = imgs                        # keep alive until the next call
 
     def set_head_grad(self, rec, grad):

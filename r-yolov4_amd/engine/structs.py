@@ -29,6 +29,15 @@ class WgradParams(C.Structure):
                 ("dW", P), ("splitk", I), ("kchunk", L), ("partial", P), ("zeros", P)]
 
 
+class StemParams(C.Structure):
+    _fields_ = [("img", P), ("NB", I), ("H", I), ("W", I), ("wf", P), ("Cout", I), ("epi", I), ("out", P), ("ldC", I), ("stats", P),
+                ("scale", P), ("shift", P), ("act", I)]
+
+
+class StemWgradParams(C.Structure):
+    _fields_ = [("img", P), ("NB", I), ("H", I), ("W", I), ("dY", P), ("ldY", I), ("Cout", I), ("scratch", P), ("workspace", P)]
+
+
 class BnActParams(C.Structure):
     _fields_ = [("y1", P), ("ld1", I), ("co1", P), ("y2", P), ("ld2", I), ("co2", P), ("res", P), ("ldr", I),
                 ("z", P), ("ldz", I), ("M", L), ("C", I), ("act", I),
@@ -65,6 +74,9 @@ for _name, _sig in {
     "ryolo_conv_wgrad": [_PTR(WgradParams), P],
     "ryolo_conv_wgrad_plan": [_PTR(WgradParams), _PTR(I), _PTR(Z)],
     "ryolo_conv_wgrad_kernel": [_PTR(WgradParams), _PTR(I)],
+    "ryolo_stem3x3_plan": [I, I, I, I, _PTR(I), _PTR(Z)],
+    "ryolo_stem3x3_fwd": [_PTR(StemParams), P],
+    "ryolo_stem3x3_wgrad": [_PTR(StemWgradParams), P],
     "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
     "ryolo_bn_eval_coeffs": [P, P, P, P, F, I, P, P],
     "ryolo_bn_act_fwd": [_PTR(BnActParams), P],
@@ -96,9 +108,9 @@ def check_layouts():
     global _checked
     if _checked:
         return
-    sizes = (I * 8)()
+    sizes = (I * 10)()
     hip.call("ryolo_struct_sizes", sizes)
-    want = [BnActParams, PoolParams, UpParams, PackEntry, ConvGemmParams, WgradParams, LossParams, TapClass]
+    want = [BnActParams, PoolParams, UpParams, PackEntry, ConvGemmParams, WgradParams, LossParams, TapClass, StemParams, StemWgradParams]
     for k, t in enumerate(want):
         if sizes[k] != C.sizeof(t):
             raise RuntimeError(f"ryolov4_amd: struct layout mismatch for {t.__name__}: C {sizes[k]} vs ctypes {C.sizeof(t)}")

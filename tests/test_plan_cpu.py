@@ -32,10 +32,13 @@ def test_plan_builds(ver, mode, nc, training):
     assert [tuple(h["out"].shape) for h in g.heads] == [(2, na, 8, 8, attrs), (2, na, 4, 4, attrs), (2, na, 2, 2, attrs)]
     nconv = sum(1 for x in m.modules() if isinstance(x, torch.nn.Conv2d))
     names = [n for _, _, n in g.fwd]
-    assert names.count("ryolo_conv_gemm") == nconv
+    direct_stem = names.count("ryolo_stem3x3_fwd")                 # 3x3 stride-1 stems (v4, v7) bypass im2col + GEMM
+    assert direct_stem == (0 if ver == "yolov5" else 1)
+    assert names.count("ryolo_conv_gemm") == nconv - direct_stem
     if training:
         bnames = [n for _, _, n in g.bwd]
-        assert bnames.count("ryolo_conv_wgrad") == nconv
+        assert bnames.count("ryolo_conv_wgrad") + bnames.count("ryolo_stem3x3_wgrad") == nconv
+        assert bnames.count("ryolo_stem3x3_wgrad") == direct_stem
         assert bnames.count("ryolo_conv_gemm") == nconv - 1          # every conv but the stem has a data gradient
         for p in m.parameters():
             assert rt.grad_view(p).shape == p.shape
