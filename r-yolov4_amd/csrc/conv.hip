@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 
     if (p.epi == EPI_F32_BIAS) {
         // small outputs (detection heads): direct fp32 stores, 4 consecutive channels per lane
+        const bool vec4 = (p.ldC & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int64_t m = m0 + wm * WTM + i * 32 + (lane & 31);
@@ -336,6 +337,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++) {
                     const int n = n0 + wn * WTN + j * 32 + 8 * g4 + 4 * h;
+                    if (vec4 && n + 3 < p.Nout) {                             // 16-byte store of the lane's 4 consecutive channels
+                        float4 v = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+                        if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
+                        *reinterpret_cast<float4*>(orow + n) = v;
+                        continue;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         if (n + q >= p.Nout) continue;

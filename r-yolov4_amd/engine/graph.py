@@ -104,6 +104,7 @@ class Graph:
         self.meta = {}                         # (tape id, index) -> (kernel class, algorithmic flops)
         self.timer = None                      # set by bench.py: per-launch HIP-event timing of the conv kernels
         self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by every weight-gradient launch (backward is serial)
+        self.grad_writes = []                  # (backward tape index, [element offsets into Runtime.gflat it writes])
 
     # ------------------------------------------------------------------ helpers
     def new(self, N, H, W, Cc):
@@ -123,6 +124,15 @@ class Graph:
         fn = getattr(hip.lib(), name)
         tape.append((fn, conv, name))
         self.meta[(id(tape), len(tape) - 1)] = self._describe(name, args)
+        if tape is self.bwd:
+            # which bytes of the flat gradient buffer this launch writes (data-parallel overlap: a bucket is reduced as soon as
+            # the last launch that touches it has been enqueued) — raw pointer arguments and the dW field of the wgrad blocks
+            lo = self.rt.gflat.data_ptr()
+            hi = lo + self.rt.gflat.numel() * 4
+            ptrs = [a for a in args if isinstance(a, int) and lo <= a < hi]
+            ptrs += [a.dW for a in args if isinstance(a, S.WgradParams) and a.dW and lo <= a.dW < hi]
+            if ptrs:
+                self.grad_writes.append((len(tape) - 1, [(q - lo) // 4 for q in ptrs]))
 
     @staticmethod
     def _describe(name, args):
@@ -148,9 +158,33 @@ class Graph:
             return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl)
         return (name, 0)
 
-    def run(self, tape, timer=None):
+    def grad_ready_points(self, bounds):
+        """For each [a, b) element range of Runtime.gflat: index of the LAST backward-tape entry that writes a gradient whose first
+        element lies in it (-1 if none does).  A gradient tensor never straddles a 64-element boundary start (slices are
+        256-byte aligned), and bucket bounds are cut at parameter starts by the caller."""
+        import bisect
+        starts = [a for a, _ in bounds]
+        last = [-1] * len(bounds)
+        for idx, offs in self.grad_writes:
+            for o in offs:
+                k = bisect.bisect_right(starts, o) - 1
+                if 0 <= k < len(bounds) and o < bounds[k][1]:
+                    last[k] = max(last[k], idx)
+        return last
+
+    def run(self, tape, timer=None, after=None):
+        """Replay a tape.  after: {tape index: callable} invoked right after that launch was enqueued (gradient-bucket hooks)."""
         st = hip.stream()
         if timer is None:
+            if after:
+                for i, (fn, args, name) in enumerate(tape):
+                    rc = fn(*args, st)
+                    if rc != 0:
+                        raise RuntimeError(f"{name} failed with code {rc}")
+                    cb = after.get(i)
+                    if cb is not None:
+                        cb()
+                return
             for fn, args, name in tape:
                 rc = fn(*args, st)
                 if rc != 0:
@@ -169,6 +203,10 @@ class Graph:
                 rc = fn(*args, st)
             if rc != 0:
                 raise RuntimeError(f"{name} failed with code {rc}")
+            if after:
+                cb = after.get(i)
+                if cb is not None:
+                    cb()
 
     # ------------------------------------------------------------------ convolution
     def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,

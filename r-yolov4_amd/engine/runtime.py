@@ -177,7 +177,9 @@ class NetFunction(torch.autograd.Function):
             else:
                 h["dout"].copy_(go)
                 g.set_head_grad(h, h["dout"])
-        g.run(g.bwd, g.timer)
-        if rt.model._grad_hook is not None:
-            rt.model._grad_hook(rt)
+        hook = rt.model._grad_hook
+        after = hook.bucket_hooks(rt, g) if hook is not None and hasattr(hook, "bucket_hooks") else None
+        g.run(g.bwd, g.timer, after)
+        if hook is not None:
+            hook(rt)
         return None, None, None, None

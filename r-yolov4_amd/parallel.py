@@ -56,11 +56,80 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class DataParallel:
-    """Wraps a ryolov4_amd Yolo: broadcasts rank-0 parameters once, all-reduces the flat gradient buffer at the end of every
-    backward (hooked inside the engine's single autograd node), and exposes `grad_scale` = 1/world for the fused SGD step."""
+class _Reducer:
+    """Gradient all-reduce overlapped with the backward tape.  The flat fp32 gradient buffer is cut into buckets at parameter
+    boundaries (~bucket_bytes each); Graph.grad_ready_points tells after which backward launch a bucket is final, and right after
+    that launch is enqueued the bucket's all-reduce is issued on a side stream behind an event — RCCL moves the tail layers'
+    gradients over xGMI while the MFMA kernels of the earlier layers still run.  __call__ (end of backward) reduces whatever no
+    launch claimed and makes the compute stream wait for the collectives."""
 
-    def __init__(self, model, bucket_bytes=64 << 20):
+    def __init__(self, bucket_bytes):
+        self.bucket_bytes = bucket_bytes
+        self.bounds = None
+        self.plans = {}
+        self.works = []
+        self.done = set()
+        self.side = None
+
+    def _bounds(self, rt):
+        if self.bounds is None:
+            target = max(1, self.bucket_bytes // 4)
+            starts = sorted(v[0] for v in rt._pslice.values())        # parameter start offsets in the flat buffers
+            cuts, last = [0], 0
+            n = rt.gflat.numel()
+            for o in starts:
+                if o - last >= target:
+                    cuts.append(o)
+                    last = o
+            cuts.append(n)
+            self.bounds = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        return self.bounds
+
+    def _launch(self, rt, k):
+        if k in self.done:
+            return
+        self.done.add(k)
+        a, b = self.bounds[k]
+        view = rt.gflat[a:b]
+        if view.is_cuda:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=view.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(view.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+
+    def bucket_hooks(self, rt, g):
+        """{backward tape index: callable} for Graph.run."""
+        self.works, self.done = [], set()
+        bounds = self._bounds(rt)
+        plan = self.plans.get(id(g))
+        if plan is None:
+            ready = g.grad_ready_points(bounds)
+            plan = {}
+            for k, idx in enumerate(ready):
+                if idx >= 0:
+                    plan.setdefault(idx, []).append(k)
+            self.plans[id(g)] = plan
+        return {idx: (lambda ks=ks: [self._launch(rt, k) for k in ks]) for idx, ks in plan.items()}
+
+    def __call__(self, rt):
+        for k in range(len(self._bounds(rt))):
+            self._launch(rt, k)
+        for w in self.works:
+            w.wait()                                   # the current (compute) stream waits for the collective
+        self.works = []
+
+
+class DataParallel:
+    """Wraps a ryolov4_amd Yolo: broadcasts rank-0 parameters once, all-reduces the flat gradient buffer in ~25 MB buckets
+    overlapped with the backward tape (overlap=False: one pass at the end of backward), and exposes `grad_scale` = 1/world for
+    the fused SGD step."""
+
+    def __init__(self, model, bucket_bytes=25 << 20, overlap=True):
         self.model = model
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
@@ -70,7 +139,9 @@ class DataParallel:
             for b in model.buffers():
                 if b.dtype.is_floating_point:
                     dist.broadcast(b, src=0)
-        model._grad_hook = self._reduce
+        self.overlap = overlap
+        self._reducer = _Reducer(bucket_bytes)
+        model._grad_hook = (self._reducer if overlap else self._reduce) if self.world > 1 else None
         self.grad_scale = 1.0 / self.world
 
     def _reduce(self, rt):

@@ -57,3 +57,78 @@ def test_shard_and_buckets():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     assert parallel.bucket_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
     assert parallel.bucket_bounds(0, 4) == []
+
+
+def test_bucket_ready_points_cover_every_gradient():
+    """Plan built on CPU (no launches): every parameter's gradient is written by some backward launch, and the bucket that holds
+    it becomes ready no earlier than that launch; the tail layers' buckets are ready long before the first layers' (that window is
+    what the overlapped all-reduce uses)."""
+    from ryolov4_amd import parallel
+    from ryolov4_amd.engine.runtime import Runtime
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG
+    m = Yolo(16, CFG, "kfiou", "yolov7")
+    m.train()
+    rt = Runtime(m, torch.device("cpu"))
+    g = rt.graph(2, 64, 64, True)
+    red = parallel._Reducer(bucket_bytes=8 << 20)
+    bounds = red._bounds(rt)
+    assert bounds[0][0] == 0 and bounds[-1][1] == rt.gflat.numel() and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert len(bounds) >= 8
+    ready = g.grad_ready_points(bounds)
+    assert min(ready) >= 0
+    written = {}
+    for idx, offs in g.grad_writes:
+        for o in offs:
+            written[o] = max(written.get(o, -1), idx)
+    starts = sorted(v[0] for v in rt._pslice.values())
+    assert set(starts) <= set(written), "a parameter gradient that no backward launch writes"
+    for o, idx in written.items():
+        k = max(i for i, (a, _) in enumerate(bounds) if a <= o)
+        assert ready[k] >= idx
+    assert ready[-1] < ready[0], "last layers' gradients are final before the first layers'"
+    assert ready[-1] < len(g.bwd) // 2
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ryolov4_amd import parallel
+    parallel.init_from_env(backend="gloo")
+
+    class RT:                                                     # the two attributes the reducer reads
+        gflat = torch.arange(5000, dtype=torch.float32) * (rank + 1)
+        _pslice = {i: (o, 10, None) for i, o in enumerate(range(0, 5000, 64))}
+
+    class G:
+        grad_writes = [(3, [4992]), (7, [2048, 1024]), (9, [0])]
+
+        def grad_ready_points(self, bounds):
+            from ryolov4_amd.engine.graph import Graph
+            return Graph.grad_ready_points(self, bounds)
+
+    red = parallel._Reducer(bucket_bytes=4096)                    # 1024-float buckets cut at parameter starts
+    hooks = red.bucket_hooks(RT, G())
+    fired = []
+    for i in range(12):                                           # stand-in for Graph.run
+        if i in hooks:
+            hooks[i]()
+            fired.append(i)
+    red(RT)                                                       # end of backward: unclaimed buckets + wait
+    expect = torch.arange(5000, dtype=torch.float32) * sum(range(1, world + 1))
+    q.put((rank, torch.equal(RT.gflat, expect), fired, len(red.bounds)))
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for _, ok, fired, nb in res:
+        assert ok and fired == [3, 7, 9] and nb == 5
