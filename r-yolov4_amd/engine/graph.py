@@ -105,6 +105,8 @@ class Graph:
         self.timer = None                      # set by bench.py: per-launch HIP-event timing of the conv kernels
         self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by every weight-gradient launch (backward is serial)
         self.grad_writes = []                  # (backward tape index, [element offsets into Runtime.gflat it writes])
+        self.wprep = []                        # launches that depend on the weights only (eval-mode BN folding); run before fwd
+        self.static_weights = False            # True while a captured inference graph is recorded: pack + wprep already done
 
     # ------------------------------------------------------------------ helpers
     def new(self, N, H, W, Cc):
@@ -377,7 +379,8 @@ class Graph:
         if not train and residual is None:
             # inference: BatchNorm folded to scale/shift (running statistics) + activation inside the GEMM epilogue
             co = self.f32(4, cout)
-            self._call(self.fwd, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+            # folded scale/shift depend on the weights only: their own tape, so a captured inference graph can leave them out
+            self._call(self.wprep, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                        bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
             k_, s_, pad_ = conv.kernel_size[0], conv.stride[0], conv.padding[0]
             H_, W_ = (self.Hin, self.Win) if stem else (x.H, x.W)

@@ -157,7 +157,10 @@ class NetFunction(torch.autograd.Function):
         else:
             g.img.copy_(imgs)
             g.set_image(g.img)
-        rt.pack()
+        if not g.static_weights:
+            rt.pack()
+            if g.wprep:
+                g.run(g.wprep)
         g.run(g.fwd, g.timer)
         if g.batch_stats:
             rt.nbt += 1

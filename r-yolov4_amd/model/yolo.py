@@ -297,5 +297,41 @@ class Yolo(nn.Module):
         return self.yolo(list(outs), training)
 
 
+    def capture_inference(self, batch, size, device=None, static_weights=True):
+        """hipGraph-captured inference (BASELINE config C5): the eval forward tape (≈330 C-ABI launches: folded BN + activation
+        GEMMs, pooling, heads) and the YoloLayer decode are captured ONCE into a hipGraph on static buffers; the returned callable
+        copies a batch into the static input and replays the graph — one host call instead of hundreds, which is what batch-1
+        latency is made of.  Returns fn(imgs[B,3,S,S]) -> (head maps list, detections [B, rows, nc+6]); the outputs are the
+        graph's static buffers (valid until the next call).  post_process stays outside (its row counts are data dependent).
+        static_weights: the fp32 -> bf16 weight repack and the folded-BN coefficient kernels (weights-only work, ≈100 launches) are
+        left out of the graph; re-capture after changing the weights."""
+        if self.training:
+            raise RuntimeError("capture_inference: call .eval() first")
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        static_in = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                                   # eager warm-up: plan build, lazy kernel attributes, allocator pools
+                self(static_in, False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        g = self.runtime(dev).graph(batch, size, size, False)
+        g.static_weights = static_weights                        # bf16 weight images and folded BN coefficients are already in place
+        try:
+            with torch.cuda.graph(graph), torch.no_grad():
+                heads, infer = self(static_in, False)
+        finally:
+            g.static_weights = False
+
+        def run(imgs):
+            static_in.copy_(imgs)
+            graph.replay()
+            return heads, infer
+        run.graph, run.static_input = graph, static_in
+        return run
+
+
 class _NoCtx:
     pass

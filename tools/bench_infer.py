@@ -45,8 +45,24 @@ for B in [int(b) for b in os.environ.get("B", "1,8,64").split(",")]:
 
     n = max(5, 200 // B)
     t_f, t_a = timed(fwd, n), timed(full, n)
+    cap = model.capture_inference(B, SZ)                      # hipGraph replay of forward + decode
+
+    def gfwd():
+        return cap(imgs)
+
+    def gfull():
+        _, inf = cap(imgs)
+        return post_process(inf, 0.25, 0.45)
+    with torch.no_grad():
+        ref_h, ref_inf = model(imgs, training=False)
+        ref_inf = ref_inf.clone()
+        _, got_inf = cap(imgs)
+        assert torch.equal(ref_inf, got_inf), "graph replay differs from the eager forward"
+    t_gf, t_ga = timed(gfwd, n), timed(gfull, n)
     out[f"b{B}"] = {"fwd_ms": round(t_f, 3), "fwd_img_s": round(B / t_f * 1e3, 1), "fwd_pp_ms": round(t_a, 3),
-                    "fwd_pp_img_s": round(B / t_a * 1e3, 1)}
+                    "fwd_pp_img_s": round(B / t_a * 1e3, 1),
+                    "graph_fwd_ms": round(t_gf, 3), "graph_fwd_img_s": round(B / t_gf * 1e3, 1), "graph_fwd_pp_ms": round(t_ga, 3),
+                    "graph_fwd_pp_img_s": round(B / t_ga * 1e3, 1)}
     print(B, out[f"b{B}"], flush=True)
     del model
 os.makedirs("gpurun_out", exist_ok=True)
