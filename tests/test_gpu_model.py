@@ -165,3 +165,22 @@ def test_loss_golden(golden_dir, mode, nc):
         with torch.no_grad():
             l2, it2 = crit([o.detach() for o in outs], tg)
         assert abs(it2["total_loss"] - items["total_loss"]) < 1e-6 * max(1.0, abs(items["total_loss"]))
+
+
+@pytest.mark.gpu
+def test_captured_inference_replay_matches_eager():
+    """hipGraph capture of forward + decode (BASELINE config C5): replays on new inputs equal the eager path bit for bit."""
+    import torch
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, fill_state
+    m = Yolo(16, CFG, "kfiou", "yolov7")
+    m.load_state_dict(fill_state(m.state_dict()))
+    m.cuda().eval()
+    run = m.capture_inference(2, 128)
+    for seed in (1, 2):
+        x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(seed)).cuda()
+        with torch.no_grad():
+            _, ref = m(x, False)
+            ref = ref.clone()
+        _, got = run(x)
+        assert torch.equal(ref, got)
