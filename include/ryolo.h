@@ -152,9 +152,11 @@ int ryolo_im2col(const float* img, int NB, int Cin, int H, int W, int kh, int kw
 /* detection head tail: pre [M][ldp] fp32 (conv + bias) [* ImplicitM] -> [B, na, gs, gs, attrs] (yololayer.py:25 fused) */
 int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
                           ryolo_stream_t stream);
-/* scratch >= B*na*ceil(gs*gs/64)*attrs floats; dpre pad columns (>= na*attrs) must be pre-zeroed by the caller */
+/* backward of the head tail: dpre (bf16 GEMM operand), and ACCUMULATED into dbias (conv bias gradient = column sums of dpre, may be
+ * null) and dmul (ImplicitM gradient, with mul).  scratch >= (B*ceil(gs*gs/128) + 64) * 2*na*attrs floats; dpre pad columns
+ * (>= na*attrs) must be pre-zeroed by the caller */
 int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
-                          bf16_t* dpre, int ldd, float* dmul, float* scratch, ryolo_stream_t stream);
+                          bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
 /* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= ceil(M/1024)*C floats */
 int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);

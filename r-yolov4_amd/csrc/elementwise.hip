@@ -504,68 +504,52 @@ __global__ void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, c
     out[i] = v;
 }
 
-// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand; columns >= na*attrs stay zero from allocation)
-// and, with ImplicitM, per-workgroup partial sums of dout*pre.  One workgroup = (image, anchor, 64 cells): the dout slab
-// it reads is ONE contiguous run of 64*attrs floats; dpre/pre rows are attrs-float segments.
+// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand; columns >= na*attrs stay zero from allocation),
+// per-workgroup partial column sums of dpre (= bias gradient) and, with ImplicitM, of dout*pre.
+// One workgroup = one image x HEAD_CPB cells x ALL anchors; a thread owns output channels ch = tid, tid + 256, ... and walks the
+// cells: dpre / pre rows are written / read as whole contiguous rows (the first version gave every anchor its own workgroup: 44-byte
+// pieces of an 832-byte row from 18 different workgroups, plus an LDS float atomic per element), the dout runs of one anchor are
+// contiguous (cells x attrs floats), and the column sums need no cross-thread reduction at all.
+#define HEAD_CPB 128
 __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, int ldp,
                                                               const float* __restrict__ mul, int B, int gs, int na, int attrs,
-                                                              bf16_t* __restrict__ dpre, int ldd, float* __restrict__ dmul_partial,
-                                                              int cells_per_block)
+                                                              bf16_t* __restrict__ dpre, int ldd, float* __restrict__ partial /*[nblk][2][C]*/)
 {
-    extern __shared__ float sacc[];                       // [attrs] partial sums of dout*pre
-    const int cells = gs * gs;
-    const int ncb = (cells + cells_per_block - 1) / cells_per_block;
-    const int cb = blockIdx.x % ncb;
-    const int ba = blockIdx.x / ncb;                      // b*na + a
-    const int a = ba % na, b = ba / na;
-    const int c0 = cb * cells_per_block;
-    const int ncell = min(cells_per_block, cells - c0);
-    if (mul) { for (int i = threadIdx.x; i < attrs; i += 256) sacc[i] = 0.f; __syncthreads(); }
-    const float* src = dout + ((int64_t)ba * cells + c0) * attrs;
-    const int total = ncell * attrs;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int cell = i / attrs, at = i - cell * attrs;
-        const int ch = a * attrs + at;
-        const int64_t m = (int64_t)b * cells + c0 + cell;
-        const float d = src[i];
-        float g = d;
-        if (mul) { atomicAdd(&sacc[at], d * pre[m * ldp + ch]); g = d * mul[ch]; }
-        dpre[m * ldd + ch] = f2bf(g);
-    }
-    if (mul) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < attrs; i += 256) dmul_partial[(int64_t)blockIdx.x * attrs + i] = sacc[i];
-    }
-}
-
-// dmul[a*attrs + at] += sum over (b, cell block) of partial[((b*na + a)*ncb + cb)*attrs + at].
-// One workgroup per anchor: 256 threads = 32 attr lanes x 8 row lanes, LDS tree over the row lanes, double accumulation.
-__global__ __launch_bounds__(256) void head_dmul_reduce_kernel(const float* __restrict__ partial, int B, int na, int ncb, int attrs,
-                                                               float* __restrict__ dmul)
-{
-    __shared__ double red[8][32];
-    const int a = blockIdx.x;
-    const int al = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int nrows = B * ncb;
-    for (int a0 = 0; a0 < attrs; a0 += 32) {
-        const int at = a0 + al;
-        double s = 0.0;
-        if (at < attrs)
-            for (int r = rl; r < nrows; r += 8) {
-                const int b = r / ncb, cb = r - b * ncb;
-                s += (double)partial[(((int64_t)b * na + a) * ncb + cb) * attrs + at];
-            }
-        __syncthreads();
-        red[rl][al] = s;
-        __syncthreads();
-        if (rl == 0 && at < attrs) {
-            for (int k = 1; k < 8; k++) s += red[k][al];
-            dmul[a * attrs + at] += (float)s;
+    const int cells = gs * gs, C = na * attrs;
+    const int ncb = (cells + HEAD_CPB - 1) / HEAD_CPB;
+    const int b = blockIdx.x / ncb, cb = blockIdx.x - b * ncb;
+    const int c0 = cb * HEAD_CPB;
+    const int ncell = min(HEAD_CPB, cells - c0);
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const int a = ch / attrs, at = ch - a * attrs;
+        const float* src = dout + (((int64_t)b * na + a) * cells + c0) * attrs + at;
+        const int64_t m0 = (int64_t)b * cells + c0;
+        const float mv = mul ? mul[ch] : 1.f;
+        float sb = 0.f, sm = 0.f;
+        for (int cell = 0; cell < ncell; cell++) {
+            const float d = src[(int64_t)cell * attrs];
+            const bf16_t g = f2bf(d * mv);
+            dpre[(m0 + cell) * ldd + ch] = g;
+            sb += bf2f(g);                                      // bias gradient = column sum of the bf16 operand the wgrad GEMM reads
+            if (mul) sm += d * pre[(m0 + cell) * ldp + ch];
         }
+        partial[((int64_t)blockIdx.x * 2 + 0) * C + ch] = sb;
+        partial[((int64_t)blockIdx.x * 2 + 1) * C + ch] = sm;
     }
 }
 
-// out[c] += sum_r partial[r][c]
+// out0[c] += sum_r partial[r][0][c];  out1[c] += sum_r partial[r][1][c]   (rows already folded to <= 256; double accumulation)
+__global__ void head_grad_rows_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out0, float* __restrict__ out1)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    float* out = c < C ? out0 : out1;
+    if (!out) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; r++) s += (double)partial[(int64_t)r * 2 * C + c];
+    out[c < C ? c : c - C] += (float)s;
+}
+
 __global__ void colsum_rows_kernel(const float* __restrict__ partial, int rows, int C, int Cvalid, float* __restrict__ out)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -878,20 +862,19 @@ extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul
     return RY_OK;
 }
 
-// dmul (ImplicitM grad, may be null) is accumulated; scratch needs B*na*ceil(gs*gs/64)*attrs floats; dpre columns
-// >= na*attrs must have been zeroed once by the caller (they are never written)
+// dbias (conv bias gradient) and dmul (ImplicitM gradient, with mul) are ACCUMULATED; scratch needs
+// (B*ceil(gs*gs/128) + 64) * 2 * na*attrs floats; dpre columns >= na*attrs must have been zeroed once by the caller
 extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
-                                     bf16_t* dpre, int ldd, float* dmul, float* scratch, hipStream_t stream)
+                                     bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, hipStream_t stream)
 {
-    if (!dout || !pre || !dpre || (mul && (!dmul || !scratch))) return RY_ERR_ARG;
+    if (!dout || !pre || !dpre || !scratch || (mul && !dmul)) return RY_ERR_ARG;
     if ((int64_t)B * gs * gs == 0) return RY_OK;
-    const int cpb = 64;
-    const int ncb = (int)ry_cdiv((int64_t)gs * gs, cpb);
-    const int nblk = B * na * ncb;
-    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(nblk), dim3(256), mul ? attrs * sizeof(float) : 0, stream, dout, pre, ldp, mul, B, gs, na,
-                       attrs, dpre, ldd, mul ? scratch : nullptr, cpb);
-    if (mul)
-        hipLaunchKernelGGL(head_dmul_reduce_kernel, dim3(na), dim3(256), 0, stream, scratch, B, na, ncb, attrs, dmul);
+    const int C = na * attrs;
+    const int ncb = (int)ry_cdiv((int64_t)gs * gs, HEAD_CPB);
+    int rows = B * ncb;
+    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(rows), dim3(256), 0, stream, dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd, scratch);
+    const float* part = fold_rows(scratch, rows, 2 * C, scratch + (int64_t)rows * 2 * C, stream);
+    hipLaunchKernelGGL(head_grad_rows_kernel, dim3((unsigned)ry_cdiv(2 * C, 256)), dim3(256), 0, stream, part, rows, C, dbias, mul ? dmul : nullptr);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -545,18 +545,19 @@ class Graph:
             rec["dout"] = dout
             dpre = torch.zeros((M, coutp), dtype=BF16, device=self.dev)       # pad columns stay zero
             self.keep.append(dpre)
-            nblk = x.N * na * ((x.H * x.W + 63) // 64)
-            scratch = self.f32(max(nblk * attrs, ((M + 1023) // 1024) * max(coutp, x.C)))
+            nblk = x.N * ((x.H * x.W + 127) // 128)
+            scratch = self.f32(max((nblk + 64) * 2 * cout, ((M + 1023) // 1024) * max(coutp, x.C)))
 
             class _G:                      # geometry shim so dpre can be used as a gathered operand
                 N, H, W, ld = x.N, x.H, x.W, coutp
                 span_bytes = M * coutp * 2
 
             def backward():
+                # dpre, the conv bias gradient (column sums of dpre) and the ImplicitM gradient in one pass over dout
                 self._call(self.bwd, "ryolo_head_finish_bwd", dout.data_ptr(), pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs,
-                           dpre.data_ptr(), coutp, rt.grad_ptr(implicit_m) if implicit_m is not None else None, scratch.data_ptr())
+                           dpre.data_ptr(), coutp, rt.grad_ptr(conv.bias), rt.grad_ptr(implicit_m) if implicit_m is not None else None,
+                           scratch.data_ptr())
                 rec["dout_slot"] = len(self.bwd) - 1   # first argument (dout pointer) is patched per call when the caller's grad is usable as is
-                self._call(self.bwd, "ryolo_colsum_bf16", dpre.data_ptr(), coutp, M, coutp, cout, rt.grad_ptr(conv.bias), scratch.data_ptr())
                 self._wgrad(conv, _G, dpre.data_ptr(), coutp, xin)
                 self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, xin)
                 if implicit_a is not None:

@@ -88,7 +88,7 @@ for _name, _sig in {
     "ryolo_upsample2x_bwd": [_PTR(UpParams), P],
     "ryolo_im2col": [P, I, I, I, I, I, I, I, I, I, I, I, P, P],
     "ryolo_head_finish_fwd": [P, I, P, I, I, I, I, P, P],
-    "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P],
+    "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P, P],
     "ryolo_chan_add": [P, I, P, L, I, P, I, P],
     "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],
