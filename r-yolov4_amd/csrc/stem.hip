@@ -14,6 +14,7 @@
 //             consecutive floats of an image row: plain loads, no LDS.  Per-workgroup slab -> small deterministic fold.
 // Both are memory streams (0.5 + 2.6 GB each); nothing here is worth an LDS tile.
 #include "conv_internal.h"
+#include <type_traits>
 
 // k -> (channel, row tap, column tap) of the im2col ordering k = (r*3 + s)*3 + c
 __device__ __forceinline__ void stem_k(int k, int& c, int& r, int& s)
@@ -27,24 +28,29 @@ __device__ __forceinline__ void stem_k(int k, int& c, int& r, int& s)
 __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
 {
     __shared__ float red[4][2][32];
+    __shared__ __attribute__((aligned(16))) bf16_t otile[4][32][40];   // per wave: 32 pixels x 32 channels (+8 pad), 80-byte rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px_l = lane & 31, h = lane >> 5;
     const int H = p.H, W = p.W;
     const int64_t M = (int64_t)p.NB * H * W;
     const int64_t ntiles = (M + 31) >> 5;
-    // this lane's 16 k values: q*16 + h*8 + e  -> offsets relative to (n, c=0, oh, ow), tap coordinates, k < 27
+    // this lane's 16 k values: q*16 + h*8 + e  -> offsets relative to (n, c=0, oh, ow); validity is a 16-bit mask per tile built
+    // from four per-lane constants: which of the 16 k use the top / bottom row tap and the left / right column tap
     int koff[16];
-    unsigned krs = 0, krs2 = 0, kval = 0;                         // (r | s << 2) in 4 bits per k: one word per K16 half; k < 27 bits
+    unsigned kval = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int k = (i >> 3) * 16 + h * 8 + (i & 7);
         int c, r, s;
         stem_k(k < 27 ? k : 0, c, r, s);
         koff[i] = (c * H + (r - 1)) * W + (s - 1);
-        const unsigned code = (unsigned)(r | (s << 2)) << (4 * (i & 7));
-        if (i < 8) krs |= code;
-        else krs2 |= code;
-        if (k < 27) kval |= 1u << i;
+        if (k < 27) {
+            kval |= 1u << i;
+            if (r == 0) m_top |= 1u << i;
+            if (r == 2) m_bot |= 1u << i;
+            if (s == 0) m_left |= 1u << i;
+            if (s == 2) m_right |= 1u << i;
+        }
     }
     // weight fragments (A operand: row = output channel, k = h*8 + e): loaded once
     bf16x8 wfrag[2];
@@ -59,28 +65,40 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
     for (int e = 0; e < 16; e++) { ssum[e] = 0.f; ssq[e] = 0.f; }
 
     const int HW = H * W;
+    const bool aligned = (W & 31) == 0;                          // a 32-pixel tile never leaves its image row: (n, oh, ow0) are wave-uniform
     for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
         const int64_t pix = tt * 32 + px_l;
         const bool live = pix < M;
-        const int pp = (int)(live ? pix : 0);                     // M < 2^31 checked on the host
-        const int n = pp / HW;
-        const int rem = pp - n * HW;
-        const int oh = rem / W, ow = rem - oh * W;
+        int n, oh, ow;
+        if (aligned) {
+            const int t0 = __builtin_amdgcn_readfirstlane((int)(tt * 32 < M ? tt * 32 : 0));      // scalar divisions, once per tile
+            n = t0 / HW;
+            const int rem = t0 - n * HW;
+            oh = rem / W;
+            ow = rem - oh * W + px_l;
+        } else {
+            const int pp = (int)(live ? pix : 0);                 // M < 2^31 checked on the host
+            n = pp / HW;
+            const int rem = pp - n * HW;
+            oh = rem / W;
+            ow = rem - oh * W;
+        }
         const int base = (n * 3 * H + oh) * W + ow;
-        const unsigned rowok = (oh >= 1 ? 1u : 0u) | 2u | (oh + 1 < H ? 4u : 0u);
-        const unsigned colok = (ow >= 1 ? 1u : 0u) | 2u | (ow + 1 < W ? 4u : 0u);
+        unsigned okm = live ? kval : 0u;
+        if (oh < 1) okm &= ~m_top;
+        if (oh + 1 >= H) okm &= ~m_bot;
+        if (ow < 1) okm &= ~m_left;
+        if (ow + 1 >= W) okm &= ~m_right;
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[e] = 0.f;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             float v[8];
-            const unsigned rs = q ? krs2 : krs;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int i = q * 8 + e;
-                const unsigned r = (rs >> (4 * e)) & 3u, s = (rs >> (4 * e + 2)) & 3u;
-                const bool ok = live && ((kval >> i) & 1u) && ((rowok >> r) & 1u) && ((colok >> s) & 1u);
+                const bool ok = (okm >> i) & 1u;
                 const float x = p.img[ok ? base + koff[i] : 0];   // unconditional load from a safe address, zeroed below
                 v[e] = ok ? x : 0.f;
             }
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
                 for (int q = 0; q < 4; q++) v[q] = act_fwd(v[q] * p.scale[c0 + q] + p.shift[c0 + q], p.act);
             }
             const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            if (live && c0 < p.Cout) *reinterpret_cast<uint2*>(p.out + pix * p.ldC + c0) = w;
+            *reinterpret_cast<uint2*>(&otile[wave][px_l][c0]) = w;             // staged: the lane's 8-byte piece of its pixel row
             if (p.epi == EPI_STATS && live) {
                 const float f0 = __uint_as_float(w.x << 16), f1 = __uint_as_float(w.x & 0xffff0000u);
                 const float f2 = __uint_as_float(w.y << 16), f3 = __uint_as_float(w.y & 0xffff0000u);
@@ -108,6 +126,15 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
                 ssum[4 * g4 + 2] += f2; ssq[4 * g4 + 2] += f2 * f2;
                 ssum[4 * g4 + 3] += f3; ssq[4 * g4 + 3] += f3 * f3;
             }
+        }
+        // whole pixel rows to HBM: lane -> (pixel = lane >> 2 (+16), 16-byte slot = lane & 3); one instruction = 16 rows x 64 B.
+        // (direct 8-byte stores from the MFMA layout touched 32 rows per instruction, 16 B each: request-rate bound)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int pr = half * 16 + (lane >> 2), sl = lane & 3;
+            const int64_t opix = tt * 32 + pr;
+            const uint4 o = *reinterpret_cast<const uint4*>(&otile[wave][pr][sl * 8]);
+            if (opix < M && sl * 8 < p.Cout) *reinterpret_cast<uint4*>(p.out + opix * p.ldC + sl * 8) = o;
         }
     }
     if (p.epi == EPI_STATS) {
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParam
 {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    __shared__ __attribute__((aligned(1024))) unsigned char dyt[4][2][1024];     // wave-private double buffer: [16 px][32 ch] bf16
+    __shared__ __attribute__((aligned(1024))) unsigned char dyt[4][4][1024];     // wave-private: 4 pieces of [16 px][32 ch] bf16
     __shared__ float redw[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W;
@@ -161,38 +188,74 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParam
 
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t ss = (int64_t)blockIdx.x * 4 + wave;
-    auto issue = [&](int64_t st, int buf) {
-        const bf16_t* src = p.dY + (st * 16 + d_row) * (int64_t)p.ldY + d_slot * 8;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(&dyt[wave][buf][0]), 16, 0, 0);
-    };
-    if (ss < nsteps) issue(ss, 0);
-    int buf = 0;
-    for (; ss < nsteps; ss += stride, buf ^= 1) {
-        const int p0 = (int)(ss * 16);
-        const int n = p0 / HW;
-        const int rem = p0 - n * HW;
-        const int oh = rem / W, ow0 = rem - oh * W;
-        const int base = (n * 3 * H + oh) * W + ow0;
-        const bool rowok = kok && (unsigned)(oh + r - 1) < (unsigned)H;
-        const int iw0 = ow0 + h * 8 + s - 1;                       // column of this lane's first element
-        float v[8];
+    // Four 16-pixel steps per iteration: their 4 dY pieces (LDS-DMA) and 4 x 8 image values (registers) are all issued up front and
+    // waited for ONCE, so a memory round trip is paid per 4 MFMAs instead of per MFMA; occupancy (8 waves / SIMD) overlaps the rest.
+    // (A one-step-ahead software pipeline was defeated by hipcc's waitcnt pass: across the loop back-edge it drains vmcnt to 0.)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int64_t img_elems = (int64_t)p.NB * 3 * HW;
+    constexpr int UNR = 4;
+    // (n, oh, ow0) of the wave's current step, advanced by `stride` steps with carries (no division in the loop)
+    int cn, coh, cow;
+    {
+        const int64_t p0 = (ss < nsteps ? ss : 0) * 16;
+        cn = (int)(p0 / HW);
+        const int rem = (int)(p0 - (int64_t)cn * HW);
+        coh = rem / W;
+        cow = rem - coh * W;
+    }
+    const int64_t adv = stride * 16;                               // pixels per advance
+    const int adv_n = (int)(adv / HW), adv_r = (int)(adv - (int64_t)adv_n * HW);
+    const int adv_h = adv_r / W, adv_w = adv_r - adv_h * W;
+    for (; ss < nsteps; ss += UNR * stride) {
+        float v[UNR][8];
+        unsigned okm[UNR];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const bool ok = rowok && (unsigned)(iw0 + e) < (unsigned)W;
-            const float x = p.img[ok ? base + koff + e : 0];
-            v[e] = ok ? x : 0.f;
+        for (int u = 0; u < UNR; u++) {
+            const int64_t st = ss + u * stride;
+            const bool live = st < nsteps;
+            const bf16_t* src = live ? p.dY + (st * 16 + d_row) * (int64_t)p.ldY + d_slot * 8 : p.dY;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(&dyt[wave][u][0]), 16, 0, 0);
+            const int base = (cn * 3 * H + coh) * W + cow;
+            const bool rowok = live && kok && (unsigned)(coh + r - 1) < (unsigned)H;
+            const int iw0 = cow + h * 8 + s - 1;                   // column of this lane's first element
+            // only the first / last element of a row run can fall outside: two compares instead of eight
+            unsigned m = rowok ? 0xffu : 0u;
+            if (iw0 < 0) m &= ~1u;
+            if (iw0 + 7 >= W) m &= ~0x80u;
+            // 8 consecutive floats of one image row: two unaligned 16-byte loads (one request per 16 B instead of per 4 B — the
+            // scalar version was bound by the number of cache lines touched per instruction); the run may start one float before
+            // the row (left tap) or end one after it (right tap): only at the very ends of the whole image buffer is that outside
+            // the allocation, there the lane falls back to masked scalar loads
+            const int64_t off = (int64_t)base + koff;
+            if (m && off >= 0 && off + 8 <= img_elems) {
+                const f4u lo4 = *reinterpret_cast<const f4u*>(p.img + off), hi4 = *reinterpret_cast<const f4u*>(p.img + off + 4);
+                v[u][0] = lo4.x; v[u][1] = lo4.y; v[u][2] = lo4.z; v[u][3] = lo4.w;
+                v[u][4] = hi4.x; v[u][5] = hi4.y; v[u][6] = hi4.z; v[u][7] = hi4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[u][e] = p.img[(m >> e) & 1u ? off + e : 0];
+            }
+            okm[u] = m;
+            // advance to the wave's next step
+            cow += adv_w;
+            coh += adv_h;
+            cn += adv_n;
+            if (cow >= W) { cow -= W; coh++; }
+            if (coh >= H) { coh -= H; cn++; }
         }
-        const bool more = ss + stride < nsteps;
-        if (more) issue(ss + stride, buf ^ 1);
-        // the dY piece of THIS step was issued one iteration ago: everything but the piece just issued must have landed
-        if (more) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned char* a = &dyt[wave][buf][0] + fr_off;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
-        const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        const uint4 b = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const unsigned char* a = &dyt[wave][u][0] + fr_off;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = (okm[u] >> e) & 1u ? v[u][e] : 0.f;   // dead steps: mask 0 -> contribute nothing
+            const uint4 b = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        }
     }
     // acc[co][k]: column = lane & 31 = k, rows = co pattern.  Fold the 4 waves, one slab [32][32] per workgroup.
 #pragma unroll
@@ -234,7 +297,7 @@ extern "C" int ryolo_stem3x3_fwd(const StemParams* pp, hipStream_t stream)
 {
     if (!pp || !pp->img || !pp->wf || !pp->out) return RY_ERR_ARG;
     const StemParams& p = *pp;
-    if (!stem_ok(p.NB, p.H, p.W, p.Cout) || p.ldC % 4) return RY_ERR_UNSUPPORTED;
+    if (!stem_ok(p.NB, p.H, p.W, p.Cout) || p.ldC % 8 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return RY_ERR_UNSUPPORTED;
     if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT) return RY_ERR_ARG;
     if ((p.epi == EPI_STATS && !p.stats) || (p.epi == EPI_AFFINE_ACT && (!p.scale || !p.shift))) return RY_ERR_ARG;
     hipLaunchKernelGGL(stem3x3_fwd_kernel, dim3((unsigned)stem_blocks((int64_t)p.NB * p.H * p.W)), dim3(256), 0, stream, p);
