@@ -487,21 +487,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 
 // ------------------------------------------------------------------------------------------------ head finish / implicit
 // pre [M][ldp] fp32 (head conv + bias) -> out [B, na, gs, gs, attrs] fp32, times ImplicitM (mul may be null)
-__global__ void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs, int na,
-                                       int attrs, float* __restrict__ out)
+// One workgroup = one image x 128 cells x all anchors, a thread owns channels ch = tid, tid + 256, ...: pre rows are read whole and
+// contiguous, the outputs of one anchor are contiguous runs of cells x attrs floats; no index division per element.
+__global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs,
+                                                              int na, int attrs, float* __restrict__ out)
 {
-    const int64_t total = (int64_t)B * na * gs * gs * attrs;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int at = (int)(i % attrs);
-    const int64_t r = i / attrs;
-    const int cell = (int)(r % (gs * gs));
-    const int a = (int)((r / (gs * gs)) % na);
-    const int b = (int)(r / ((int64_t)gs * gs * na));
-    const int ch = a * attrs + at;
-    float v = pre[((int64_t)b * gs * gs + cell) * ldp + ch];
-    if (mul) v *= mul[ch];
-    out[i] = v;
+    const int cells = gs * gs, C = na * attrs;
+    const int ncb = (cells + 127) / 128;
+    const int b = blockIdx.x / ncb, cb = blockIdx.x - b * ncb;
+    const int c0 = cb * 128;
+    const int ncell = min(128, cells - c0);
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const int a = ch / attrs, at = ch - a * attrs;
+        const float mv = mul ? mul[ch] : 1.f;
+        const float* src = pre + ((int64_t)b * cells + c0) * ldp + ch;
+        float* dst = out + (((int64_t)b * na + a) * cells + c0) * attrs + at;
+        for (int cell = 0; cell < ncell; cell++) dst[(int64_t)cell * attrs] = src[(int64_t)cell * ldp] * mv;
+    }
 }
 
 // backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand; columns >= na*attrs stay zero from allocation),
@@ -857,7 +859,8 @@ extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul
     if (!pre || !out) return RY_ERR_ARG;
     const int64_t total = (int64_t)B * na * gs * gs * attrs;
     if (total == 0) return RY_OK;
-    hipLaunchKernelGGL(head_finish_fwd_kernel, dim3((unsigned)ry_cdiv(total, 256)), dim3(256), 0, stream, pre, ldp, mul, B, gs, na, attrs, out);
+    hipLaunchKernelGGL(head_finish_fwd_kernel, dim3((unsigned)(B * ry_cdiv((int64_t)gs * gs, 128))), dim3(256), 0, stream, pre, ldp, mul, B, gs, na,
+                       attrs, out);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
