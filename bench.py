@@ -21,6 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E ~8 TB/s (≈6.3 achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md (2495 measured)
 TRAIN_GFLOP_PER_IMG = {("yolov7", "kfiou", 800): 499.6, ("yolov7", "csl", 800): 505.1}      # BASELINE.md §2 (3 x forward)
 
@@ -38,17 +39,18 @@ class EventTimer:
         self.used += 2
         return a, b
 
-    def note(self, kind, flops, e0, e1):
-        self.notes.append((kind, flops, e0, e1))
+    def note(self, kind, flops, e0, e1, nbytes=0):
+        self.notes.append((kind, flops, e0, e1, nbytes))
 
     def summary(self):
         agg = {}
-        for kind, fl, e0, e1 in self.notes:
-            d = agg.setdefault(kind, [0.0, 0.0, 0])
+        for kind, fl, e0, e1, nb in self.notes:
+            d = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             d[0] += e0.elapsed_time(e1) * 1e-3
             d[1] += fl
             d[2] += 1
-        return {k: dict(seconds=v[0], flops=v[1], launches=v[2]) for k, v in agg.items()}
+            d[3] += nb
+        return {k: dict(seconds=v[0], flops=v[1], launches=v[2], bytes=v[3]) for k, v in agg.items()}
 
 
 def weights_init_normal(m):            # train.py:28-33
@@ -218,9 +220,16 @@ def main():
         pmc = pmc_traffic(args)
 
         def roof(k, v):
-            ach = v["flops"] / v["seconds"] / 1e12
-            return {"kernel": k, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc.get(k),
+            # the roofline that binds the class: algorithmic FLOPs against the dense bf16 MFMA peak, or algorithmic bytes (every
+            # operand element once) against the HBM peak — whichever fraction is larger (the generic GEMM class is mostly 1x1
+            # layers with 8-32 K steps: memory streams)
+            tf = v["flops"] / v["seconds"] / 1e12
+            gb = v["bytes"] / v["seconds"] / 1e9
+            fm, fh = tf / MFMA_BF16_PEAK_TFLOPS, gb / HBM_PEAK_GBS
+            head = ({"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fh, 4)} if fh > fm else
+                    {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fm, 4)})
+            return {"kernel": k, **head, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                    "algorithmic_bytes_per_launch": int(v["bytes"] / max(1, v["launches"])), "traffic": pmc.get(k),
                     "launches_per_step": v["launches"] // args.steps,
                     "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
                     "share_of_step": round(v["seconds"] / dt, 4)}

@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         }
         // tap table -> LDS (ONE __shared__ object; an ordinary VMEM load inside the loop would make hipcc drain vmcnt(0))
         int* taptab = reinterpret_cast<int*>(smem + (MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS));
-        if (tid < tc.ntaps) taptab[tid] = (tc.dh[tid] & 0xff) | ((tc.dw[tid] & 0xff) << 8) | ((tc.widx[tid] & 0xff) << 16);
+        // constant tap index -> the bytes come from scalar dword loads of the kernarg segment; `tc.dh[tid]` made every thread fetch
+        // its byte with a VMEM load and the workgroup wait a full memory round trip before its first DMA could be issued
+#pragma unroll
+        for (int t = 0; t < RY_MAX_TAPS; t++)
+            if (tid == t && t < tc.ntaps) taptab[t] = (tc.dh[t] & 0xff) | ((tc.dw[t] & 0xff) << 8) | ((tc.widx[t] & 0xff) << 16);
         __syncthreads();
         int is_t = 0, is_c0 = 0;                                  // (tap, channel chunk) of the next stage to issue
         int cur_dh = 0, cur_dw = 0;

@@ -138,27 +138,31 @@ class Graph:
 
     @staticmethod
     def _describe(name, args):
-        """(kernel class, algorithmic FLOPs) of a launch — used by bench.py's live roofline accounting."""
+        """(kernel class, algorithmic FLOPs, algorithmic HBM bytes) of a launch — used by bench.py's live roofline accounting.
+        Bytes = every operand element once: gathered input + weights + output (twice for accumulate epilogues)."""
         if name == "ryolo_conv_gemm":
             p = args[0]
             fl = 0
             for c in range(p.nclasses):
                 fl += 2 * p.NB * p.OH * p.OW * p.Nout * p.cls[c].ntaps * p.Cin
+            outb = p.NB * p.OHf * p.OWf * p.Nout * (4 if p.epi == S.EPI_F32_BIAS else 2) * (2 if p.epi == S.EPI_ACCUM else 1)
+            by = p.NB * p.IH * p.IW * p.Cin * 2 + p.Nout * p.wtaps * p.Cin * 2 + outb
             kern = S.I()
             hip.call("ryolo_conv_gemm_plan", p, S.I(), kern)
             if kern.value == 1:
-                return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl)
+                return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl, by)
             tile = "256x32" if p.Nout <= 32 else ("128x64" if p.Nout <= 64 else "128x128")
-            return (f"conv_gemm_kernel<{tile}>", fl)
+            return (f"conv_gemm_kernel<{tile}>", fl, by)
         if name == "ryolo_conv_wgrad":
             p = args[0]
             fl = 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin
+            by = p.NB * p.OH * p.OW * p.Cout * 2 + p.NB * p.IH * p.IW * p.Cin * 2 + p.Cout * p.ntaps * p.Cin * 4
             kern = S.I()
             hip.call("ryolo_conv_wgrad_kernel", p, kern)
             if kern.value == 1:
-                return ("conv3x3_wgrad_kernel<128x9x32>", fl)
-            return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl)
-        return (name, 0)
+                return ("conv3x3_wgrad_kernel<128x9x32>", fl, by)
+            return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl, by)
+        return (name, 0, 0)
 
     def grad_ready_points(self, bounds):
         """For each [a, b) element range of Runtime.gflat: index of the LAST backward-tape entry that writes a gradient whose first
@@ -194,13 +198,13 @@ class Graph:
             return
         tid = id(tape)
         for i, (fn, args, name) in enumerate(tape):
-            kind, fl = self.meta.get((tid, i), (name, 0))
+            kind, fl, by = self.meta.get((tid, i), (name, 0, 0))
             if fl:
                 e0, e1 = timer.pair()
                 e0.record()
                 rc = fn(*args, st)
                 e1.record()
-                timer.note(kind, fl, e0, e1)
+                timer.note(kind, fl, e0, e1, by)
             else:
                 rc = fn(*args, st)
             if rc != 0:

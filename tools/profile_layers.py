@@ -39,7 +39,7 @@ tot = collections.defaultdict(float)
 detail = []
 for (tname, i, name), ms in best.items():
     tape = g.fwd if tname == "fwd" else g.bwd
-    kind, fl = g.meta.get((id(tape), i), (name, 0))
+    kind, fl = g.meta.get((id(tape), i), (name, 0, 0))[:2]
     tot[(tname, kind)] += ms
     detail.append((ms, tname, i, kind, fl))
 print("== totals per kernel class (ms per step, isolated launches) ==")
