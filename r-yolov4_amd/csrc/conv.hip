@@ -29,7 +29,9 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 #define BK 32
 
+#ifndef RY_STAGES
 #define RY_STAGES 3
+#endif
 
 template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
