@@ -1,0 +1,20 @@
+"""The per-block and whole-network parity tests once more with the 3x3 halo-patch kernel (forward / data gradient) and the
+halo-ring weight-gradient kernel FORCED onto the small grids those tests use (by default the dispatch keeps small problems on
+the generic kernels, so the network-level tests would never reach the new ones).  The switches are read once per process
+(RYOLO_GEMM_PIPE by the runtime, RYOLO_W3_FORCE by the library), hence the subprocess."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_block_and_network_parity_with_3x3_kernels_forced():
+    env = dict(os.environ, RYOLO_GEMM_PIPE="0x601", RYOLO_W3_FORCE="1")           # 0x200 patch kernel, 0x400 also for small grids
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "-q", "-m", "gpu", "-x",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
