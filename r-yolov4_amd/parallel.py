@@ -38,7 +38,7 @@ def bucket_bounds(n, bucket_elems):
 
 def allreduce_flat(flat, bucket_bytes=64 << 20, async_op=False):
     """Sum `flat` over all ranks in buckets of ~bucket_bytes; returns the work handles when async_op."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return []
     elems = max(1, bucket_bytes // flat.element_size())
     works = []
@@ -129,7 +129,7 @@ class DataParallel:
     overlapped with the backward tape (overlap=False: one pass at the end of backward), and exposes `grad_scale` = 1/world for
     the fused SGD step."""
 
-    def __init__(self, model, bucket_bytes=25 << 20, overlap=True):
+    def __init__(self, model, bucket_bytes=25 << 20, overlap=True, force=False):
         self.model = model
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
@@ -141,7 +141,8 @@ class DataParallel:
                     dist.broadcast(b, src=0)
         self.overlap = overlap
         self._reducer = _Reducer(bucket_bytes)
-        model._grad_hook = (self._reducer if overlap else self._reduce) if self.world > 1 else None
+        # force: install the hooks even for a single rank (exercises the RCCL path on a one-GPU box: tools/dp_check.py)
+        model._grad_hook = (self._reducer if overlap else self._reduce) if (self.world > 1 or force) else None
         self.grad_scale = 1.0 / self.world
 
     def _reduce(self, rt):

@@ -12,7 +12,15 @@ from ryolov4_amd.model.yolo import Yolo
 from ryolov4_amd.synth import CFG, HYP, synth_batch
 
 torch.cuda.set_device(0)
-rank, _, world = parallel.init_from_env(backend=os.environ.get("BACKEND", "gloo"))
+backend = os.environ.get("BACKEND", "gloo")
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # single rank: still create the process group so the collectives really go through the backend (RCCL with BACKEND=nccl)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend, rank=0, world_size=1)
+    rank, world = 0, 1
+else:
+    rank, _, world = parallel.init_from_env(backend=backend)
 dev = torch.device("cuda:0")
 res = {}
 for overlap in (True, False):
@@ -21,7 +29,7 @@ for overlap in (True, False):
     for p in m.parameters():
         torch.nn.init.normal_(p, 0.0, 0.05)
     m.to(dev).train()
-    dp = parallel.DataParallel(m, bucket_bytes=8 << 20, overlap=overlap)
+    dp = parallel.DataParallel(m, bucket_bytes=8 << 20, overlap=overlap, force=True)
     rt = m.runtime()
     crit = ComputeKFIoULoss(m, HYP)
     for step in range(2):
