@@ -1,0 +1,67 @@
+"""The 3x3 stride-1 halo-ring weight-gradient kernel (csrc/conv3x3.hip) through the C ABI against torch's fp32 conv weight
+gradient on the same bf16 operands: both variants (128-channel tiles; <= 64 output channels with split K halves), channel
+strides wider than the tensors (concat slices), Cout that is not a multiple of 32, odd map sizes, accumulation into an existing
+gradient.  Sizes are chosen so the library's own dispatch picks the ring kernel (asserted).  Tolerance 2e-3 relative (bf16
+operands, fp32 accumulation in a different order)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(B, H, W, Cin, Cout, ldx_extra=0, ldy_extra=0, seed=0):
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S
+    hip.lib()
+    S.check_layouts()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(seed)
+    ldX, coutp = Cin + ldx_extra, ((Cout + 7) // 8) * 8
+    ldY = coutp + ldy_extra
+    x = torch.randn(B * H * W, ldX, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.zeros(B * H * W, ldY, dtype=torch.bfloat16)
+    dy[:, :Cout] = (torch.randn(B * H * W, Cout, generator=g) * 0.1).to(torch.bfloat16)
+    dy[:, coutp:] = 3.0                                               # neighbouring slice of a concat buffer: must be ignored
+    dy = dy.to(dev)
+    dw0 = torch.randn(Cout, Cin, 9, generator=g).to(dev)
+    dw = dw0.clone()
+    zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+    p = S.WgradParams()
+    p.dY, p.ldY, p.Cout, p.CoutPad = dy.data_ptr(), ldY, Cout, coutp
+    p.X, p.NB, p.IH, p.IW, p.Cin, p.ldX = x.data_ptr(), B, H, W, Cin, ldX
+    p.OH, p.OW, p.sh, p.sw, p.ntaps = H, W, 1, 1, 9
+    for r in range(3):
+        for s in range(3):
+            p.dh[r * 3 + s], p.dw[r * 3 + s] = r - 1, s - 1
+    p.dW, p.zeros = dw.data_ptr(), zeros.data_ptr()
+    kern, sk, ws = S.I(), S.I(), S.Z()
+    hip.call("ryolo_conv_wgrad_kernel", p, kern)
+    assert kern.value == 1, "dispatch did not pick the halo-ring kernel for this shape"
+    hip.call("ryolo_conv_wgrad_plan", p, sk, ws)
+    work = torch.empty(ws.value, dtype=torch.uint8, device=dev)
+    p.partial = work.data_ptr()
+    hip.call("ryolo_conv_wgrad", p, hip.stream())
+    torch.cuda.synchronize()
+    xr = x[:, :Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    w0 = torch.zeros(Cout, Cin, 3, 3, device=dev, requires_grad=True)
+    torch.nn.functional.conv2d(xr, w0, padding=1).backward(dy[:, :Cout].float().view(B, H, W, Cout).permute(0, 3, 1, 2))
+    ref = w0.grad.reshape(Cout, Cin, 9)
+    got = dw - dw0                                                    # the kernel ACCUMULATES into the gradient
+    assert float((got - ref).norm() / ref.norm()) < 2e-3
+    assert bool(torch.isfinite(dw).all())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (16, 64, 64, 64, 128),        # 128-channel tiles
+    (12, 50, 50, 128, 256),       # two output-channel tiles, four input chunks
+    (32, 33, 47, 64, 72),         # odd map, Cout not a multiple of 32 (rows of the last quarter masked)
+    (48, 40, 40, 64, 64),         # <= 64 output channels: wave pairs split the K step
+    (40, 60, 44, 32, 40),         # <= 64 variant, single input chunk, Cout = 40
+])
+def test_ring_wgrad(B, H, W, Cin, Cout):
+    _run(B, H, W, Cin, Cout)
+
+
+def test_ring_wgrad_concat_slices():
+    _run(16, 64, 64, 64, 128, ldx_extra=96, ldy_extra=64, seed=4)
+    _run(48, 40, 40, 64, 48, ldx_extra=32, ldy_extra=16, seed=5)
