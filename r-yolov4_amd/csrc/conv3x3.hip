@@ -496,6 +496,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cow = CO64 ? (wave & 1) : wave;                     // 32-channel quarter of this wave
     const int kh = CO64 ? (wave >> 1) : 0;                        // CO64: the 16-pixel half of each K step this wave multiplies
+#ifdef W3_TIMING
+    const unsigned long long T0 = __builtin_readcyclecounter();
+#endif
     const int t_id = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = t_id % g.gx, bc = (t_id / g.gx) % g.gc, bz = t_id / (g.gx * g.gc);
     const int i0 = bx * 128, ci0 = bc * 32;
@@ -511,67 +514,70 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
 
     // ---- DMA bookkeeping.  A 1-KiB piece = 16 pixel rows x 64 B; lane -> (row = lane >> 2, 16-byte slot = lane & 3).
     // dY: wave w stages the two 16-row halves of ITS OWN 32-channel quarter; X: waves 0/1 stage the two halves of the 32 new rows.
-    // Loop-carried padded coordinates (img, ihp, iwp) per lane: no division inside the loop.
+    // Every stream carries its padded coordinates (q, img, ihp, iwp) in 32-bit registers and advances them with carries; the source
+    // address is rebuilt from them with two 32-bit mads and one 64-bit mad (the first version walked 64-bit indices through
+    // while-loops and cost ~1600 cycles of DMA issue per K step — cycle counters).
     const int prow_l = lane >> 2, slot = lane & 3;
-    auto decomp = [&](int64_t qa, int& img, int& ihp, int& iwp) {
-        const int64_t per = (int64_t)HPp * PWp;
-        int64_t q = qa < 0 ? 0 : qa;
-        img = (int)(q / per);
-        const int rem = (int)(q - (int64_t)img * per);
-        ihp = rem / PWp;
-        iwp = rem - ihp * PWp;
+    const int kend32 = (int)kend, Mp32 = (int)g.Mp;               // Mp < 2^31 (host check)
+    struct Cur { int q, img, ihp, iwp; };
+    auto decomp = [&](int qa, Cur& c) {
+        const int per = HPp * PWp;
+        const int q = qa < 0 ? 0 : qa;
+        c.q = qa;
+        c.img = q / per;
+        const int rem = q - c.img * per;
+        c.ihp = rem / PWp;
+        c.iwp = rem - c.ihp * PWp;
     };
-    auto advance = [&](int& img, int& ihp, int& iwp, int by) {
-        iwp += by;
-        while (iwp >= PWp) {
-            iwp -= PWp;
-            if (++ihp >= HPp) { ihp = 0; img++; }
+    auto advance = [&](Cur& c, int by) {                          // by >= 0, c.q >= 0 (a loop that rarely iterates beat a branch-free
+        c.q += by;                                                // triple select: 582 vs 544 TF/s at 128->128 @100^2)
+        c.iwp += by;
+        while (c.iwp >= PWp) {
+            c.iwp -= PWp;
+            if (++c.ihp >= HPp) { c.ihp = 0; c.img++; }
         }
     };
+    auto interior = [&](const Cur& c) { return (unsigned)(c.ihp - 1) < (unsigned)H && (unsigned)(c.iwp - 1) < (unsigned)W; };
+    auto pixel = [&](const Cur& c) { return (c.img * H + c.ihp - 1) * W + c.iwp - 1; };     // < 2^31 (host check)
     // dY rows of step s, half u: padded pixel kbeg + 32 s + 16 u + prow_l
-    int64_t dq[NDY];
-    int dimg[NDY], dih[NDY], diw[NDY];
+    Cur dc[NDY];
 #pragma unroll
-    for (int u = 0; u < NDY; u++) {
-        dq[u] = kbeg + 16 * (CO64 ? kh : u) + prow_l;
-        decomp(dq[u], dimg[u], dih[u], diw[u]);
-    }
+    for (int u = 0; u < NDY; u++) decomp((int)kbeg + 16 * (CO64 ? kh : u) + prow_l, dc[u]);
     const bool d_chan_ok = (i0 + 32 * cow + slot * 8) < p.CoutPad;
+    const bf16_t* const dy_base = p.dY + i0 + 32 * cow + slot * 8;
+    const bf16_t* const x_base = p.X + ci0 + slot * 8;
+    auto issue_dy1 = [&](int stage, int u) {
+        const bool ok = d_chan_ok && dc[u].q < kend32 && interior(dc[u]);
+        const bf16_t* src = ok ? dy_base + (int64_t)pixel(dc[u]) * p.ldY : p.zeros;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + cow * 2048 + (CO64 ? kh : u) * 1024), 16, 0, 0);
+        advance(dc[u], 32);
+    };
     auto issue_dy = [&](int stage) {
 #pragma unroll
-        for (int u = 0; u < NDY; u++) {
-            const bool ok = d_chan_ok && dq[u] < kend && dih[u] >= 1 && dih[u] <= H && diw[u] >= 1 && diw[u] <= W && dimg[u] < p.NB;
-            const bf16_t* src = ok ? p.dY + (((int64_t)dimg[u] * H + (dih[u] - 1)) * W + (diw[u] - 1)) * p.ldY + i0 + 32 * cow + slot * 8 : p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + cow * 2048 + (CO64 ? kh : u) * 1024), 16, 0, 0);
-            dq[u] += 32;
-            advance(dimg[u], dih[u], diw[u], 32);
-        }
+        for (int u = 0; u < NDY; u++) issue_dy1(stage, u);
     };
     // X ring: slot of padded row q = q mod RX (q may be negative before the first image: two's-complement masking).  Pieces are
     // 16 aligned rows.  Prologue: every wave stages 16 rows per iteration over [x0, xend) (a multiple of 64 rows covering the rows
     // of steps 0 and 1 with their halos); steady state: waves 0 and 1 append the next 32 rows each step (for step s + 2).
-    const int64_t x0 = ((kbeg - HALO) >> 5) << 5;                    // aligned down to 32 (arithmetic shift: also for negatives)
-    const int pro_iters = (int)((kbeg + 64 + HALO - x0 + 63) >> 6);
-    int64_t xq = x0 + 16 * wave + prow_l;                            // this lane's row in its current piece
-    int ximg = 0, xih = 0, xiw = 0;
-    if (xq >= 0) decomp(xq, ximg, xih, xiw);
+    const int x0 = (int)(((kbeg - HALO) >> 5) << 5);                 // aligned down to 32 (arithmetic shift: also for negatives)
+    const int pro_iters = ((int)kbeg + 64 + HALO - x0 + 63) >> 6;
+    Cur xc;
+    decomp(x0 + 16 * wave + prow_l, xc);                             // this lane's row in its current piece
     auto issue_x = [&]() {
-        const bool ok = xq >= 0 && xq < g.Mp && xih >= 1 && xih <= H && xiw >= 1 && xiw <= W;
-        const bf16_t* src = ok ? p.X + (((int64_t)ximg * H + (xih - 1)) * W + (xiw - 1)) * p.ldX + ci0 + slot * 8 : p.zeros;
-        const unsigned row0 = (unsigned)(int)(xq - prow_l) & rmask;   // wave-uniform, 16-aligned
+        const bool ok = xc.q >= 0 && xc.q < Mp32 && interior(xc);
+        const bf16_t* src = ok ? x_base + (int64_t)pixel(xc) * p.ldX : p.zeros;
+        const unsigned row0 = (unsigned)(xc.q - prow_l) & rmask;      // wave-uniform, 16-aligned
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring + row0 * 64), 16, 0, 0);
     };
     auto step_x = [&](int by) {
-        const int64_t nq = xq + by;
-        if (xq < 0) { if (nq >= 0) decomp(nq, ximg, xih, xiw); }
-        else advance(ximg, xih, xiw, by);
-        xq = nq;
+        if (xc.q < 0) { if (xc.q + by >= 0) decomp(xc.q + by, xc); else xc.q += by; }
+        else advance(xc, by);
     };
     for (int it = 0; it < pro_iters; it++) {
         issue_x();
         step_x(64);
     }
-    // now xq = x0 + 64 * pro_iters + 16 * wave + prow_l: exactly where waves 0 and 1 continue
+    // now xc.q = x0 + 64 * pro_iters + 16 * wave + prow_l: exactly where waves 0 and 1 continue
     issue_dy(0);
     if (nk > 1) issue_dy(1);
 
@@ -585,6 +591,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
+#ifdef W3_TIMING
+    const unsigned long long T1 = __builtin_readcyclecounter();
+#endif
     const unsigned kb32 = (unsigned)(int)kbeg;                        // low bits are all the ring index needs
     for (int s = 0; s < nk; s++) {
         // DMA this wave issued during step s-1 (operands of step s+1) may stay in flight: 2 dY pieces (+1 ring piece on waves 0, 1);
@@ -593,10 +602,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
         else if (s == 0 || wave >= 2) wait_vm<NDY>();
         else wait_vm<NDY + 1>();
         __builtin_amdgcn_s_barrier();                                 // step s operands visible; step s-1 fully consumed
-        if (s + 2 < nk) {
+        const bool do_dma = s + 2 < nk;
+        const int nstage = (s + 2) % W3_NS;
+#if !defined(W3_DMA_SHADOW) && !defined(W3_NO_DMA)
+        if (do_dma) {
             if (wave < 2) { issue_x(); step_x(32); }
-            issue_dy((s + 2) % W3_NS);
+            issue_dy(nstage);
         }
+#endif
         const unsigned char* da = dyst + (s % W3_NS) * DYS + cow * 2048;
         const unsigned q0 = kb32 + 32u * (unsigned)s;                 // padded index (mod 2^32) of the step's first pixel
         // 18 (16-pixel half, tap) MFMAs per step; the B fragment of MFMA i+PF is read while MFMA i runs (a software pipeline PF
@@ -628,6 +641,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
                 if (i + PF < 18) bq[i + PF] = read_b(i + PF);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
+                // -DW3_DMA_SHADOW: the step's DMA instructions between the MFMAs instead of at the top of the step — measured
+                // SLOWER here (470 vs 570 TF/s at 128->128 @100^2): their address VALU starves the in-order MFMA issue of a 2-wave SIMD
+                if (i == 3 || i == 8 || i == 13) {
+                    __builtin_amdgcn_sched_barrier(0);
+#if !defined(W3_NO_DMA) && defined(W3_DMA_SHADOW)
+                    if (do_dma) {
+                        if (i == 3) { if (wave < 2) { issue_x(); step_x(32); } }
+                        else issue_dy1(nstage, i == 8 ? 0 : 1);
+                    }
+#endif
+                }
             }
         } else {
             bf16x8 bq[9];
@@ -640,11 +664,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
                 if (i + PF < 9) bq[i + PF] = read_b(kh * 9 + i + PF);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[i], acc[i], 0, 0, 0);
+                if (i == 2 || i == 5) {
+                    __builtin_amdgcn_sched_barrier(0);
+#if !defined(W3_NO_DMA) && defined(W3_DMA_SHADOW)
+                    if (do_dma) {
+                        if (i == 2) { if (wave < 2) { issue_x(); step_x(32); } }
+                        else issue_dy1(nstage, 0);
+                    }
+#endif
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 
+#ifdef W3_TIMING
+    const unsigned long long T2 = __builtin_readcyclecounter();
+#endif
     // ---- split-K partial tile -> workspace [z][Cout][9*Cin] (GEMM layout; 128-byte row segments per store)
     const int NK = 9 * p.Cin;
     float* part = p.partial + ((int64_t)bz * (CO64 ? 2 : 1) + kh) * p.Cout * NK;
@@ -657,6 +693,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
             if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[t][e];
         }
     }
+#ifdef W3_TIMING
+    if (tid == 0) {   // debug build only: timestamps into the tail of the slab workspace (tools/bench_wgrad.py reads them)
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.partial + (size_t)g.slabs * p.Cout * NK) + (size_t)blockIdx.x * 4;
+        dbg[0] = T1 - T0; dbg[1] = T2 - T1; dbg[2] = __builtin_readcyclecounter() - T2; dbg[3] = nk;
+    }
+#endif
 }
 
 bool w3_geometry(const WgradParams& p, W3Geom& g)
@@ -681,7 +723,7 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.RX = rx;
     g.gx = (int)ry_cdiv(p.Cout, 128);
     g.gc = p.Cin / 32;
-    if (g.Mp >= (1ll << 31)) return false;
+    if (g.Mp >= (1ll << 31)) return false;                        // 32-bit stream coordinates
     int64_t sk = ry_cdiv(512, (int64_t)g.gx * g.gc);             // 2 resident workgroups x 256 CUs
     static const int minsteps = getenv("RYOLO_W3_MINSTEPS") ? atoi(getenv("RYOLO_W3_MINSTEPS")) : 24;   // measured 24 / 48 / 128: shorter splits fill the chip, the two-halo prologue still amortises
     const int64_t maxsplit = g.Mp / ((int64_t)minsteps * 32);      // K-steps per split: the ring prologue (2 halos) must amortise

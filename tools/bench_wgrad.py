@@ -26,7 +26,7 @@ zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
 if os.environ.get('W3', '1') == '1': p.zeros = zeros.data_ptr()
 sk, ws = S.I(), S.Z()
 hip.call("ryolo_conv_wgrad_plan", p, sk, ws)
-work = torch.empty(ws.value, dtype=torch.uint8, device=dev)
+work = torch.zeros(ws.value + (1 << 22), dtype=torch.uint8, device=dev)     # + room for the W3_TIMING debug stamps
 p.partial = work.data_ptr()
 st = hip.stream()
 for _ in range(2): hip.call("ryolo_conv_wgrad", p, st)
@@ -48,3 +48,10 @@ if os.environ.get("CHECK", "1") == "1":
     y.backward(dy[: nb * OH * OH].float().view(nb, OH, OH, Cout).permute(0, 3, 1, 2))
     ref = w0.grad.reshape(Cout, Cin, k * k)
     print("rel err", float((dw2 - ref).norm() / ref.norm()))
+
+if os.environ.get("W3_TIMING"):
+    import numpy as np
+    torch.cuda.synchronize()
+    d = work[ws.value:].view(torch.int64).view(-1, 4).cpu().numpy()
+    d = d[d[:, 3] != 0]
+    print("blocks", len(d), "steps", d[:, 3].mean(), "prologue", d[:, 0].mean(), "loop", d[:, 1].mean(), "per-step", (d[:, 1] / d[:, 3]).mean(), "epilogue", d[:, 2].mean())
