@@ -598,16 +598,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
     for (int s = 0; s < nk; s++) {
         // DMA this wave issued during step s-1 (operands of step s+1) may stay in flight: 2 dY pieces (+1 ring piece on waves 0, 1);
         // step 0 follows the prologue, whose last two instructions are dY(1)
+#if defined(W3_NO_XDMA) || defined(W3_NO_YDMA)
+        wait_vm<0>();                                                 // ablation builds: counts differ, drain
+#else
         if (s + 1 >= nk) wait_vm<0>();
         else if (s == 0 || wave >= 2) wait_vm<NDY>();
         else wait_vm<NDY + 1>();
+#endif
         __builtin_amdgcn_s_barrier();                                 // step s operands visible; step s-1 fully consumed
         const bool do_dma = s + 2 < nk;
         const int nstage = (s + 2) % W3_NS;
 #if !defined(W3_DMA_SHADOW) && !defined(W3_NO_DMA)
         if (do_dma) {
+#ifndef W3_NO_XDMA
             if (wave < 2) { issue_x(); step_x(32); }
+#endif
+#ifndef W3_NO_YDMA
             issue_dy(nstage);
+#endif
         }
 #endif
         const unsigned char* da = dyst + (s % W3_NS) * DYS + cow * 2048;
