@@ -14,7 +14,7 @@ R=os.environ["GRAFT_REPO_ROOT"]
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for f in glob.glob(R+"/gpurun_out/pmc_*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "conv_gemm" not in r["Kernel_Name"]: continue
+        if "conv_gemm" not in r["Kernel_Name"] and "conv3x3" not in r["Kernel_Name"]: continue
         agg[r["Counter_Name"]]["v"]+=float(r["Counter_Value"]); cnt[r["Counter_Name"]]+=1
 for k,v in sorted(agg.items()):
     print(f"{k:36s} per-dispatch {v['v']/cnt[k]:16.1f}  (n={cnt[k]})")
