@@ -83,6 +83,11 @@ typedef struct PoolParams {
     int NB, H, W, C, k, stride, pad, OH, OW;
     unsigned char* idx;            // [NB,OH,OW,C] argmax window offset (k>2 only)
     const bf16_t* dz; int lddz; bf16_t* dx; int lddx; int accum;
+    /* optional, stride-1 windows (SPP / SPPF / SPPCSPC, k = 5, 9, 13): with rowmax set the pool runs as a row pass + a column
+     * pass (2k reads per output instead of k*k) with the SAME first-maximum argmax as the direct form */
+    bf16_t* rowmax;                /* [NB,H,W,C] row-window maxima (forward scratch) */
+    unsigned char* rowidx;         /* [NB,H,W,C] their first-max column offset (kept for backward; null in eval plans) */
+    float* growws;                 /* [NB,H,W,C] fp32 scratch of the backward column pass */
 } PoolParams;
 
 typedef struct UpParams { const bf16_t* x; int ldx; bf16_t* z; int ldz; int NB, H, W, C; int accum; } UpParams;

@@ -497,6 +497,168 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const UpParams p)  
     }
 }
 
+// ---- stride-1 pools with large windows (SPP k = 5 / 9 / 13): row pass + column pass -------------------------------------------------
+// The direct form reads k*k inputs per output (169 at k = 13) and its gather-form backward scans k*k windows per input.  A window
+// maximum is separable; so is its FIRST-maximum argmax in (dy, dx) scanning order: the winner is the smallest dy whose row maximum
+// equals the window maximum, and within that row the smallest dx — exactly (column pass first-max over dy) of (row pass first-max over
+// dx).  2k reads per output in both directions, same indices and gradients as the direct kernels.
+__global__ __launch_bounds__(256) void pool_rows_fwd_kernel(const PoolParams p)
+{
+    const int c8 = p.C >> 3;
+    const PixIter it(c8);
+    if (!it.active) return;
+    const int64_t npix = (int64_t)p.NB * p.H * p.W;
+    const float rHW = 1.0f / (float)(p.H * p.W), rW = 1.0f / (float)p.W;
+    for (int64_t pix = (int64_t)blockIdx.x * it.ppb + it.pl; pix < npix; pix += (int64_t)gridDim.x * it.ppb) {
+        int n, h, ow;
+        split_pixel(pix, p.H, p.W, rHW, rW, n, h, ow);
+        for (int cb = it.cc; cb < c8; cb += it.c8w) {
+            const int c = cb << 3;
+            float best[8];
+            int bi[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { best[k] = -INFINITY; bi[k] = 0; }
+            for (int dx = 0; dx < p.k; dx++) {
+                const int iw = ow - p.pad + dx;
+                if ((unsigned)iw >= (unsigned)p.W) continue;
+                const V8 v = ld8(p.x + (pix - ow + iw) * p.ldx + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (v.v[k] > best[k]) { best[k] = v.v[k]; bi[k] = dx; }
+            }
+            V8 o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = best[k];
+            st8(p.rowmax + pix * p.C + c, o);
+            if (p.rowidx) {
+                unsigned long long packed = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) packed |= (unsigned long long)(bi[k] & 0xff) << (8 * k);
+                *reinterpret_cast<unsigned long long*>(p.rowidx + pix * p.C + c) = packed;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_cols_fwd_kernel(const PoolParams p)
+{
+    const int c8 = p.C >> 3;
+    const PixIter it(c8);
+    if (!it.active) return;
+    const int64_t npix = (int64_t)p.NB * p.H * p.W;                // stride 1, pad k/2: the output grid equals the input grid
+    const float rHW = 1.0f / (float)(p.H * p.W), rW = 1.0f / (float)p.W;
+    for (int64_t pix = (int64_t)blockIdx.x * it.ppb + it.pl; pix < npix; pix += (int64_t)gridDim.x * it.ppb) {
+        int n, oh, ow;
+        split_pixel(pix, p.H, p.W, rHW, rW, n, oh, ow);
+        for (int cb = it.cc; cb < c8; cb += it.c8w) {
+            const int c = cb << 3;
+            float best[8];
+            int bi[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { best[k] = -INFINITY; bi[k] = 0; }
+            for (int dy = 0; dy < p.k; dy++) {
+                const int ih = oh - p.pad + dy;
+                if ((unsigned)ih >= (unsigned)p.H) continue;
+                const int64_t rp = pix + (int64_t)(ih - oh) * p.W;
+                const V8 v = ld8(p.rowmax + rp * p.C + c);
+                unsigned long long rix = 0;
+                if (p.idx) rix = *reinterpret_cast<const unsigned long long*>(p.rowidx + rp * p.C + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (v.v[k] > best[k]) { best[k] = v.v[k]; bi[k] = dy * p.k + (int)((rix >> (8 * k)) & 0xff); }
+            }
+            V8 o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = best[k];
+            st8(p.z + pix * p.ldz + c, o);
+            if (p.idx) {
+                unsigned long long packed = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) packed |= (unsigned long long)(bi[k] & 0xff) << (8 * k);
+                *reinterpret_cast<unsigned long long*>(p.idx + pix * p.C + c) = packed;
+            }
+        }
+    }
+}
+
+// backward, column pass: g_row[n, ih, ow] = sum over the outputs (oh, ow) whose winning row is ih of dz[n, oh, ow]
+__global__ __launch_bounds__(256) void pool_cols_bwd_kernel(const PoolParams p)
+{
+    const int c8 = p.C >> 3;
+    const PixIter it(c8);
+    if (!it.active) return;
+    const int64_t npix = (int64_t)p.NB * p.H * p.W;
+    const float rHW = 1.0f / (float)(p.H * p.W), rW = 1.0f / (float)p.W, rk = 1.0f / (float)p.k;
+    for (int64_t pix = (int64_t)blockIdx.x * it.ppb + it.pl; pix < npix; pix += (int64_t)gridDim.x * it.ppb) {
+        int n, ih, ow;
+        split_pixel(pix, p.H, p.W, rHW, rW, n, ih, ow);
+        for (int cb = it.cc; cb < c8; cb += it.c8w) {
+            const int c = cb << 3;
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = 0.f;
+            for (int dy = 0; dy < p.k; dy++) {
+                const int oh = ih + p.pad - dy;                    // output row whose window row dy is ih
+                if ((unsigned)oh >= (unsigned)p.OH) continue;
+                const int64_t op = pix + (int64_t)(oh - ih) * p.W;
+                const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.idx + op * p.C + c);
+                const V8 g = ld8(p.dz + op * p.lddz + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int id = (int)((packed >> (8 * k)) & 0xff);
+                    const int wdy = (int)(((float)id + 0.5f) * rk);                      // id / k, exact for id < 256
+                    if (wdy == dy) acc[k] += g.v[k];
+                }
+            }
+            float4* o = reinterpret_cast<float4*>(p.growws + pix * p.C + c);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
+// backward, row pass: dx[n, ih, iw] (+)= sum over the row-window positions (ih, ow) whose winning column is iw of g_row[n, ih, ow]
+__global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const PoolParams p)
+{
+    const int c8 = p.C >> 3;
+    const PixIter it(c8);
+    if (!it.active) return;
+    const int64_t npix = (int64_t)p.NB * p.H * p.W;
+    const float rHW = 1.0f / (float)(p.H * p.W), rW = 1.0f / (float)p.W;
+    for (int64_t pix = (int64_t)blockIdx.x * it.ppb + it.pl; pix < npix; pix += (int64_t)gridDim.x * it.ppb) {
+        int n, ih, iw;
+        split_pixel(pix, p.H, p.W, rHW, rW, n, ih, iw);
+        for (int cb = it.cc; cb < c8; cb += it.c8w) {
+            const int c = cb << 3;
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = 0.f;
+            for (int dx = 0; dx < p.k; dx++) {
+                const int ow = iw + p.pad - dx;                    // row-window position whose column dx is iw
+                if ((unsigned)ow >= (unsigned)p.W) continue;
+                const int64_t rp = pix - iw + ow;
+                const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.rowidx + rp * p.C + c);
+                const float4* g = reinterpret_cast<const float4*>(p.growws + rp * p.C + c);
+                const float4 g0 = g[0], g1 = g[1];
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((int)((packed >> (8 * k)) & 0xff) == dx) acc[k] += gv[k];
+            }
+            V8 o;
+            if (p.accum) {
+                const V8 e = ld8(p.dx + pix * p.lddx + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++) o.v[k] = e.v[k] + acc[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) o.v[k] = acc[k];
+            }
+            st8(p.dx + pix * p.lddx + c, o);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ small-Cin im2col
 // img fp32 NCHW [NB,3,H,W] (what train.py:186 hands over) -> col [NB*OH*OW][Kpad] bf16, k = (r*kw + s)*Cin + c
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, int NB, int Cin, int H, int W, int kh, int kw,
@@ -856,6 +1018,13 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
 extern "C" int ryolo_maxpool_fwd(const PoolParams* pp, hipStream_t stream)
 {
     if (!pp || !pp->x || !pp->z || (pp->C & 7) || pp->k < 1 || pp->k > 15) return RY_ERR_ARG;
+    if (pp->rowmax && pp->stride == 1 && pp->OH == pp->H && pp->OW == pp->W && (!pp->idx || pp->rowidx)) {
+        const dim3 g(grid_for((int64_t)pp->NB * pp->H * pp->W * ((pp->C >> 3) < 256 ? (pp->C >> 3) : 256)));
+        hipLaunchKernelGGL(pool_rows_fwd_kernel, g, dim3(256), 0, stream, *pp);
+        hipLaunchKernelGGL(pool_cols_fwd_kernel, g, dim3(256), 0, stream, *pp);
+        RY_CHECK_LAUNCH();
+        return RY_OK;
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)pp->NB * pp->OH * pp->OW * ((pp->C >> 3) < 256 ? (pp->C >> 3) : 256))), dim3(256), 0, stream, *pp);
     RY_CHECK_LAUNCH();
     return RY_OK;
@@ -864,6 +1033,13 @@ extern "C" int ryolo_maxpool_fwd(const PoolParams* pp, hipStream_t stream)
 extern "C" int ryolo_maxpool_bwd(const PoolParams* pp, hipStream_t stream)
 {
     if (!pp || !pp->dz || !pp->dx || !pp->idx || (pp->C & 7)) return RY_ERR_ARG;
+    if (pp->rowmax && pp->rowidx && pp->growws && pp->stride == 1 && pp->OH == pp->H && pp->OW == pp->W) {
+        const dim3 g(grid_for((int64_t)pp->NB * pp->H * pp->W * ((pp->C >> 3) < 256 ? (pp->C >> 3) : 256)));
+        hipLaunchKernelGGL(pool_cols_bwd_kernel, g, dim3(256), 0, stream, *pp);
+        hipLaunchKernelGGL(pool_rows_bwd_kernel, g, dim3(256), 0, stream, *pp);
+        RY_CHECK_LAUNCH();
+        return RY_OK;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)pp->NB * pp->H * pp->W * ((pp->C >> 3) < 256 ? (pp->C >> 3) : 256))), dim3(256), 0, stream, *pp);
     RY_CHECK_LAUNCH();
     return RY_OK;

@@ -485,6 +485,15 @@ class Graph:
         p.x, p.ldx, p.z, p.ldz = x.ptr(), x.ld, z.ptr(), z.ld
         p.NB, p.H, p.W, p.C, p.k, p.stride, p.pad, p.OH, p.OW = x.N, x.H, x.W, x.C, k, stride, pad, OH, OW
         p.idx = idx.data_ptr() if idx is not None else None
+        if stride == 1 and k >= 5:
+            # SPP-style windows: separable row / column passes (scratch: row maxima; their argmax offsets are kept for backward)
+            rowmax = torch.empty((x.M, x.C), dtype=BF16, device=self.dev)
+            rowidx = torch.empty((x.M, x.C), dtype=torch.uint8, device=self.dev) if self.training else None
+            grow = torch.empty((x.M, x.C), dtype=torch.float32, device=self.dev) if self.training else None
+            self.keep.extend([rowmax, rowidx, grow])
+            p.rowmax = rowmax.data_ptr()
+            p.rowidx = rowidx.data_ptr() if rowidx is not None else None
+            p.growws = grow.data_ptr() if grow is not None else None
         self._call(self.fwd, "ryolo_maxpool_fwd", p)
         if self.training:
             def backward():

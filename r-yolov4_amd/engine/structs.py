@@ -47,7 +47,8 @@ class BnActParams(C.Structure):
 
 class PoolParams(C.Structure):
     _fields_ = [("x", P), ("ldx", I), ("z", P), ("ldz", I), ("NB", I), ("H", I), ("W", I), ("C", I), ("k", I), ("stride", I),
-                ("pad", I), ("OH", I), ("OW", I), ("idx", P), ("dz", P), ("lddz", I), ("dx", P), ("lddx", I), ("accum", I)]
+                ("pad", I), ("OH", I), ("OW", I), ("idx", P), ("dz", P), ("lddz", I), ("dx", P), ("lddx", I), ("accum", I),
+                ("rowmax", P), ("rowidx", P), ("growws", P)]
 
 
 class UpParams(C.Structure):
