@@ -731,7 +731,7 @@ extern "C" int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* ro
     // number of [2][Nout] partial-statistics rows the EPI_STATS epilogue writes (== gridM of the chosen tile)
     if (!rows) return RY_ERR_ARG;
     (void)pipe;
-    *rows = (int)ry_cdiv(M, Nout <= 32 ? 256 : 128);
+    *rows = (int)ry_cdiv(M, Nout <= 32 ? 256 : 128);               // (n tiles share the row; every generic tile is 128 pixels but the 256x32 one)
     return RY_OK;
 }
 
@@ -780,7 +780,7 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         // layers (tools/bench_conv.py matrix in DESIGN.md); 0x100 forces 32-channel stages for A/B runs
         const bool k64 = (p.Cin % 64 == 0) && p.cls[0].ntaps > 1 && p.Cin <= 256 && !(p.pipe & 0x100);
         if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 1>(p, stream);
-        if (p.Nout <= 64) return k64 ? launch_gemm<128, 64, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 64, 2, 2, 1>(p, stream);
+        if (p.Nout <= 64 || (p.pipe & 0x800)) return k64 ? launch_gemm<128, 64, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 64, 2, 2, 1>(p, stream);   // 0x800: A/B, 64-wide N tiles everywhere
         return k64 ? launch_gemm<128, 128, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 128, 2, 2, 1>(p, stream);
     }
     if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 0>(p, stream);

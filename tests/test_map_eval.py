@@ -87,3 +87,13 @@ def test_hip_matching_random_vs_oracle():
         for a, b in zip(ref, got):
             assert np.array_equal(np.asarray(a[0]), np.asarray(b[0]))
             assert a[3] == b[3]
+
+
+def test_no_predictions_and_no_labels_anywhere():
+    """Nothing to launch: images without predictions contribute a row only when they have labels (test.py:112-115)."""
+    from ryolov4_amd.lib import evaluate
+    outs = [torch.zeros((0, 7)), torch.zeros((0, 7))]
+    assert evaluate.get_batch_statistics(outs, torch.zeros((0, 7)), torch.linspace(0.5, 0.95, 10), 10) == []
+    tg = torch.tensor([[1.0, 3.0, 10.0, 10.0, 4.0, 8.0, 0.1]])
+    st = evaluate.get_batch_statistics(outs, tg, torch.linspace(0.5, 0.95, 10), 10)
+    assert len(st) == 1 and st[0][0].shape == (0, 10) and st[0][3] == [3.0]
