@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
                 sc1[k] = p.co1[2 * p.C + c + k]; sh1[k] = p.co1[3 * p.C + c + k];
                 if (Y2) { sc2[k] = p.co2[2 * p.C + c + k]; sh2[k] = p.co2[3 * p.C + c + k]; }
             }
-#pragma unroll 1
+#pragma unroll 1                                            // measured: unroll 2 = same, unroll 4 = 1.4x slower (registers -> occupancy)
             for (int64_t m = r0 + rl; m < r1; m += nrl) {
                 const V8 d = ld8(p.dz + m * p.lddz + c);
                 const V8 a = ld8(p.y1 + m * p.ld1 + c);
