@@ -184,3 +184,26 @@ def test_captured_inference_replay_matches_eager():
             ref = ref.clone()
         _, got = run(x)
         assert torch.equal(ref, got)
+
+
+@pytest.mark.gpu
+def test_load_state_dict_after_first_forward_keeps_the_engine_in_sync():
+    """Checkpoint loading AFTER the runtime exists (parameters are views of one flat buffer by then): load_state_dict copies in
+    place, the next forward must see the new weights (bf16 images are repacked every forward) — same output as a fresh model."""
+    from ryolov4_amd.model.yolo import Yolo
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(DEV)
+    a = Yolo(2, CFG, "kfiou", "yolov7").to(DEV).eval()
+    with torch.no_grad():
+        a(x, False)                                                # builds the runtime + plan with the random init
+    sd = fill_state(a.state_dict())
+    a.load_state_dict(sd, strict=True)
+    b = Yolo(2, CFG, "kfiou", "yolov7")
+    b.load_state_dict(sd, strict=True)
+    b.to(DEV).eval()
+    with torch.no_grad():
+        _, ia = a(x, False)
+        _, ib = b(x, False)
+    assert torch.equal(ia, ib)
+    saved = {k: v.clone() for k, v in a.state_dict().items()}     # save -> load round trip (train.py:88-90)
+    for k in sd:
+        assert torch.equal(saved[k].cpu(), sd[k].cpu()), k

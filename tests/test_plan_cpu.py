@@ -51,3 +51,23 @@ def test_unknown_mode_raises_like_reference():
         Yolo(2, CFG, "smooth_l1", "yolov4")
     with pytest.raises(RuntimeError):
         Yolo(2, CFG, "csl", "yolov4")(torch.zeros(1, 3, 64, 64), True)          # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("ver", ["yolov4", "yolov7"])
+def test_pretrained_first_552_entries_rule(ver):
+    """train.py:74-86 verbatim on this build's Yolo: a reference checkpoint (here: the oracle's state_dict, whose keys / shapes /
+    order are pinned to the imported reference) is cut to its first 552 entries, merged into model.state_dict() and loaded
+    strictly — the checkpoint ABI is the reference's."""
+    from oracle import ref_model
+    from ryolov4_amd.synth import fill_state
+    pretrained = fill_state(ref_model.Yolo(16, CFG, "kfiou", ver).state_dict())
+    model = Yolo(16, CFG, "kfiou", ver)
+    pretrained_dict = {k: v for i, (k, v) in enumerate(pretrained.items()) if i < 552}
+    model_dict = model.state_dict()
+    model_dict.update(pretrained_dict)
+    model.load_state_dict(model_dict)                              # strict
+    got = model.state_dict()
+    for i, (k, v) in enumerate(pretrained.items()):
+        if i < 552:
+            assert torch.equal(got[k], v), k
+    assert len(pretrained) >= 552
