@@ -5,8 +5,8 @@
 //
 // The reference spends ~100 tiny launches, 4-5 device->host syncs (.cpu().item(), boolean-mask indexing) and an
 // O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 5 launches with no host round trip:
-//   K1 loss_targets_kernel   one 1024-thread workgroup per scale: candidate (offset, anchor, target) triples are tested
-//                            and compacted IN THE REFERENCE'S ORDER with ballot/popcount prefix sums (bit-exact indices);
+//   K1 loss_targets_*        32 workgroups per scale, two launches (count, then place): candidate (offset, anchor, target) triples
+//                            are tested and compacted IN THE REFERENCE'S ORDER with ballot/popcount prefix sums (bit-exact indices);
 //   K2 loss_match_kernel     one wavefront per match: lane 0 differentiates the box term with forward-mode dual numbers
 //                            (CIoU with constant alpha / KFIoU closed form), all 64 lanes run the class / 180-bin CSL
 //                            BCE with wave64 shuffle reductions; gradients are emitted directly (fused fwd+bwd);
@@ -57,44 +57,100 @@ __host__ __device__ static inline void carve(const LossParams& p, ScaleWs* s, si
 }
 
 // ------------------------------------------------------------------------------------------------ K1 targets
+// Candidate (offset o, anchor a, target t) of linear index cnd = (o*na + a)*nt + t in the reference's enumeration order
+// (lib/loss.py:275-310 / :432-471): does it produce a match on scale i?
+struct Cand { bool ok; int o, a, t; float gx, gy, gw, gh; };
+__device__ __forceinline__ Cand cand_test(const LossParams& p, int i, int cnd, int total)
+{
+    Cand c;
+    c.ok = false; c.o = 0; c.a = 0; c.t = 0; c.gx = c.gy = c.gw = c.gh = 0.f;
+    if (cnd >= total) return c;
+    const int na = p.na, nt = p.nt;
+    const float fg = (float)p.gs[i];
+    c.o = cnd / (na * nt);
+    const int r = cnd - c.o * na * nt;
+    c.a = r / nt;
+    c.t = r - c.a * nt;
+    const float* tg = p.targets + (int64_t)c.t * p.tcols;
+    c.gx = tg[2] * fg; c.gy = tg[3] * fg; c.gw = tg[4] * fg; c.gh = tg[5] * fg;
+    const float aw = p.anchors[i][c.a][0], ah = p.anchors[i][c.a][1];
+    const float rw = c.gw / aw, rh = c.gh / ah;
+    const float mw = fmaxf(rw, 1.0f / rw), mh = fmaxf(rh, 1.0f / rh);
+    bool ok = fmaxf(mw, mh) < 4.0f;                                                    // lib/loss.py:297-298 / :454-455
+    if (p.mode == 1) ok = ok && (fabsf(cosf(tg[6] - p.anchors[i][c.a][2])) > 0.866f);     // lib/loss.py:458-461
+    if (ok && c.o > 0) {
+        const float ix = fg - c.gx, iy = fg - c.gy;                                    // gxi = gain - gxy
+        if (c.o == 1) ok = (c.gx - floorf(c.gx) < 0.5f) && (c.gx > 1.0f);
+        else if (c.o == 2) ok = (c.gy - floorf(c.gy) < 0.5f) && (c.gy > 1.0f);
+        else if (c.o == 3) ok = (ix - floorf(ix) < 0.5f) && (ix > 1.0f);
+        else ok = (iy - floorf(iy) < 0.5f) && (iy > 1.0f);
+    }
+    c.ok = ok;
+    return c;
+}
+
+// Target assignment in two launches over LT_BLOCKS workgroups per scale (one workgroup per scale walked 360 barrier-separated
+// iterations at batch 64: 0.76 ms): pass 1 counts the matches of each workgroup's contiguous candidate range into count[1 + j];
+// pass 2 starts each range at the sum of the preceding counts and compacts IN THE REFERENCE'S ORDER (ballot / popcount prefix inside
+// the workgroup), so the records — and the last-writer-wins owner resolution downstream — are bit-identical to the serial walk.
+#define LT_BLOCKS 32
+__device__ __forceinline__ void lt_range(int total, int j, int& lo, int& hi)
+{
+    const int per = ((total + LT_BLOCKS - 1) / LT_BLOCKS + 1023) / 1024 * 1024;      // whole 1024-candidate iterations
+    lo = min(total, j * per);
+    hi = min(total, lo + per);
+}
+
+__global__ __launch_bounds__(1024) void loss_targets_count_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
+{
+    const int i = blockIdx.x, j = blockIdx.y;
+    const ScaleWs s = i == 0 ? s0 : (i == 1 ? s1 : s2);
+    const int total = 5 * p.na * p.nt;
+    int lo, hi;
+    lt_range(total, j, lo, hi);
+    __shared__ int wave_cnt[16];
+    int mine = 0;
+    for (int base = lo; base < hi; base += 1024) {
+        const Cand c = cand_test(p, i, base + (int)threadIdx.x, hi);
+        mine += __popcll(__ballot(c.ok));                                              // identical in every lane of the wave
+    }
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; w++) tot += wave_cnt[w];
+        s.count[1 + j] = tot;
+    }
+}
+
 __global__ __launch_bounds__(1024) void loss_targets_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
 {
-    const int i = blockIdx.x;
+    const int i = blockIdx.x, j = blockIdx.y;
     const ScaleWs s = i == 0 ? s0 : (i == 1 ? s1 : s2);
     const int gs = p.gs[i];
-    const int na = p.na, nt = p.nt;
-    const int total = 5 * na * nt;
+    const int na = p.na;
+    const int total = 5 * na * p.nt;
+    int lo, hi;
+    lt_range(total, j, lo, hi);
     __shared__ int wave_cnt[16];
     __shared__ int running;
-    if (threadIdx.x == 0) running = 0;
+    if (threadIdx.x == 0) {
+        int before = 0, all = 0;
+        for (int k = 0; k < LT_BLOCKS; k++) {
+            const int ck = s.count[1 + k];
+            if (k < j) before += ck;
+            all += ck;
+        }
+        running = before;
+        if (j == 0) s.count[0] = all;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float fg = (float)gs;
-    for (int base = 0; base < total; base += 1024) {
-        const int cnd = base + threadIdx.x;
-        bool ok = false;
-        int o = 0, a = 0, t = 0;
-        float gx = 0.f, gy = 0.f, gw = 0.f, gh = 0.f;
-        if (cnd < total) {
-            o = cnd / (na * nt);
-            const int r = cnd - o * na * nt;
-            a = r / nt;
-            t = r - a * nt;
-            const float* tg = p.targets + (int64_t)t * p.tcols;
-            gx = tg[2] * fg; gy = tg[3] * fg; gw = tg[4] * fg; gh = tg[5] * fg;
-            const float aw = p.anchors[i][a][0], ah = p.anchors[i][a][1];
-            const float rw = gw / aw, rh = gh / ah;
-            const float mw = fmaxf(rw, 1.0f / rw), mh = fmaxf(rh, 1.0f / rh);
-            ok = fmaxf(mw, mh) < 4.0f;                                                     // lib/loss.py:297-298 / :454-455
-            if (p.mode == 1) ok = ok && (fabsf(cosf(tg[6] - p.anchors[i][a][2])) > 0.866f);   // lib/loss.py:458-461
-            if (ok && o > 0) {
-                const float ix = fg - gx, iy = fg - gy;                                    // gxi = gain - gxy
-                if (o == 1) ok = (gx - floorf(gx) < 0.5f) && (gx > 1.0f);
-                else if (o == 2) ok = (gy - floorf(gy) < 0.5f) && (gy > 1.0f);
-                else if (o == 3) ok = (ix - floorf(ix) < 0.5f) && (ix > 1.0f);
-                else ok = (iy - floorf(iy) < 0.5f) && (iy > 1.0f);
-            }
-        }
+    for (int base = lo; base < hi; base += 1024) {
+        const Cand c = cand_test(p, i, base + (int)threadIdx.x, hi);
+        const bool ok = c.ok;
+        const int o = c.o, a = c.a, t = c.t;
+        const float gx = c.gx, gy = c.gy, gw = c.gw, gh = c.gh;
         const unsigned long long m = __ballot(ok);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
         __syncthreads();
@@ -122,7 +178,6 @@ __global__ __launch_bounds__(1024) void loss_targets_kernel(const LossParams p, 
         if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < 16; w++) tot += wave_cnt[w]; running += tot; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *s.count = running;
 }
 
 // ------------------------------------------------------------------------------------------------ dual numbers
@@ -426,7 +481,8 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
         if (p.compute_grad && hipMemsetAsync(p.grad[i], 0, (size_t)s[i].cells * attrs * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
     }
     if (p.nt > 0) {
-        hipLaunchKernelGGL(loss_targets_kernel, dim3(3), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
+        hipLaunchKernelGGL(loss_targets_count_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
+        hipLaunchKernelGGL(loss_targets_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
         for (int i = 0; i < 3; i++) {
             hipLaunchKernelGGL(loss_match_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
             hipLaunchKernelGGL(loss_tconf_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, s[i]);

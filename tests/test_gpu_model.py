@@ -167,6 +167,35 @@ def test_loss_golden(golden_dir, mode, nc):
         assert abs(it2["total_loss"] - items["total_loss"]) < 1e-6 * max(1.0, abs(items["total_loss"]))
 
 
+@pytest.mark.parametrize("mode,B,per", [("kfiou", 16, 64), ("csl", 64, 64), ("kfiou", 1, 3)])
+def test_loss_target_assignment_many_targets_bit_exact(mode, B, per):
+    """Target assignment at bench-like target counts (every one of the 32 workgroups per scale owns a non-empty candidate range):
+    match records in the reference's enumeration order, bit-exact against oracle.build_targets (itself pinned to the reference by
+    the g46 index vectors), and loss items against the oracle loss (1e-4 relative)."""
+    from ryolov4_amd.lib import loss as L
+
+    class M:
+        pass
+    nc, S = 16, 416
+    m = M()
+    m.anchors, m.nc = ref_ops.make_anchors(CFG, mode), nc
+    crit = (L.ComputeCSLLoss if mode == "csl" else L.ComputeKFIoULoss)(m, HYP)
+    tg = synth_targets(B, per, nc, mode == "csl", seed=11, img_size=S, edge_cases=True)
+    na = 3 if mode == "csl" else 18
+    attrs = (5 + 180 + nc) if mode == "csl" else (6 + nc)
+    g = torch.Generator().manual_seed(5)
+    outs = [torch.randn(B, na, S // st, S // st, attrs, generator=g) * 0.5 for st in (8, 16, 32)]
+    with torch.no_grad():
+        _, items = crit([o.to(DEV) for o in outs], tg.to(DEV))
+    recs = crit.debug_matches()
+    bt = ref_ops.build_targets([(o.shape[2], o.shape[3]) for o in outs], tg, m.anchors, mode)
+    for i in range(3):
+        exp = torch.stack((bt[i]["b"], bt[i]["a"], bt[i]["gj"], bt[i]["gi"], bt[i]["c"], bt[i]["tidx"]), 1).numpy()
+        assert np.array_equal(recs[i][:, :6], exp), (i, recs[i].shape, exp.shape)
+    _, items_o = ref_ops.compute_loss(outs, tg, m.anchors, nc, mode, HYP)
+    assert abs(items["total_loss"] - float(items_o["total_loss"])) < 1e-4 * abs(float(items_o["total_loss"]))
+
+
 @pytest.mark.gpu
 def test_captured_inference_replay_matches_eager():
     """hipGraph capture of forward + decode (BASELINE config C5): replays on new inputs equal the eager path bit for bit."""
