@@ -39,15 +39,15 @@ tot = collections.defaultdict(float)
 detail = []
 for (tname, i, name), ms in best.items():
     tape = g.fwd if tname == "fwd" else g.bwd
-    kind, fl = g.meta.get((id(tape), i), (name, 0, 0))[:2]
+    kind, fl, by = (tuple(g.meta.get((id(tape), i), (name, 0, 0))) + (0, 0))[:3]
     tot[(tname, kind)] += ms
-    detail.append((ms, tname, i, kind, fl))
+    detail.append((ms, tname, i, kind, fl, by))
 print("== totals per kernel class (ms per step, isolated launches) ==")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
     print(f"{k[0]:4s} {k[1]:34s} {v:8.3f} ms")
 print("sum", sum(tot.values()))
-print("== top 40 launches ==")
+print("== top launches ==")
 # recover shapes from the kept structs: walk keep list in order of creation for gemm/wgrad structs
-for ms, tname, i, kind, fl in sorted(detail, reverse=True)[:40]:
-    print(f"{tname} #{i:4d} {kind:30s} {ms*1e3:9.1f} us  {fl/ms/1e9 if fl else 0:8.1f} TF/s  flops {fl/1e9:8.2f} G")
-json.dump([(ms, tname, i, kind, fl) for ms, tname, i, kind, fl in detail], open("gpurun_out/layers.json", "w"))
+for ms, tname, i, kind, fl, by in sorted(detail, reverse=True)[:int(os.environ.get("TOP", 70))]:
+    print(f"{tname} #{i:4d} {kind:34s} {ms*1e3:9.1f} us  {fl/ms/1e9 if fl else 0:8.1f} TF/s  {by/ms/1e6 if by else 0:8.1f} GB/s  flops {fl/1e9:8.2f} G  bytes {by/1e6:8.1f} MB")
+json.dump(detail, open("gpurun_out/layers.json", "w"))
