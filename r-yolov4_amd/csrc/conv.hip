@@ -687,32 +687,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 }
 
 // dW[co][cin][tap] += sum_z partial[z][co][tap*Cin + cin]   (torch weight layout; fixed summation order => deterministic).
-// One workgroup per (co, 32-channel chunk): 32 channel lanes x 32 split lanes read the split-K slabs with 128-byte
-// coalesced rows, an LDS tree folds the split lanes, and the [tap][cin] -> [cin][tap] transpose happens in LDS so the
-// read-modify-write of the torch-layout gradient is one contiguous 32*ntaps-float run.
+// One workgroup per (co, CH-channel chunk): P = ntaps*CH/4 float4 positions x ZL split lanes stream the split-K slabs with
+// 16-byte loads (the first version used 4-byte loads, 32 channel lanes x 32 split lanes: 1.9 TB/s over 5.5 GB of slabs per step,
+// request-rate bound), an LDS pass folds the split lanes, and the [tap][cin] -> [cin][tap] transpose happens in LDS so the
+// read-modify-write of the torch-layout gradient is one contiguous CH*ntaps-float run.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splitk, int Cout, int Cin, int ntaps,
-                                                            float* __restrict__ dW)
+                                                            int CH, int ZL, float* __restrict__ dW)
 {
-    __shared__ float red[32][RY_MAX_TAPS][33];
-    const int c = threadIdx.x & 31, zl = threadIdx.x >> 5;
-    const int co = blockIdx.x, cin0 = blockIdx.y * 32;
+    extern __shared__ float red[];                   // [ZL][ntaps][CH + 1]
+    const int c4n = CH >> 2, P = ntaps * c4n;
+    const int pos = threadIdx.x % P, zl = threadIdx.x / P;
+    const int t = pos / c4n, c4 = pos - t * c4n;
+    const int co = blockIdx.x, cin0 = blockIdx.y * CH;
     const int NK = ntaps * Cin;
     const int64_t slab = (int64_t)Cout * NK;
-    const float* base = partial + (int64_t)co * NK + cin0 + c;
-    for (int t = 0; t < ntaps; t++) {
-        float s = 0.f;
-        for (int z = zl; z < splitk; z += 32) s += base[(int64_t)z * slab + (int64_t)t * Cin];
-        red[zl][t][c] = s;
+    const int ldr = CH + 1;
+    if (zl < ZL) {
+        const float* base = partial + (int64_t)co * NK + (int64_t)t * Cin + cin0 + c4 * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int z = zl;
+        for (; z + 3 * ZL < splitk; z += 4 * ZL) {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (int64_t)z * slab);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (int64_t)(z + ZL) * slab);
+            const float4 v2 = *reinterpret_cast<const float4*>(base + (int64_t)(z + 2 * ZL) * slab);
+            const float4 v3 = *reinterpret_cast<const float4*>(base + (int64_t)(z + 3 * ZL) * slab);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; z < splitk; z += ZL) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)z * slab);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* r = red + ((int64_t)zl * ntaps + t) * ldr + c4 * 4;
+        r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = s.w;
     }
     __syncthreads();
-    const int j = threadIdx.x;                       // output element within the contiguous run: j = cl*ntaps + t
-    if (j < 32 * ntaps) {
-        const int cl = j / ntaps, t = j - cl * ntaps;
-        float s = 0.f;
-#pragma unroll 8
-        for (int z = 0; z < 32; z++) s += red[z][t][cl];
-        dW[((int64_t)co * Cin + cin0) * ntaps + j] += s;
+    for (int j = threadIdx.x; j < CH * ntaps; j += 1024) {           // output element within the contiguous run: j = cl*ntaps + t
+        const int cl = j / ntaps, tt = j - cl * ntaps;
+        float sum = 0.f;
+        for (int z = 0; z < ZL; z++) sum += red[((int64_t)z * ntaps + tt) * ldr + cl];
+        dW[((int64_t)co * Cin + cin0) * ntaps + j] += sum;
     }
+}
+
+// chunk width / split lanes / LDS of wgrad_reduce_kernel for one layer
+static void launch_wgrad_reduce(const WgradParams& p, int splitk, hipStream_t stream)
+{
+    int CH = 32;
+    if (p.ntaps == 1) { while (CH < 256 && p.Cin % (CH * 2) == 0) CH *= 2; }
+    else if (p.ntaps <= 4) { while (CH < 64 && p.Cin % (CH * 2) == 0) CH *= 2; }
+    const int P = p.ntaps * (CH / 4);
+    int ZL = 1024 / P;
+    if (ZL > splitk) ZL = splitk;
+    if (ZL > 32) ZL = 32;
+    const size_t lds = (size_t)ZL * p.ntaps * (CH + 1) * sizeof(float);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / CH), dim3(1024), lds, stream, p.partial, splitk, p.Cout, p.Cin, p.ntaps,
+                       CH, ZL, p.dW);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -844,7 +876,7 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     if (w3_geometry(p, g3)) {
         const int rc3 = w3_launch(p, g3, stream);
         if (rc3) return rc3;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, g3.slabs, p.Cout, p.Cin, p.ntaps, p.dW);
+        launch_wgrad_reduce(p, g3.slabs, stream);
         RY_CHECK_LAUNCH();
         return RY_OK;
     }
@@ -852,7 +884,7 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
         hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / 32), dim3(1024), 0, stream, p.partial, p.splitk, p.Cout, p.Cin, p.ntaps, p.dW);
+    launch_wgrad_reduce(p, p.splitk, stream);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
