@@ -176,6 +176,9 @@ int ryolo_struct_sizes(int* sizes /* [10] */);
  * ------------------------------------------------------------------------------------------------------------ */
 int ryolo_loss_workspace_bytes(const LossParams* p, size_t* bytes);
 int ryolo_loss(const LossParams* p, ryolo_stream_t stream);
+/* autograd chain rule of the loss node (lib/loss.py:256,414 return a [1] tensor; `loss.backward()` hands back d(out)/d(loss) as a
+ * device scalar): grad[0..n) *= *scale, skipped ON THE DEVICE when *scale == 1.0f (the usual case) — no host read, capturable */
+int ryolo_loss_grad_scale(float* grad, int64_t n, const float* scale, ryolo_stream_t stream);
 
 #ifdef __cplusplus
 }

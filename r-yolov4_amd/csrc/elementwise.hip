@@ -65,23 +65,36 @@ __device__ __forceinline__ void st8(bf16_t* p, const V8& a)
 // ------------------------------------------------------------------------------------------------ partial-row folding
 // in [rows][K*C] float -> out [S][K*C] float: slice s sums rows s, s+S, s+2S, ... in double.  Keeps the finalize kernels
 // (one workgroup per 32 channels) short when a big layer produced tens of thousands of per-tile partial rows.
-__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ in, int rows, int KC, int S, float* __restrict__ out)
+__global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict__ in, int rows, int KC, int S, float* __restrict__ out)
 {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int s = blockIdx.y, rl = threadIdx.x >> 6;             // 4 row lanes per slice
-    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63;
+    const int col = blockIdx.x * 64 + cl;
+    const int s = blockIdx.y, rl = threadIdx.x >> 6;             // 16 row lanes per slice (4 lanes walked the 160 k tile rows of the first layers in 135 us)
+    __shared__ double red[16][64];
     double acc = 0.0;
-    if (col < KC)
-        for (int r = s + rl * S; r < rows; r += 4 * S) acc += (double)in[(int64_t)r * KC + col];
-    red[rl][threadIdx.x & 63] = acc;
+    if (col < KC) {
+        int r = s + rl * S;
+        for (; r + 48 * S < rows; r += 64 * S) {                  // 4 independent loads in flight
+            const float v0 = in[(int64_t)r * KC + col], v1 = in[(int64_t)(r + 16 * S) * KC + col];
+            const float v2 = in[(int64_t)(r + 32 * S) * KC + col], v3 = in[(int64_t)(r + 48 * S) * KC + col];
+            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+        }
+        for (; r < rows; r += 16 * S) acc += (double)in[(int64_t)r * KC + col];
+    }
+    red[rl][cl] = acc;
     __syncthreads();
-    if (rl == 0 && col < KC) out[(int64_t)s * KC + col] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rl == 0 && col < KC) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][cl];
+        out[(int64_t)s * KC + col] = (float)t;
+    }
 }
 #define FOLD_S 64
 static inline const float* fold_rows(const float* partial, int& rows, int KC, float* scratch, hipStream_t stream)
 {
     if (rows <= 4 * FOLD_S || !scratch) return partial;
-    hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)ry_cdiv(KC, 64), FOLD_S), dim3(256), 0, stream, partial, rows, KC, FOLD_S, scratch);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)ry_cdiv(KC, 64), FOLD_S), dim3(1024), 0, stream, partial, rows, KC, FOLD_S, scratch);
     rows = FOLD_S;
     return scratch;
 }

@@ -495,3 +495,21 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
     return RY_OK;
 }
 
+// grad *= *scale unless *scale == 1 (uniform early exit: one scalar load per workgroup)
+__global__ __launch_bounds__(256) void loss_grad_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ scale)
+{
+    const float s = *scale;
+    if (s == 1.0f) return;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] *= s;
+}
+
+extern "C" int ryolo_loss_grad_scale(float* grad, int64_t n, const float* scale, hipStream_t stream)
+{
+    if (!scale || n < 0 || (n > 0 && !grad)) return RY_ERR_ARG;
+    if (n == 0) return RY_OK;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(loss_grad_scale_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, grad, n, scale);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}

@@ -98,6 +98,7 @@ for _name, _sig in {
     "ryolo_struct_sizes": [_PTR(I)],
     "ryolo_loss_workspace_bytes": [_PTR(LossParams), _PTR(Z)],
     "ryolo_loss": [_PTR(LossParams), P],
+    "ryolo_loss_grad_scale": [P, L, P, P],
 }.items():
     hip.register(_name, _sig)
 

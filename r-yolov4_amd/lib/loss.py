@@ -24,8 +24,12 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         g = ctx.grads
-        # d(total)/d(logits) was produced by the fused kernel; scale in place by the incoming gradient (a [1] tensor)
-        return (None, None) + tuple(gi.mul_(go) for gi in g)
+        # d(total)/d(logits) was produced by the fused kernel; chain rule with the incoming gradient (a [1] device tensor, 1.0 after a
+        # plain loss.backward()): scaled in place on the device, and skipped there when the scalar is exactly 1 (no host read)
+        sc = go.detach().reshape(-1)[:1].to(device=g[0].device, dtype=torch.float32).contiguous()
+        for gi in g:
+            hip.call("ryolo_loss_grad_scale", gi.data_ptr(), gi.numel(), sc.data_ptr(), hip.stream())
+        return (None, None) + tuple(g)
 
 
 class _ComputeLossBase:

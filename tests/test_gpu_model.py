@@ -196,6 +196,29 @@ def test_loss_target_assignment_many_targets_bit_exact(mode, B, per):
     assert abs(items["total_loss"] - float(items_o["total_loss"])) < 1e-4 * abs(float(items_o["total_loss"]))
 
 
+def test_loss_backward_chain_rule_scalar_is_applied_on_device():
+    """loss.backward() (incoming gradient exactly 1: the scaling kernel exits on the device) vs (3 * loss).backward()."""
+    from ryolov4_amd.lib import loss as L
+
+    class M:
+        pass
+    m = M()
+    m.anchors, m.nc = ref_ops.make_anchors(CFG, "kfiou"), 2
+    crit = L.ComputeKFIoULoss(m, HYP)
+    tg = synth_targets(2, 6, 2, False, seed=4, img_size=128).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    base = [torch.randn(2, 18, 128 // st, 128 // st, 8, generator=g) for st in (8, 16, 32)]
+    grads = []
+    for k in (1.0, 3.0):
+        outs = [b.clone().to(DEV).requires_grad_() for b in base]
+        loss, _ = crit(outs, tg)
+        (loss * k).backward() if k != 1.0 else loss.backward()
+        grads.append([o.grad.clone() for o in outs])
+    for a, b in zip(*grads):
+        assert a.abs().sum() > 0
+        torch.testing.assert_close(b, 3.0 * a, rtol=1e-6, atol=0)
+
+
 @pytest.mark.gpu
 def test_captured_inference_replay_matches_eager():
     """hipGraph capture of forward + decode (BASELINE config C5): replays on new inputs equal the eager path bit for bit."""
