@@ -180,6 +180,30 @@ int ryolo_loss(const LossParams* p, ryolo_stream_t stream);
  * device scalar): grad[0..n) *= *scale, skipped ON THE DEVICE when *scale == 1.0f (the usual case) — no host read, capturable */
 int ryolo_loss_grad_scale(float* grad, int64_t n, const float* scale, ryolo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Data side (SURVEY.md §8(f) N2 slice, N4): the batch-finalisation end of BaseDataset.__getitem__ + collate_fn and the box
+ * geometry of the detect path.  uint8 images and polygon targets come from whatever produced them (the reference's cv2 pipeline, or
+ * a decoded cache resident in HBM); everything after them runs on the device.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* imgs uint8 [B][H][W][3] BGR -> dst fp32 [B][3][H][W] RGB / 255; flags[b] bit0 = fliplr, bit1 = flipud (null: none).
+ * Replaces np.fliplr / np.flipud (lib/augmentations.py:33-42), transpose + [::-1] + float() / 255 (datasets/base_dataset.py:155-157),
+ * torch.stack (:166).  Bit-exact. */
+int ryolo_to_tensor(const uint8_t* imgs, int B, int H, int W, const uint8_t* flags, float* dst, ryolo_stream_t stream);
+/* targets fp32 [nt][10] = (image slot, class, x1, y1, ..., x4, y4) in pixels of the H x W network input, clockwise vertices ->
+ * out [count][7 | 187] = (sample, class, x, y, w, h, theta [, csl x180]) in the reference's row order, *count on the device.
+ * Replaces BaseDataset.filtering (:340-352, border (0, W, 0, H)), normalize (:354-361), the label half of horizontal_flip /
+ * vertical_flip (flags[slot], as above), xyxyxyxy2xywha (lib/general.py:70-104), gaussian_label (base_dataset.py:13-31,143-149)
+ * and collate_fn's sample index (:161-164; sample_of_img[slot], null = identity).  workspace: nt ints (csl only). */
+int ryolo_encode_labels(const float* targets, int64_t nt, int H, int W, const uint8_t* flags, const int* sample_of_img, int csl,
+                        float* out, int* count, int* workspace, ryolo_stream_t stream);
+/* xyxyxyxy2xywha (lib/general.py:70-104) alone: clockwise polygons fp32 [n][8] -> (x, y, w, h, theta) fp32 [n][5] */
+int ryolo_polys_to_xywha(const float* polys, int64_t n, float* out, ryolo_stream_t stream);
+/* dets fp32 [n][7] = (x, y, w, h, theta, conf, cls) as post_process returns them; rescale != 0: rescale_boxes (lib/plot.py:9-31) in
+ * place on columns 0-3 with shapes[img_of_det[i]] = original (h, w) and the padded network size current_dim; then
+ * xywha2xyxyxyxy (lib/general.py:41-67, cv2.getRotationMatrix2D restated) -> polys fp32 [n][4][2]. */
+int ryolo_dets_to_polys(float* dets, const int* img_of_det, const int* shapes, int current_dim, int rescale, int64_t n, float* polys,
+                        ryolo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

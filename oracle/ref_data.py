@@ -1,0 +1,148 @@
+"""CPU restatement (torch-CPU / numpy) of the batch-finalisation end of the reference's data pipeline and of the detect path's
+box geometry — SURVEY.md §8(f) N2 slice + N4.  TEST INFRASTRUCTURE ONLY: imported by tests/ and the golden generator, never by
+the product path (r-yolov4_amd/).
+
+Pinned against the imported reference by tests/golden/make_golden_data.py (fixture g9_data.npz): BaseDataset.__getitem__'s tail
+and collate_fn run for real there (datasets/base_dataset.py:129-166), as do xyxyxyxy2xywha / xywha2xyxyxyxy (lib/general.py) and
+rescale_boxes (lib/plot.py).  cv2 is absent in this image: `get_rotation_matrix_2d` restates OpenCV's documented closed form
+(cv::getRotationMatrix2D) and is what the generator plugs into the reference's `cv.getRotationMatrix2D` call — that one call is
+"parity unpinned" (third-party, un-pinned version); everything around it is the reference's own arithmetic.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .ref_ops import norm_angle
+
+
+def gaussian_label(label, num_class=180, u=0, sig=6.0):
+    """datasets/base_dataset.py:13-31.  `int()` truncates toward zero; negative indices wrap through python slicing."""
+    x = np.arange(-num_class / 2, num_class / 2)
+    y_sig = np.exp(-(x - u) ** 2 / (2 * sig ** 2))
+    index = int(num_class / 2 - label)
+    return np.concatenate([y_sig[index:], y_sig[:index]], axis=0)
+
+
+def filtering(targets, border):
+    """datasets/base_dataset.py:340-352: keep polygons whose vertex mean lies strictly inside (x1, x2, y1, y2)."""
+    x1, x2, y1, y2 = border
+    x = torch.mean(targets[:, [2, 4, 6, 8]], dim=1)
+    y = torch.mean(targets[:, [3, 5, 7, 9]], dim=1)
+    return targets[(x > x1) & (x < x2) & (y > y1) & (y < y2)]
+
+
+def normalize(targets, img_size):
+    """datasets/base_dataset.py:354-361 (in place)."""
+    height, width = img_size
+    targets[:, [2, 4, 6, 8]] /= width
+    targets[:, [3, 5, 7, 9]] /= height
+    return targets
+
+
+def horizontal_flip(image, targets):
+    """lib/augmentations.py:39-42."""
+    targets[:, [2, 4, 6, 8]] = 1 - targets[:, [2, 4, 6, 8]]
+    return np.fliplr(image), targets
+
+
+def vertical_flip(image, targets):
+    """lib/augmentations.py:33-36."""
+    targets[:, [3, 5, 7, 9]] = 1 - targets[:, [3, 5, 7, 9]]
+    return np.flipud(image), targets
+
+
+def xyxyxyxy2xywha(boxes):
+    """lib/general.py:70-104: clockwise polygon -> (x, y, w, h, theta); h = long side, theta in [-pi/2, pi/2)."""
+    x1, y1, x2, y2, x3, y3, x4, y4 = boxes.unbind(dim=-1)
+    x = (x1 + x2 + x3 + x4) / 4
+    y = (y1 + y2 + y3 + y4) / 4
+    w = (torch.linalg.norm(torch.stack((x2 - x3, y2 - y3), -1), dim=1) + torch.linalg.norm(torch.stack((x1 - x4, y1 - y4), -1), dim=1)) / 2
+    h = (torch.linalg.norm(torch.stack((x1 - x2, y1 - y2), -1), dim=1) + torch.linalg.norm(torch.stack((x4 - x3, y4 - y3), -1), dim=1)) / 2
+    theta = -(torch.atan2(y1 - y2, x1 - x2) + torch.atan2(y4 - y3, x4 - x3)) / 2
+    swap = w >= h                                                             # the reference loops per box (:92-99); same result
+    w, h = torch.where(swap, h, w), torch.where(swap, w, h)
+    theta = torch.where(swap, torch.where(theta > 0, theta - np.pi / 2, theta + np.pi / 2), theta)
+    return torch.stack((x, y, w, h, norm_angle(theta)), -1)
+
+
+def finalize_sample(img_bgr_u8, targets10, fliplr, flipud, csl):
+    """datasets/base_dataset.py:129-157: filtering -> normalize -> flips -> poly->xywha (+ CSL) -> BGR->RGB CHW float / 255.
+    targets10 [n, 10] = (0, cls, x1..y4) in pixels of the (already padded / warped) image."""
+    img = img_bgr_u8
+    targets = filtering(targets10.clone(), (0, img.shape[1], 0, img.shape[0]))
+    targets = normalize(targets, img.shape[:2])
+    if fliplr:
+        img, targets = horizontal_flip(img, targets)
+    if flipud:
+        img, targets = vertical_flip(img, targets)
+    labels = torch.zeros((0, 187 if csl else 7), dtype=torch.float32)
+    if len(targets):
+        rboxes = xyxyxyxy2xywha(targets[:, 2:])
+        if csl:
+            rows = [gaussian_label(label=rboxes[i, 4] * 180 / np.pi + 90, num_class=180, u=0, sig=6) for i in range(len(rboxes))]
+            labels = torch.cat((targets[:, :2], rboxes, torch.from_numpy(np.stack(rows)).type(torch.float32)), -1)
+        else:
+            labels = torch.cat((targets[:, :2], rboxes), -1)
+    t = np.ascontiguousarray(img.transpose((2, 0, 1))[::-1])
+    return torch.from_numpy(t).float() / 255, labels
+
+
+def collate(samples):
+    """datasets/base_dataset.py:159-166 on a list of (img, labels)."""
+    imgs, targets = list(zip(*samples))
+    for i, boxes in enumerate(targets):
+        boxes[:, 0] = i
+    return torch.stack(imgs, 0), torch.cat(targets, 0)
+
+
+# ------------------------------------------------------------------------------------------------ detect path
+def get_rotation_matrix_2d(center, angle, scale):
+    """OpenCV cv::getRotationMatrix2D (imgproc; documented closed form), float64 2x3:
+    [[a, b, (1-a)cx - b cy], [-b, a, b cx + (1-a) cy]], a = scale cos(angle), b = scale sin(angle), angle in degrees."""
+    ang = angle * math.pi / 180.0
+    a, b = math.cos(ang) * scale, math.sin(ang) * scale
+    cx, cy = center
+    return np.array([[a, b, (1 - a) * cx - b * cy], [-b, a, b * cx + (1 - a) * cy]], dtype=np.float64)
+
+
+def xywh2xyxy(x):
+    """lib/general.py:23-38."""
+    y = x.new(x.shape)
+    y[..., 0] = x[..., 0] - x[..., 2] / 2
+    y[..., 1] = x[..., 1] - x[..., 3] / 2
+    y[..., 2] = x[..., 0] + x[..., 2] / 2
+    y[..., 3] = x[..., 1] + x[..., 3] / 2
+    return y
+
+
+def xywha2xyxyxyxy(boxes):
+    """lib/general.py:41-67 -> [N, 4, 2]; note h spans x and w spans y before the rotation (:59-62)."""
+    n = boxes.size(0)
+    Rs = torch.zeros((n, 2, 3))
+    x, y, w, h, theta = boxes.unbind(dim=-1)
+    for i in range(n):
+        Rs[i] = torch.from_numpy(get_rotation_matrix_2d((float(x[i]), float(y[i])), float(theta[i] * 180 / np.pi), 1))
+    p = torch.stack((x - h / 2, y - w / 2, x + h / 2, y - w / 2, x + h / 2, y + w / 2, x - h / 2, y + w / 2), dim=-1).reshape(-1, 4, 2)
+    p = torch.cat((p, torch.ones((n, 4, 1))), dim=-1)
+    return torch.bmm(p, Rs.permute((0, 2, 1)))
+
+
+def rescale_boxes(boxes, current_dim, original_shape):
+    """lib/plot.py:9-31 (in place on columns 0-3): undo pad-to-square + resize, xywh kept as centre/size."""
+    orig_h, orig_w = original_shape
+    pad_x = max(orig_h - orig_w, 0) * (current_dim / max(original_shape))
+    pad_y = max(orig_w - orig_h, 0) * (current_dim / max(original_shape))
+    unpad_h = current_dim - pad_y
+    unpad_w = current_dim - pad_x
+    boxes[:, :4] = xywh2xyxy(boxes[:, :4])
+    x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    x1 = ((x1 - pad_x // 2) / unpad_w) * orig_w
+    y1 = ((y1 - pad_y // 2) / unpad_h) * orig_h
+    x2 = ((x2 - pad_x // 2) / unpad_w) * orig_w
+    y2 = ((y2 - pad_y // 2) / unpad_h) * orig_h
+    boxes[:, 0] = (x1 + x2) / 2
+    boxes[:, 1] = (y1 + y2) / 2
+    boxes[:, 2] = (x2 - x1)
+    boxes[:, 3] = (y2 - y1)
+    return boxes

@@ -6,7 +6,9 @@ Same names / arguments / return types as /root/reference/lib/general.py:
 plus the two detectron2 ops the reference imports (lib/general.py:4, test.py:7):
     nms_rotated(boxes[N,5] deg, scores[N], iou_threshold) -> int64 keep indices
     pairwise_iou_rotated(boxes1[N,5], boxes2[M,5]) -> [N, M]
-Out of scope here (CPU/cv2 dataset-side helpers): xywha2xyxyxyxy, xyxyxyxy2xywha.
+and the two polygon converters of the data / detect side, batched on the device:
+    xyxyxyxy2xywha(boxes[N,8]) -> [N,5]                                                    (lib/general.py:70-104)
+    xywha2xyxyxyxy(boxes[N,5]) -> [N,4,2]                                                  (lib/general.py:41-67)
 """
 import numpy as np
 import torch
@@ -141,3 +143,26 @@ def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
     hip.call("ryolo_pp_emit", hip.ptr(dets), hip.ptr(keep), hip.ptr(num), B, K, ks, hip.ptr(out), st)
     n_host = num.cpu().tolist()          # the single device->host read of the whole batch
     return [out[b, :n] if n > 0 else empty for b, n in enumerate(n_host)]
+
+
+# ------------------------------------------------------------------------------------------ polygon <-> rotated box
+def xyxyxyxy2xywha(boxes):
+    """lib/general.py:70-104: clockwise polygons [N, 8] -> (x, y, w, h, theta) [N, 5], h = long side, theta in [-pi/2, pi/2).
+    One launch for the batch (the reference loops over boxes on the host); the range assert of norm_angle (a host sync) is dropped."""
+    hip.require_device(boxes, "xyxyxyxy2xywha")
+    src = boxes.float().contiguous()
+    out = torch.empty((src.shape[0], 5), dtype=torch.float32, device=boxes.device)
+    hip.call("ryolo_polys_to_xywha", hip.ptr(src), src.shape[0], hip.ptr(out), hip.stream())
+    return out
+
+
+def xywha2xyxyxyxy(boxes):
+    """lib/general.py:41-67: (x, y, w, h, theta rad) [N, 5] -> vertices [N, 4, 2] (h spans x, w spans y before the rotation, as
+    in the reference); cv2.getRotationMatrix2D restated in double on the device."""
+    hip.require_device(boxes, "xywha2xyxyxyxy")
+    n = boxes.shape[0]
+    d = torch.zeros((n, 7), dtype=torch.float32, device=boxes.device)
+    d[:, :5] = boxes[:, :5].float()
+    polys = torch.empty((n, 4, 2), dtype=torch.float32, device=boxes.device)
+    hip.call("ryolo_dets_to_polys", hip.ptr(d), None, None, 0, 0, n, hip.ptr(polys), hip.stream())
+    return polys
