@@ -455,7 +455,8 @@ template <int BN, int WM, int WN> static int p3_launch_t(const ConvGemmParams& p
             return RY_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes, stream, p, g);
+    static const unsigned ldspad = getenv("RYOLO_P3_LDSPAD") ? (unsigned)atoi(getenv("RYOLO_P3_LDSPAD")) : 0u;   // occupancy experiments
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes + ldspad, stream, p, g);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 
