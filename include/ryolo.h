@@ -161,6 +161,11 @@ int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, b
 /* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= ceil(M/1024)*C floats */
 int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);
 
+/* inference re-parameterisation of RepConv (model/utils.py:189-215 leaves the 3 branches un-fused): w3 fp32 [Cout][Cin][3][3],
+ * w1 fp32 [Cout][Cin], coa / cob = ryolo_bn_eval_coeffs of the two BatchNorms -> wf bf16 [Cout][9][Cin] (GEMM image of the merged
+ * 3x3 kernel) and co_out [4][Cout] (scale 1, shift = shift3 + shift1) for the EPI_AFFINE_ACT epilogue */
+int ryolo_repconv_fold(const float* w3, const float* w1, const float* coa, const float* cob, int Cout, int Cin, bf16_t* wf, float* co_out,
+                       ryolo_stream_t stream);
 /* fp32 master weights (torch layout) -> bf16 GEMM images, all convolutions in one launch */
 int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t total, ryolo_stream_t stream);
 int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int CinP, float* grad, ryolo_stream_t stream);

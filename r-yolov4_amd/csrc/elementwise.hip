@@ -891,6 +891,28 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
     }
 }
 
+// Inference re-parameterisation of RepConv (model/utils.py:189-215; the reference never fuses): with eval-mode
+// BatchNorm both branches are affine, so  act(bn3(conv3x3(x)) + bn1(conv1x1(x))) = act(conv3x3'(x) + shift)  with
+// W'[co][t][c] = s3[co] W3[co][c][t] + [t == centre] s1[co] W1[co][c]  and  shift = shift3 + shift1.  One 3x3 GEMM with the
+// folded-BN epilogue replaces two GEMMs and a two-branch BN + activation pass.  coa / cob: [4][Cout] from bn_eval_coeffs.
+__global__ void repconv_fold_kernel(const float* __restrict__ w3, const float* __restrict__ w1, const float* __restrict__ coa,
+                                    const float* __restrict__ cob, int Cout, int Cin, bf16_t* __restrict__ wf, float* __restrict__ co_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)Cout * 9 * Cin;
+    if (i < Cout) {
+        co_out[0 * Cout + i] = 0.f;
+        co_out[1 * Cout + i] = 1.f;
+        co_out[2 * Cout + i] = 1.f;
+        co_out[3 * Cout + i] = coa[3 * Cout + i] + cob[3 * Cout + i];
+    }
+    if (i >= total) return;
+    const int c = (int)(i % Cin), t = (int)((i / Cin) % 9), co = (int)(i / ((int64_t)9 * Cin));
+    float v = coa[2 * Cout + co] * w3[((int64_t)co * Cin + c) * 9 + t];
+    if (t == 4) v += cob[2 * Cout + co] * w1[(int64_t)co * Cin + c];
+    wf[i] = f2bf(v);
+}
+
 // dW scratch [Cout][CinP] (single-tap layout of a small-Cin layer) -> += into torch layout [Cout][Cin][taps]
 __global__ void unpack_wgrad_kernel(const float* __restrict__ scratch, int Cout, int Cin, int taps, int CinP, float* __restrict__ grad)
 {
@@ -1159,6 +1181,16 @@ extern "C" int ryolo_pack_weights(const PackEntry* table_dev, int n, int64_t tot
 {
     if (!table_dev || n <= 0 || total <= 0) return RY_ERR_ARG;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)(total > 16384 ? 16384 : total)), dim3(256), 0, stream, table_dev, n, total);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_repconv_fold(const float* w3, const float* w1, const float* coa, const float* cob, int Cout, int Cin, bf16_t* wf,
+                                  float* co_out, hipStream_t stream)
+{
+    if (!w3 || !w1 || !coa || !cob || !wf || !co_out || Cout <= 0 || Cin <= 0) return RY_ERR_ARG;
+    const int64_t total = (int64_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(repconv_fold_kernel, dim3((unsigned)ry_cdiv(total, 256)), dim3(256), 0, stream, w3, w1, coa, cob, Cout, Cin, wf, co_out);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -438,6 +438,22 @@ class Graph:
         conv_a, bn_a = rep.rbr_dense[0], rep.rbr_dense[1]
         conv_b, bn_b = rep.rbr_1x1[0], rep.rbr_1x1[1]
         cout = conv_a.out_channels
+        if not train and rt.fold_repconv and conv_a.stride[0] == 1 and conv_a.in_channels % 32 == 0:
+            # inference: the two affine branches collapse into ONE 3x3 GEMM with the folded-BN epilogue (csrc/elementwise.hip:
+            # repconv_fold_kernel); like the BN folding it depends on the weights only -> wprep tape
+            cin = conv_a.in_channels
+            coa, cob, co = self.f32(4, cout), self.f32(4, cout), self.f32(4, cout)
+            for bn, c4 in ((bn_a, coa), (bn_b, cob)):
+                self._call(self.wprep, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                           bn.running_var.data_ptr(), float(bn.eps), cout, c4.data_ptr())
+            wfold = torch.empty((cout, 9, cin), dtype=BF16, device=self.dev)
+            self.keep.append(wfold)
+            self._call(self.wprep, "ryolo_repconv_fold", conv_a.weight.data_ptr(), conv_b.weight.data_ptr(), coa.data_ptr(), cob.data_ptr(),
+                       cout, cin, wfold.data_ptr(), co.data_ptr())
+            z = self.new(x.N, x.H, x.W, cout)
+            self._gemm(self.fwd, x, x.ptr(), wfold, cout, 9, cin, x.H, x.W, 1, [(_taps_fwd(3, 1), 0, 0)], S.EPI_AFFINE_ACT, z.ptr(), z.ld,
+                       coeffs=co, act=S.ACT["swish"])
+            return z
         ya, sa, bwd_a = self.conv_raw(conv_a, x, bstat)
         yb, sb, bwd_b = self.conv_raw(conv_b, x, bstat)
         coa, cob = self.f32(4, cout), self.f32(4, cout)

@@ -94,6 +94,7 @@ for _name, _sig in {
     "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],
     "ryolo_unpack_wgrad": [P, I, I, I, I, P, P],
+    "ryolo_repconv_fold": [P, P, P, P, I, I, P, P, P],
     "ryolo_sgd_nesterov": [P, P, P, L, F, F, F, I, P],
     "ryolo_struct_sizes": [_PTR(I)],
     "ryolo_loss_workspace_bytes": [_PTR(LossParams), _PTR(Z)],

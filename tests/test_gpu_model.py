@@ -259,3 +259,28 @@ def test_load_state_dict_after_first_forward_keeps_the_engine_in_sync():
     saved = {k: v.clone() for k, v in a.state_dict().items()}     # save -> load round trip (train.py:88-90)
     for k in sd:
         assert torch.equal(saved[k].cpu(), sd[k].cpu()), k
+
+
+def test_repconv_inference_fold_matches_unfused_branches():
+    """Eval-mode RepConv as ONE re-parameterised 3x3 GEMM (ryolo_repconv_fold) vs the un-fused two-branch plan the reference's
+    forward describes (model/utils.py:209-215): same module, same input; bf16 weight rounding is the only difference (rel-L2 < 6e-3),
+    and both sit within 1e-2 of the fp32 oracle."""
+    import subprocess, sys, json
+    code = r'''
+import json, torch
+from ryolov4_amd.model.yolo import Yolo
+from ryolov4_amd.synth import CFG, fill_state
+m = Yolo(2, CFG, "kfiou", "yolov7"); m.load_state_dict(fill_state(m.state_dict())); m.cuda().eval()
+x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(5)).cuda()
+with torch.no_grad():
+    outs, inf = m(x, False)
+print(json.dumps([o.double().sum().item() for o in outs] + [inf.double().abs().sum().item()]))
+torch.save([o.cpu() for o in outs], "/tmp/_rep_%s.pt" % __import__("os").environ.get("RYOLO_FOLD_REPCONV", "1"))
+'''
+    for flag in ("1", "0"):
+        env = dict(os.environ, RYOLO_FOLD_REPCONV=flag)
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    a, b = torch.load("/tmp/_rep_1.pt"), torch.load("/tmp/_rep_0.pt")
+    for fa, fb in zip(a, b):
+        assert rel(fa, fb) < 6e-3, rel(fa, fb)
+        assert not torch.equal(fa, fb)                       # the fold really ran (different rounding), not the same plan twice

@@ -34,7 +34,13 @@ def test_plan_builds(ver, mode, nc, training):
     names = [n for _, _, n in g.fwd]
     direct_stem = names.count("ryolo_stem3x3_fwd")                 # 3x3 stride-1 stems (v4, v7) bypass im2col + GEMM
     assert direct_stem == (0 if ver == "yolov5" else 1)
-    assert names.count("ryolo_conv_gemm") == nconv - direct_stem
+    # eval plans re-parameterise every RepConv (3x3 + 1x1 -> one 3x3 GEMM); training plans keep both branches
+    from ryolov4_amd.model.blocks import RepConv
+    nrep = sum(1 for x in m.modules() if isinstance(x, RepConv))
+    assert nrep == (3 if ver == "yolov7" else 0)
+    assert names.count("ryolo_conv_gemm") == nconv - direct_stem - (0 if training else nrep)
+    if not training:
+        assert [n for _, _, n in g.wprep].count("ryolo_repconv_fold") == nrep
     if training:
         bnames = [n for _, _, n in g.bwd]
         assert bnames.count("ryolo_conv_wgrad") + bnames.count("ryolo_stem3x3_wgrad") == nconv
