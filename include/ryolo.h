@@ -138,7 +138,9 @@ int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* run
 int ryolo_bn_act_fwd(const BnActParams* p, ryolo_stream_t stream);
 int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_per_block);
 /* backward of the above: dy1 [, dy2] [, dres], dgamma/dbeta accumulated; p->partial needs (nblk+64)*K*C floats, bco 3*C.
- * frozen=1: the coefficients came from ryolo_bn_eval_coeffs (fixed affine map, no batch-statistics coupling). */
+ * frozen=1: the coefficients came from ryolo_bn_eval_coeffs (fixed affine map, no batch-statistics coupling).
+ * p->dy1 == NULL (single branch, no residual): statistics only — bco [2][C] = mean g, mean g*xhat and dgamma/dbeta are produced and
+ * the apply pass is left to the consumer (ryolo_stem3x3_wgrad with StemWgradParams.y set). */
 int ryolo_bn_act_bwd(const BnActParams* p, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
                      int frozen, ryolo_stream_t stream);
 

@@ -61,6 +61,12 @@ typedef struct StemWgradParams {
     const bf16_t* dY; int ldY, Cout;                 // [NB*H*W][ldY] bf16, Cout == 32
     float* scratch;                                  // out: dW in the GEMM layout [Cout][32] fp32 (overwritten; ryolo_unpack_wgrad adds it to .grad)
     float* workspace;                                // ryolo_stem3x3_plan bytes
+    // fused BatchNorm + activation backward (y != null): dY then holds dz = dL/d act(bn(y)) and the kernel forms the gradient of the
+    // raw conv output on the fly, dy = sc*g + A*y + B with g = dz*act'(sc*y + sh) (the algebra of ryolo_bn_act_bwd's apply pass,
+    // which is then skipped: its 3 tensor passes over the largest activation of the network go away)
+    const bf16_t* y; int ldy; int act;               // raw conv output [NB*H*W][ldy]
+    const float* co;                                 // [4][Cout]: mean, invstd, scale, shift (ryolo_bn_finalize / ryolo_bn_eval_coeffs)
+    const float* bco;                                // [2][Cout]: mean g, mean g*xhat (ryolo_bn_act_bwd with dy1 == null)
 } StemWgradParams;
 
 typedef struct BnActParams {

@@ -24,6 +24,21 @@ __device__ __forceinline__ float act_fwd(float u, int act)
     return u;
 }
 
+// d act / du, same expressions as elementwise.hip's act_d (one v_exp_f32, v_rcp_f32 instead of IEEE division)
+__device__ __forceinline__ float act_bwd(float u, int act)
+{
+    if (act == ACT_SILU) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
+    if (act == ACT_LEAKY) return u > 0.f ? 1.f : 0.1f;
+    if (act == ACT_MISH) {
+        if (u > 20.f) return 1.f;
+        const float n = __expf(u), w = n * (n + 2.f);
+        const float t = w * __builtin_amdgcn_rcpf(w + 2.f);
+        const float sg = n * __builtin_amdgcn_rcpf(1.f + n);
+        return t + u * (1.f - t * t) * sg;
+    }
+    return 1.f;
+}
+
 // bijective XCD remap (cdna guide T1): workgroup b runs on XCD b%8; give each XCD a contiguous tile range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {

@@ -1025,7 +1025,8 @@ extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_pe
 extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* bco,
                                 int frozen, hipStream_t stream)
 {
-    if (!pp || check_bnact(*pp) || !pp->dz || !pp->dy1 || !pp->partial || !bco) return RY_ERR_ARG;
+    if (!pp || check_bnact(*pp) || !pp->dz || !pp->partial || !bco) return RY_ERR_ARG;
+    if (!pp->dy1 && (pp->y2 || pp->dres)) return RY_ERR_ARG;     // dy1 == null: statistics only (the consumer applies them itself: stem wgrad)
     BnActParams p = *pp;
     if (p.M == 0) return RY_OK;
     int nblk, rpb;
@@ -1051,7 +1052,7 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<2>, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, fpart, frows, p.C,
                            (double)p.M, frozen, p.co1, p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2);
-    {
+    if (p.dy1) {
         const dim3 g(grid_rows(p.M, p.C)), b(256);
 #define RY_APP(ACT)                                                                                                   \
     if (p.y2 && p.dres) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<ACT, true, true>), g, b, 0, stream, p);           \

@@ -162,11 +162,13 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------- weight gradient
+template <bool FUSE>
 __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParams p, float* __restrict__ slabs)
 {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     __shared__ __attribute__((aligned(1024))) unsigned char dyt[4][4][1024];     // wave-private: 4 pieces of [16 px][32 ch] bf16
+    __shared__ __attribute__((aligned(1024))) unsigned char yt[FUSE ? 4 : 1][FUSE ? 4 : 1][FUSE ? 1024 : 16];   // FUSE: the raw conv output, same tiles
     __shared__ float redw[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W;
@@ -185,6 +187,16 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParam
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    // FUSE: the A fragment of a lane is 8 pixels of ONE output channel (lane & 31): four per-channel constants, as in bn_act_bwd_apply
+    float bn_sc = 0.f, bn_sh = 0.f, bn_A = 0.f, bn_B = 0.f;
+    if constexpr (FUSE) {
+        const int ch = lane & 31, C = p.Cout;
+        const float mu = p.co[ch], is = p.co[C + ch], mg = p.bco[ch], mx = p.bco[C + ch];
+        bn_sc = p.co[2 * C + ch];
+        bn_sh = p.co[3 * C + ch];
+        bn_A = -bn_sc * is * mx;
+        bn_B = bn_sc * (is * mx * mu - mg);
+    }
 
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t ss = (int64_t)blockIdx.x * 4 + wave;
@@ -215,6 +227,10 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParam
             const bool live = st < nsteps;
             const bf16_t* src = live ? p.dY + (st * 16 + d_row) * (int64_t)p.ldY + d_slot * 8 : p.dY;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(&dyt[wave][u][0]), 16, 0, 0);
+            if constexpr (FUSE) {
+                const bf16_t* ysrc = live ? p.y + (st * 16 + d_row) * (int64_t)p.ldy + d_slot * 8 : p.y;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)ysrc, (lds_void_t*)(&yt[wave][u][0]), 16, 0, 0);
+            }
             const int base = (cn * 3 * H + coh) * W + cow;
             const bool rowok = live && kok && (unsigned)(coh + r - 1) < (unsigned)H;
             const int iw0 = cow + h * 8 + s - 1;                   // column of this lane's first element
@@ -249,7 +265,29 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const StemWgradParam
             const unsigned char* a = &dyt[wave][u][0] + fr_off;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
-            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            if constexpr (FUSE) {
+                const unsigned char* ya = &yt[wave][u][0] + fr_off;
+                const s16x4 ylo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ya);
+                const s16x4 yhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ya + 256));
+                const uint4 dq = __builtin_bit_cast(uint4, af);
+                const uint4 yq = __builtin_bit_cast(uint4, __builtin_shufflevector(ylo, yhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const unsigned dd[4] = {dq.x, dq.y, dq.z, dq.w}, yy[4] = {yq.x, yq.y, yq.z, yq.w};
+                unsigned oo[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float r2[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const float d = __uint_as_float(hh ? (dd[q] & 0xffff0000u) : (dd[q] << 16));
+                        const float a = __uint_as_float(hh ? (yy[q] & 0xffff0000u) : (yy[q] << 16));
+                        const float g = d * act_bwd(a * bn_sc + bn_sh, p.act);
+                        r2[hh] = bn_sc * g + bn_A * a + bn_B;
+                    }
+                    oo[q] = pack_bf2(r2[0], r2[1]);
+                }
+                af = __builtin_bit_cast(bf16x8, make_uint4(oo[0], oo[1], oo[2], oo[3]));
+            }
             float w[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) w[e] = (okm[u] >> e) & 1u ? v[u][e] : 0.f;   // dead steps: mask 0 -> contribute nothing
@@ -311,7 +349,12 @@ extern "C" int ryolo_stem3x3_wgrad(const StemWgradParams* pp, hipStream_t stream
     const StemWgradParams& p = *pp;
     if (!stem_ok(p.NB, p.H, p.W, p.Cout) || p.Cout != 32 || p.W % 16 || p.ldY % 8) return RY_ERR_UNSUPPORTED;
     const int nb = stem_blocks((int64_t)p.NB * p.H * p.W);
-    hipLaunchKernelGGL(stem3x3_wgrad_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, p.workspace);
+    if (p.y) {
+        if (!p.co || !p.bco || p.ldy % 8) return RY_ERR_ARG;
+        hipLaunchKernelGGL(stem3x3_wgrad_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, p, p.workspace);
+    } else {
+        hipLaunchKernelGGL(stem3x3_wgrad_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, p, p.workspace);
+    }
     float* part = p.workspace + (size_t)nb * 1024;                 // two-level fold: 64 groups, then one
     hipLaunchKernelGGL(stem_fold_kernel, dim3(64), dim3(1024), 0, stream, p.workspace, nb, part);
     hipLaunchKernelGGL(stem_fold_kernel, dim3(1), dim3(1024), 0, stream, part, 64, p.scratch);

@@ -342,16 +342,24 @@ class Graph:
             self._call(self.fwd, "ryolo_stem3x3_fwd", p)
             self._img_structs.append(p)
 
-            def backward(need_dx=False):
+            def backward(need_dx=False, fuse=None):
+                """fuse = (dz TRef, coeffs [4][C], bco, act code): BatchNorm + activation backward applied inside the kernel (the raw
+                gradient of this layer, the largest activation of the network, is never materialised)."""
                 scratch = self.f32(cout, kp)
                 ws = self.f32(wsb.value // 4)
                 q = S.StemWgradParams()
                 q.img, q.NB, q.H, q.W = self.img.data_ptr(), self.B, self.Hin, self.Win
-                q.dY, q.ldY, q.Cout = y.gptr(), y.ld, cout
+                if fuse is not None:
+                    dz, co4, bco, actc = fuse
+                    q.dY, q.ldY, q.Cout = dz.gptr(), dz.ld, cout
+                    q.y, q.ldy, q.act, q.co, q.bco = y.ptr(), y.ld, actc, co4.data_ptr(), bco.data_ptr()
+                else:
+                    q.dY, q.ldY, q.Cout = y.gptr(), y.ld, cout
                 q.scratch, q.workspace = scratch.data_ptr(), ws.data_ptr()
                 self._call(self.bwd, "ryolo_stem3x3_wgrad", q)
                 self._img_structs.append(q)
                 self._call(self.bwd, "ryolo_unpack_wgrad", scratch.data_ptr(), cout, 3, k * k, kp, rt.grad_ptr(conv.weight))
+            backward.can_fuse_bn = True
             return y, stats, backward
         col = self.new(self.B, OH, OW, kp)
         self._call(self.fwd, "ryolo_im2col", self.img.data_ptr(), self.B, 3, self.Hin, self.Win, k, k, s, pad, OH, OW, kp, col.ptr())
@@ -421,12 +429,18 @@ class Graph:
                 q = S.BnActParams()
                 C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
                 q.dz, q.lddz = z.gptr(), z.ld
-                q.dy1, q.lddy1 = y.gptr(), y.ld
+                # direct stem: the apply pass moves into the weight-gradient kernel (its only consumer); here statistics only
+                fuse_stem = stem and residual is None and getattr(conv_bwd, "can_fuse_bn", False) and rt.fuse_stem_bn
+                if not fuse_stem:
+                    q.dy1, q.lddy1 = y.gptr(), y.ld
                 if residual is not None:
                     q.dres, q.lddres, q.dres_accum = residual.gptr(), residual.ld, residual.grad_write_mode()
                 q.partial = partial.data_ptr()
                 self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn.weight), rt.grad_ptr(bn.bias), None, None, bco.data_ptr(), 1 if self.frozen else 0)
-                conv_bwd(need_dx=not stem)
+                if fuse_stem:
+                    conv_bwd(need_dx=False, fuse=(z, co, bco, actc))
+                else:
+                    conv_bwd(need_dx=not stem)
             self._pending_bwd.append(backward)
         return z
 

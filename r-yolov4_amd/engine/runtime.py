@@ -30,6 +30,7 @@ class Runtime:
         # bits 0-7: generic mainloop (1 LDS-DMA ring [default], 0 register staged);
         # 0x200: 3x3 stride-1 layers run the halo-patch kernel (csrc/conv3x3.hip)
         self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200)), 0)
+        self.fuse_stem_bn = os.environ.get("RYOLO_FUSE_STEM_BN", "1") != "0"      # BN + act backward applied inside the stem wgrad kernel
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
 
     # ------------------------------------------------------------------ parameters

@@ -35,7 +35,8 @@ class StemParams(C.Structure):
 
 
 class StemWgradParams(C.Structure):
-    _fields_ = [("img", P), ("NB", I), ("H", I), ("W", I), ("dY", P), ("ldY", I), ("Cout", I), ("scratch", P), ("workspace", P)]
+    _fields_ = [("img", P), ("NB", I), ("H", I), ("W", I), ("dY", P), ("ldY", I), ("Cout", I), ("scratch", P), ("workspace", P),
+                ("y", P), ("ldy", I), ("act", I), ("co", P), ("bco", P)]
 
 
 class BnActParams(C.Structure):

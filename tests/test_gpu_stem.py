@@ -70,3 +70,33 @@ def test_stem_wgrad(B, H, W):
     ref = w0.grad.permute(0, 2, 3, 1).reshape(32, 27)
     assert float((scratch[:, :27] - ref).norm() / ref.norm()) < 2e-3
     assert float(scratch[:, 27:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ver", ["yolov7", "yolov4"])
+def test_stem_wgrad_with_fused_bn_backward_matches_the_unfused_plan(ver):
+    """BatchNorm + activation backward applied INSIDE the stem weight-gradient kernel (StemWgradParams.y set; SiLU for yolov7, Mish
+    for yolov4) vs the plan that materialises the raw gradient with ryolo_bn_act_bwd's apply pass: same algebra, same bf16 rounding
+    point -> the first conv's weight gradient and its BatchNorm gradients agree to 2e-3 relative (an FMA-contraction difference may
+    flip a bf16 ulp here and there), everything downstream is untouched."""
+    from ryolov4_amd.lib.loss import ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, HYP, fill_state, synth_targets
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(11)).cuda()
+    tg = synth_targets(2, 6, 2, False, seed=2, img_size=96).cuda()
+    grads = []
+    for fuse in (True, False):
+        m = Yolo(2, CFG, "kfiou", ver)
+        m.load_state_dict(fill_state(m.state_dict()))
+        m.cuda().train()
+        m.runtime().fuse_stem_bn = fuse
+        crit = ComputeKFIoULoss(m, HYP)
+        loss, _ = crit(m(x, training=True), tg)
+        loss.backward()
+        names = [n for _, _, n in m.runtime().graph(2, 96, 96, True).bwd]
+        assert "ryolo_stem3x3_wgrad" in names
+        ps = list(m.parameters())
+        grads.append([ps[0].grad.clone(), ps[1].grad.clone(), ps[2].grad.clone(), ps[3].grad.clone()])
+    for a, b in zip(*grads):
+        assert a.abs().sum() > 0
+        err = float((a - b).norm() / b.norm())
+        assert err < 2e-3, err
