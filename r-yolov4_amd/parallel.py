@@ -22,7 +22,12 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if be == "nccl":
+            # bind the communicator to the device the caller selected (torch.cuda.set_device before this call): no rank -> GPU guessing
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(be, rank=rank, world_size=world, **kw)
     return rank, local, world
 
 
