@@ -44,9 +44,13 @@ __device__ __forceinline__ float act_d(float u, int act)
 }
 
 struct V8 { float v[8]; };
-__device__ __forceinline__ V8 ld8(const bf16_t* p)
+// Streaming access policy (same-box A/B on the whole step, yolov7 800^2 batch 64): these kernels touch every activation once or twice
+// and the tensors are far larger than L2 + Infinity Cache, so loads and stores are NONTEMPORAL (-1.45 ms/step: they stop evicting
+// what the neighbouring GEMMs re-read) — except the loads of the BN-backward REDUCE pass, whose two operands are read again by the
+// apply pass right after it (plain loads there: another -0.4 ms).
+typedef unsigned ew_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ V8 unpack8(const uint4 r)
 {
-    const uint4 r = *reinterpret_cast<const uint4*>(p);
     V8 o;
     o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
     o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
@@ -54,12 +58,16 @@ __device__ __forceinline__ V8 ld8(const bf16_t* p)
     o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
     return o;
 }
+__device__ __forceinline__ V8 ld8(const bf16_t* p)
+{
+    const ew_u32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const ew_u32x4*>(p));
+    return unpack8(make_uint4(rv.x, rv.y, rv.z, rv.w));
+}
+__device__ __forceinline__ V8 ld8_keep(const bf16_t* p) { return unpack8(*reinterpret_cast<const uint4*>(p)); }    // will be read again soon
 __device__ __forceinline__ void st8(bf16_t* p, const V8& a)
 {
-    uint4 r;
-    r.x = pack_bf2(a.v[0], a.v[1]); r.y = pack_bf2(a.v[2], a.v[3]);
-    r.z = pack_bf2(a.v[4], a.v[5]); r.w = pack_bf2(a.v[6], a.v[7]);
-    *reinterpret_cast<uint4*>(p) = r;
+    const ew_u32x4 rv = {pack_bf2(a.v[0], a.v[1]), pack_bf2(a.v[2], a.v[3]), pack_bf2(a.v[4], a.v[5]), pack_bf2(a.v[6], a.v[7])};
+    __builtin_nontemporal_store(rv, reinterpret_cast<ew_u32x4*>(p));
 }
 
 // ------------------------------------------------------------------------------------------------ partial-row folding
@@ -226,8 +234,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
                 // Infinity Cache, and the forward-sweeping apply pass then starts on what this pass read last (measured: -0.3 ms/step;
                 // reversing the apply or the forward pass instead: -0.15 / -0.05 ms)
                 const int64_t m = p.M - 1 - mf;
-                const V8 d = ld8(p.dz + m * p.lddz + c);
-                const V8 a = ld8(p.y1 + m * p.ld1 + c);
+                const V8 d = ld8_keep(p.dz + m * p.lddz + c);
+                const V8 a = ld8_keep(p.y1 + m * p.ld1 + c);
                 V8 b;
                 if (Y2) b = ld8(p.y2 + m * p.ld2 + c);
 #pragma unroll
