@@ -92,6 +92,18 @@ def pmc_traffic(args):
     return res
 
 
+def pmc_step_bytes(args):
+    """HBM bytes of ONE training step summed over every kernel of the committed PMC profile (NMS timing kernels excluded)."""
+    if (args.ver, args.mode, args.size, args.nc, args.batch) != ("yolov7", "kfiou", 800, 16, 64):
+        return 0
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_step_traffic.json")
+    if not os.path.exists(path):
+        return 0
+    doc = json.load(open(path))
+    steps = doc.get("steps_profiled", 3)
+    return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in doc["kernels"].items() if not k.startswith("nms_")) / steps)
+
+
 def cpu_baseline(args, budget_s=25.0):
     """The oracle restatement (oracle/ref_model.py + ref_ops.py, pinned to the imported reference by the golden fixtures)
     doing the same training step on the host cores: fp32, SGD nesterov.  Bounded sample: batch 1, at most 2 steps."""
@@ -215,6 +227,11 @@ def main():
     if gf:
         out["config"]["train_gflop_per_img"] = gf
         out["mfma_roofline_frac_whole_step"] = round(value * gf * 1e9 / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
+    step_bytes = pmc_step_bytes(args)
+    if step_bytes and world == 1:
+        # whole-step HBM view: PMC bytes of every kernel of one step (committed profile of THIS workload) over the measured step time
+        out["hbm_whole_step"] = {"traffic_gb_per_step": round(step_bytes / 1e9, 1), "achieved_gbs": round(step_bytes / (dt / args.steps) / 1e9, 1),
+                                 "peak_gbs": HBM_PEAK_GBS, "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
     if timer is not None:
         summ = timer.summary()
         pmc = pmc_traffic(args)
