@@ -730,54 +730,161 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 // pre [M][ldp] fp32 (head conv + bias) -> out [B, na, gs, gs, attrs] fp32, times ImplicitM (mul may be null)
 // One workgroup = one image x 128 cells x all anchors, a thread owns channels ch = tid, tid + 256, ...: pre rows are read whole and
 // contiguous, the outputs of one anchor are contiguous runs of cells x attrs floats; no index division per element.
+// Both head kernels move fp32 tensors between two layouts — GEMM rows [cell][na*attrs] and the reference's [na][cell][attrs] — whose
+// contiguous pieces are 88 bytes (attrs = 22) on one side: the direct version did 4-byte accesses on that side and ran at
+// 2.6-3.0 TB/s.  Here a tile of TC cells x all channels is staged in LDS, so BOTH sides use 16-byte accesses: whole rows of the
+// GEMM layout, and the (TC x attrs)-float run of each anchor, which is contiguous in the reference layout.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access at 4-byte alignment (runs start at odd offsets)
+static int head_tile_cells(int C) { int tc = 32; while (tc > 1 && ((size_t)tc * (C + 1) + C) * 4 > 60u * 1024u) tc >>= 1; return tc; }
+
 __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs,
-                                                              int na, int attrs, float* __restrict__ out)
+                                                              int na, int attrs, int TC, float* __restrict__ out)
 {
-    const int cells = gs * gs, C = na * attrs;
-    const int ncb = (cells + 127) / 128;
+    extern __shared__ float hl[];                              // t[TC][C + 1]
+    const int cells = gs * gs, C = na * attrs, LD = C + 1;
+    const int ncb = (cells + TC - 1) / TC;
     const int b = blockIdx.x / ncb, cb = blockIdx.x - b * ncb;
-    const int c0 = cb * 128;
-    const int ncell = min(128, cells - c0);
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-        const int a = ch / attrs, at = ch - a * attrs;
-        const float mv = mul ? mul[ch] : 1.f;
-        const float* src = pre + ((int64_t)b * cells + c0) * ldp + ch;
-        float* dst = out + (((int64_t)b * na + a) * cells + c0) * attrs + at;
-        for (int cell = 0; cell < ncell; cell++) dst[(int64_t)cell * attrs] = src[(int64_t)cell * ldp] * mv;
+    const int c0 = cb * TC;
+    const int ncell = min(TC, cells - c0);
+    const float* src = pre + ((int64_t)b * cells + c0) * ldp;
+    if (((C | ldp) & 3) == 0 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0) {
+        const int c4n = C >> 2;
+        for (int i = threadIdx.x; i < ncell * c4n; i += 256) {
+            const int cell = i / c4n, c4 = i - cell * c4n;
+            float4 v = *reinterpret_cast<const float4*>(src + (int64_t)cell * ldp + c4 * 4);
+            if (mul) { const float4 m = *reinterpret_cast<const float4*>(mul + c4 * 4); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+            float* t = hl + cell * LD + c4 * 4;
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < ncell * C; i += 256) {
+            const int cell = i / C, ch = i - cell * C;
+            hl[cell * LD + ch] = src[(int64_t)cell * ldp + ch] * (mul ? mul[ch] : 1.f);
+        }
+    }
+    __syncthreads();
+    const int run = ncell * attrs, nq = (run + 3) >> 2;
+    const float rattrs = 1.0f / (float)attrs;
+    for (int i = threadIdx.x; i < na * nq; i += 256) {
+        const int a = i / nq, q = i - a * nq;
+        const int e0 = q * 4;
+        float* dst = out + (((int64_t)b * na + a) * cells + c0) * attrs + e0;
+        float v[4];
+        int cell = (int)((float)e0 * rattrs);                     // e0 / attrs (exact after the two corrections; e0 < 32 * attrs)
+        if (cell * attrs > e0) cell--;
+        if ((cell + 1) * attrs <= e0) cell++;
+        int at = e0 - cell * attrs;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = (e0 + k < run) ? hl[cell * LD + a * attrs + at] : 0.f;
+            if (++at == attrs) { at = 0; cell++; }
+        }
+        if (e0 + 3 < run) { const f4u w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4u*>(dst) = w; }
+        else for (int k = 0; e0 + k < run; k++) dst[k] = v[k];
     }
 }
 
-// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand; columns >= na*attrs stay zero from allocation),
-// per-workgroup partial column sums of dpre (= bias gradient) and, with ImplicitM, of dout*pre.
-// One workgroup = one image x HEAD_CPB cells x ALL anchors; a thread owns output channels ch = tid, tid + 256, ... and walks the
-// cells: dpre / pre rows are written / read as whole contiguous rows (the first version gave every anchor its own workgroup: 44-byte
-// pieces of an 832-byte row from 18 different workgroups, plus an LDS float atomic per element), the dout runs of one anchor are
-// contiguous (cells x attrs floats), and the column sums need no cross-thread reduction at all.
+// backward: dout [B,na,gs,gs,attrs] fp32 -> dpre [M][ldd] bf16 (GEMM operand; columns >= na*attrs inside the last 8-channel chunk are
+// written as zeros, the rest stay zero from allocation), per-workgroup partial column sums of dpre (= bias gradient) and, with
+// ImplicitM, of dout*pre.  One workgroup = one image x HEAD_CPB cells, walked as sub-tiles of TC cells staged in LDS; the column sums
+// live in registers across the sub-tiles (4 channels x every other cell per thread), one partial row per workgroup as before.
 #define HEAD_CPB 128
 __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, int ldp,
-                                                              const float* __restrict__ mul, int B, int gs, int na, int attrs,
+                                                              const float* __restrict__ mul, int B, int gs, int na, int attrs, int TC,
                                                               bf16_t* __restrict__ dpre, int ldd, float* __restrict__ partial /*[nblk][2][C]*/)
 {
-    const int cells = gs * gs, C = na * attrs;
+    extern __shared__ float hl[];                              // t[TC][C + 1], then mulv[C]
+    const int cells = gs * gs, C = na * attrs, LD = C + 1;
+    float* const mulv = hl + TC * LD;
     const int ncb = (cells + HEAD_CPB - 1) / HEAD_CPB;
     const int b = blockIdx.x / ncb, cb = blockIdx.x - b * ncb;
-    const int c0 = cb * HEAD_CPB;
-    const int ncell = min(HEAD_CPB, cells - c0);
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-        const int a = ch / attrs, at = ch - a * attrs;
-        const float* src = dout + (((int64_t)b * na + a) * cells + c0) * attrs + at;
+    const int cbase = cb * HEAD_CPB;
+    const int nblock = min(HEAD_CPB, cells - cbase);
+    for (int ch = threadIdx.x; ch < C; ch += 256) mulv[ch] = mul ? mul[ch] : 1.f;
+    // column sums: thread (cl, c4) owns channels 4*c4 .. 4*c4+3 of the cells with (cell & 1) == cl; loop when C > 512
+    const int c4n = (C + 3) >> 2;
+    const int cl = threadIdx.x & 1, c4l = threadIdx.x >> 1;       // 128 channel-quad lanes x 2 cell lanes
+    constexpr int MAXQ = 4;                                       // C <= 2048
+    float sb[MAXQ][4], sm[MAXQ][4];
+#pragma unroll
+    for (int j = 0; j < MAXQ; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sb[j][k] = 0.f; sm[j][k] = 0.f; }
+    const float rattrs = 1.0f / (float)attrs;
+    const bool pre4 = mul && ((ldp & 3) == 0) && (reinterpret_cast<uintptr_t>(pre) & 15) == 0;
+    for (int s0 = 0; s0 < nblock; s0 += TC) {
+        const int c0 = cbase + s0, ncell = min(TC, nblock - s0);
         const int64_t m0 = (int64_t)b * cells + c0;
-        const float mv = mul ? mul[ch] : 1.f;
-        float sb = 0.f, sm = 0.f;
-        for (int cell = 0; cell < ncell; cell++) {
-            const float d = src[(int64_t)cell * attrs];
-            const bf16_t g = f2bf(d * mv);
-            dpre[(m0 + cell) * ldd + ch] = g;
-            sb += bf2f(g);                                      // bias gradient = column sum of the bf16 operand the wgrad GEMM reads
-            if (mul) sm += d * pre[(m0 + cell) * ldp + ch];
+        __syncthreads();                                          // previous sub-tile fully consumed (and mulv visible)
+        const int run = ncell * attrs, nq = (run + 3) >> 2;
+        for (int i = threadIdx.x; i < na * nq; i += 256) {
+            const int a = i / nq, q = i - a * nq;
+            const int e0 = q * 4;
+            const float* src = dout + (((int64_t)b * na + a) * cells + c0) * attrs + e0;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (e0 + 3 < run) { const f4u w = *reinterpret_cast<const f4u*>(src); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+            else for (int k = 0; e0 + k < run; k++) v[k] = src[k];
+            int cell = (int)((float)e0 * rattrs);
+            if (cell * attrs > e0) cell--;
+            if ((cell + 1) * attrs <= e0) cell++;
+            int at = e0 - cell * attrs;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (e0 + k < run) hl[cell * LD + a * attrs + at] = v[k];
+                if (++at == attrs) { at = 0; cell++; }
+            }
         }
-        partial[((int64_t)blockIdx.x * 2 + 0) * C + ch] = sb;
-        partial[((int64_t)blockIdx.x * 2 + 1) * C + ch] = sm;
+        __syncthreads();
+        // dpre rows: 8 channels = one 16-byte store
+        const int c8n = (C + 7) >> 3;
+        for (int i = threadIdx.x; i < ncell * c8n; i += 256) {
+            const int cell = i / c8n, c8 = i - cell * c8n;
+            const float* t = hl + cell * LD + c8 * 8;
+            float g[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) g[k] = (c8 * 8 + k < C) ? t[k] * mulv[c8 * 8 + k] : 0.f;
+            const uint4 w = make_uint4(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]), pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7]));
+            bf16_t* o = dpre + (m0 + cell) * ldd + c8 * 8;
+            if (c8 * 8 + 8 <= ldd && (reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<uint4*>(o) = w;
+            else for (int k = 0; k < 8 && c8 * 8 + k < C; k++) o[k] = f2bf(g[k]);
+        }
+        // column sums of this sub-tile
+#pragma unroll
+        for (int j = 0; j < MAXQ; j++) {
+            const int c4 = c4l + j * 128;
+            if (c4 >= c4n) break;
+            for (int cell = cl; cell < ncell; cell += 2) {
+                const float* t = hl + cell * LD + c4 * 4;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (mul) {
+                    const float* pp = pre + (m0 + cell) * ldp + c4 * 4;
+                    if (pre4 && c4 * 4 + 3 < C) { const float4 w = *reinterpret_cast<const float4*>(pp); pv[0] = w.x; pv[1] = w.y; pv[2] = w.z; pv[3] = w.w; }
+                    else for (int k = 0; k < 4 && c4 * 4 + k < C; k++) pv[k] = pp[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (c4 * 4 + k < C) {
+                        const float d = t[k];
+                        sb[j][k] += bf2f(f2bf(d * mulv[c4 * 4 + k]));      // bias gradient = column sum of the bf16 operand the wgrad GEMM reads
+                        sm[j][k] += d * pv[k];
+                    }
+                }
+            }
+        }
+    }
+    // fold the two cell lanes (adjacent lanes of one wave) and write the partial row
+#pragma unroll
+    for (int j = 0; j < MAXQ; j++) {
+        const int c4 = c4l + j * 128;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float a0 = sb[j][k] + __shfl_xor(sb[j][k], 1, 64);
+            const float a1 = sm[j][k] + __shfl_xor(sm[j][k], 1, 64);
+            if (cl == 0 && c4 < c4n && c4 * 4 + k < C) {
+                partial[((int64_t)blockIdx.x * 2 + 0) * C + c4 * 4 + k] = a0;
+                partial[((int64_t)blockIdx.x * 2 + 1) * C + c4 * 4 + k] = a1;
+            }
+        }
     }
 }
 
@@ -1141,8 +1248,10 @@ extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul
     if (!pre || !out) return RY_ERR_ARG;
     const int64_t total = (int64_t)B * na * gs * gs * attrs;
     if (total == 0) return RY_OK;
-    hipLaunchKernelGGL(head_finish_fwd_kernel, dim3((unsigned)(B * ry_cdiv((int64_t)gs * gs, 128))), dim3(256), 0, stream, pre, ldp, mul, B, gs, na,
-                       attrs, out);
+    const int TC = head_tile_cells(na * attrs);
+    const size_t lds = ((size_t)TC * (na * attrs + 1) + na * attrs) * sizeof(float);
+    hipLaunchKernelGGL(head_finish_fwd_kernel, dim3((unsigned)(B * ry_cdiv((int64_t)gs * gs, TC))), dim3(256), lds, stream, pre, ldp, mul, B, gs, na,
+                       attrs, TC, out);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -1157,7 +1266,10 @@ extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ld
     const int C = na * attrs;
     const int ncb = (int)ry_cdiv((int64_t)gs * gs, HEAD_CPB);
     int rows = B * ncb;
-    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(rows), dim3(256), 0, stream, dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd, scratch);
+    if (C > 2048) return RY_ERR_UNSUPPORTED;
+    const int TC = head_tile_cells(C);
+    const size_t lds = ((size_t)TC * (C + 1) + C) * sizeof(float);
+    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch);
     const float* part = fold_rows(scratch, rows, 2 * C, scratch + (int64_t)rows * 2 * C, stream);
     hipLaunchKernelGGL(head_grad_rows_kernel, dim3((unsigned)ry_cdiv(2 * C, 256)), dim3(256), 0, stream, part, rows, C, dbias, mul ? dmul : nullptr);
     RY_CHECK_LAUNCH();
