@@ -602,15 +602,11 @@ class Graph:
                            scratch.data_ptr())
                 rec["dout_slot"] = len(self.bwd) - 1   # first argument (dout pointer) is patched per call when the caller's grad is usable as is
                 self._wgrad(conv, _G, dpre.data_ptr(), coutp, xin)
-                self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, xin)
+                # ImplicitA: d(x + a)/dx = 1, so the data gradient is written straight into x's gradient (no buffer for xin's, no copy)
+                # and d/da is its column sum
+                self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, x)
                 if implicit_a is not None:
-                    self._call(self.bwd, "ryolo_colsum_bf16", xin.gptr(), xin.ld, M, x.C, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
-                    # d(x + a)/dx = 1: route the gradient through by copying the slice (x has a single consumer here)
-                    mode = x.grad_write_mode()
-                    assert mode == 0
-                    xg, xing = x, xin
-                    self.bwd.append((lambda *_a: (xg.buf.grad_tensor()[:, xg.c0:xg.c0 + xg.C].copy_(xing.buf.grad_tensor()[:, xing.c0:xing.c0 + xing.C]), 0)[1],
-                                     (), "implicit_a_grad_copy"))
+                    self._call(self.bwd, "ryolo_colsum_bf16", x.gptr(), x.ld, M, x.C, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
             self._pending_bwd.append(backward)
         return out
 
