@@ -224,7 +224,7 @@ extern "C" int ryolo_nms_rotated_batched(const float* boxes, const int32_t* coun
 {
     if (batch < 0 || nmax < 0 || !num_keep) return RY_ERR_ARG;
     if (batch == 0) return RY_OK;
-    if (nmax == 0) { hipMemsetAsync(num_keep, 0, sizeof(int32_t) * batch, stream); return RY_OK; }
+    if (nmax == 0) return hipMemsetAsync(num_keep, 0, sizeof(int32_t) * batch, stream) == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
     if (!boxes || !keep || !ws) return RY_ERR_ARG;
     if (nmax > 65536 * 8) return RY_ERR_UNSUPPORTED;
     size_t need;
