@@ -189,22 +189,34 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = None if args.no_kernel_timing else EventTimer()
     g = rt.graph(args.batch, args.size, args.size, True)
-    g.timer = timer
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: EXACTLY K steps, nothing else on the stream ---------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    g.timer = None
+    # ---- the same K steps again with a HIP-event pair around every conv launch (per-kernel durations for the rooflines).  Kept out
+    # of the timed region: ~600 event records per step cost ~3 % (measured 688 vs 710 img/s), the kernels themselves run unchanged
+    # (the durations agree with the rocprofv3 summary of the same command, profiles/).
+    timer, dt_inst = None, None
+    if not args.no_kernel_timing:
+        timer = EventTimer()
+        g.timer = timer
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_inst = time.perf_counter() - t1
+        g.timer = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,13 +261,15 @@ def main():
                     "algorithmic_bytes_per_launch": int(v["bytes"] / max(1, v["launches"])), "traffic": pmc.get(k),
                     "launches_per_step": v["launches"] // args.steps,
                     "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
-                    "share_of_step": round(v["seconds"] / dt, 4)}
-        # dominant kernel class by time inside the timed region (HIP events on the launch stream)
+                    "share_of_step": round(v["seconds"] / dt_inst, 4)}
+        # dominant kernel class by time (HIP events on the launch stream)
         out["roofline"] = roof(*max(summ.items(), key=lambda kv: kv[1]["seconds"]))
         # BASELINE.json north_star quotes the MFMA fraction of the 3x3 convs separately: the halo-patch kernel (fwd + dgrad)
         k33 = "conv3x3_patch_kernel<256x128>"
         if k33 in summ:
             out["roofline_3x3"] = roof(k33, summ[k33])
+        out["kernel_timing"] = {"how": "HIP events around every conv launch, on the launch stream, in a second pass of the same K steps right after the timed region",
+                                "ms_per_step_instrumented": round(dt_inst / args.steps * 1e3, 3)}
         out["kernels"] = {kk: {"tflops": round(vv["flops"] / vv["seconds"] / 1e12, 2), "ms_per_step": round(vv["seconds"] / args.steps * 1e3, 3),
                                "launches_per_step": vv["launches"] // args.steps} for kk, vv in summ.items()}
     # secondary metric of BASELINE.json: rotated-NMS latency at 10k boxes (device time, median of 30; clustered set, thr 0.65)
