@@ -7,7 +7,12 @@ Layout (DESIGN.md):
   engine/      the static-graph executor that drives the conv stack (forward + backward tapes, hipGraph capture)
   parallel.py  one-process-per-GPU data parallel (RCCL all-reduce over xGMI)
 """
+import os as _os
 import sys as _sys
+
+# Takes effect when this import precedes the first HIP call of the process (see bench.py): distinct hardware queues for the main,
+# weight-gradient and collective streams.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __all__ = ["install_dropin"]
 

@@ -25,6 +25,8 @@
 #include <type_traits>
 #include <stdlib.h>
 
+template <int N> __device__ __forceinline__ void gemm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 #define BK 32
@@ -250,9 +252,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             }
         };
         constexpr int LPS = NPA + NPB;                                        // DMA instructions per wave per stage (upper bound)
-        // NOTE: vmcnt counts issued instructions; pieces skipped by the wave-uniform `piece < PCS` test are skipped by every
-        // stage alike, and the counted waits below use the upper bound LPS only where at least that many were issued
-        // (PCS_A, PCS_B multiples of 4 for every instantiated tile except BN = 32, where the wait is simply a little stricter).
+        // vmcnt counts ISSUED instructions per wave.  When the piece count of a stage is not a multiple of 4 (BN = 32: two weight
+        // pieces for four waves) some waves issue fewer DMA instructions per stage than others, and "at most LPS outstanding" would let
+        // such a wave run ahead with one piece of the CURRENT stage still in flight (seen as a handful of garbage rows in 41 M: the
+        // layer-2 data gradient at batch 64).  Each wave therefore waits on its OWN per-stage count.
+        constexpr int LPS_LO = PCS_A / 4 + PCS_B / 4;                         // pieces every wave issues
+        constexpr int XTR = LPS - LPS_LO;                                     // 0, 1 or 2 wave-dependent extra pieces
+        const int extra = __builtin_amdgcn_readfirstlane((wave < PCS_A % 4 ? 1 : 0) + (wave < PCS_B % 4 ? 1 : 0));
+        auto wait_inflight = [&](auto stages) {                               // allow `stages` later stages to stay in flight
+            constexpr int S = decltype(stages)::value;
+            if constexpr (XTR == 0) { gemm_wait_vm<S * LPS>(); }
+            else {
+                if (extra == XTR) gemm_wait_vm<S * LPS>();
+                else if (XTR == 2 && extra == 1) gemm_wait_vm<S * (LPS_LO + 1)>();
+                else gemm_wait_vm<S * LPS_LO>();
+            }
+        };
 #pragma unroll
         for (int st = 0; st < NSTG - 1; st++)
             if (st < nk) {
@@ -267,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         for (int k = 0; k < nk; k++) {
             // stages allowed to stay in flight while stage k is consumed
             const int pend = min(NSTG - 2, nk - 1 - k);
-            if (NSTG >= 4 && pend >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            else if (NSTG >= 3 && pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            if (NSTG >= 4 && pend >= 2) wait_inflight(std::integral_constant<int, 2>{});
+            else if (NSTG >= 3 && pend == 1) wait_inflight(std::integral_constant<int, 1>{});
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                     // stage k visible to all waves; stage k-1 fully consumed
             const bool do_issue = k + NSTG - 1 < nk;

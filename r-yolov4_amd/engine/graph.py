@@ -96,6 +96,8 @@ class Graph:
         self.dev = rt.device
         self.fwd, self.bwd = [], []            # tapes: lists of (fn_name, args...) closures
         self.keep = []                         # tensors/structs kept alive
+        self.side_idx = set()                  # backward-tape entries launched on the weight-gradient stream
+        self._side = None                      # (stream, event pool)
         self.stream = None
         self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
         self._img_slot, self._img_structs = None, []
@@ -179,40 +181,53 @@ class Graph:
         return last
 
     def run(self, tape, timer=None, after=None):
-        """Replay a tape.  after: {tape index: callable} invoked right after that launch was enqueued (gradient-bucket hooks)."""
+        """Replay a tape.  after: {tape index: callable} invoked right after that launch was enqueued (gradient-bucket hooks).
+
+        Backward runs on TWO streams: the weight-gradient GEMMs (MFMA-bound, 22 ms of the step, results needed only by the optimizer)
+        go to a side stream behind an event, and overlap with the data-gradient / BatchNorm-backward chain of the earlier layers
+        (HBM-bound) that the main stream continues with.  The main stream joins the side stream before a gradient bucket is handed
+        to RCCL and at the end of the tape."""
         st = hip.stream()
-        if timer is None:
-            if after:
-                for i, (fn, args, name) in enumerate(tape):
-                    rc = fn(*args, st)
-                    if rc != 0:
-                        raise RuntimeError(f"{name} failed with code {rc}")
-                    cb = after.get(i)
-                    if cb is not None:
-                        cb()
-                return
-            for fn, args, name in tape:
-                rc = fn(*args, st)
-                if rc != 0:
-                    raise RuntimeError(f"{name} failed with code {rc}")
-            return
+        side_idx = self.side_idx if (tape is self.bwd and self.side_idx and self.dev.type == "cuda") else None
+        if side_idx:
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=self.dev), [torch.cuda.Event() for _ in range(len(tape))], torch.cuda.Event())
+            side, evs, join = self._side
+            main = torch.cuda.current_stream(self.dev)
+            sst = side.cuda_stream
         tid = id(tape)
+        dirty = False
         for i, (fn, args, name) in enumerate(tape):
-            kind, fl, by = self.meta.get((tid, i), (name, 0, 0))
+            on_side = side_idx is not None and i in side_idx
+            if on_side:
+                evs[i].record(main)
+                side.wait_event(evs[i])
+                dirty = True
+            kind, fl, by = self.meta.get((tid, i), (name, 0, 0)) if timer is not None else (name, 0, 0)
             if fl:
                 e0, e1 = timer.pair()
-                e0.record()
-                rc = fn(*args, st)
-                e1.record()
+                e0.record(side if on_side else None)
+                rc = fn(*args, sst if on_side else st)
+                e1.record(side if on_side else None)
                 timer.note(kind, fl, e0, e1, by)
             else:
-                rc = fn(*args, st)
+                rc = fn(*args, sst if on_side else st)
             if rc != 0:
                 raise RuntimeError(f"{name} failed with code {rc}")
             if after:
                 cb = after.get(i)
                 if cb is not None:
+                    if dirty:
+                        # the bucket may hold gradients written on the side stream: the hook's collective stream waits for this
+                        # event as well (parallel._Reducer._launch); the main stream is NOT stalled
+                        join.record(side)
+                        self.rt.side_event = join
                     cb()
+                    self.rt.side_event = None
+        if dirty:
+            join.record(side)
+            main.wait_event(join)
+        self.rt.side_event = None
 
     # ------------------------------------------------------------------ convolution
     def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,
@@ -286,15 +301,20 @@ class Graph:
         for i, (dh, dw, _) in enumerate(taps):
             p.dh[i], p.dw[i] = dh, dw
         p.dW = self.rt.grad_ptr(conv.weight)
-        self._emit_wgrad(p)
+        self._emit_wgrad(p, side=True)
 
-    def _emit_wgrad(self, p):
+    def _emit_wgrad(self, p, side=False):
+        """side: the launch may run on the weight-gradient stream (see run()): nothing on the main stream reads what it writes (the
+        split-K slabs and .grad) before the end of backward, and what it reads (a forward activation, the raw gradient of its own
+        output) is final by the time it is enqueued."""
         p.zeros = self.rt.zeros.data_ptr()
         sk, need = S.I(), S.Z()
         hip.call("ryolo_conv_wgrad_plan", p, sk, need)
         self._wgrad_ws_bytes = max(self._wgrad_ws_bytes, need.value)
         self._wgrads.append(p)
         self._call(self.bwd, "ryolo_conv_wgrad", p)
+        if side and self.rt.wgrad_stream:
+            self.side_idx.add(len(self.bwd) - 1)
 
     def conv_raw(self, conv, x, want_stats, fused=None):
         """Emit the forward conv; returns (y TRef [M, Cout] raw bf16, stats tensor or None, backward-emitter).

@@ -31,6 +31,8 @@ class Runtime:
         # 0x200: 3x3 stride-1 layers run the halo-patch kernel (csrc/conv3x3.hip)
         self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200)), 0)
         self.fuse_stem_bn = os.environ.get("RYOLO_FUSE_STEM_BN", "1") != "0"      # BN + act backward applied inside the stem wgrad kernel
+        self.side_event = None            # set by Graph.run around a gradient-bucket hook: event of the weight-gradient stream
+        self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
 
     # ------------------------------------------------------------------ parameters

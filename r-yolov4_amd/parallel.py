@@ -103,6 +103,9 @@ class _Reducer:
             ev.record(torch.cuda.current_stream(view.device))
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
+                se = getattr(rt, "side_event", None)          # weight gradients of this bucket still running on the engine's
+                if se is not None:                            # second stream (Graph.run): the collective waits for them too
+                    self.side.wait_event(se)
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM)

@@ -284,3 +284,35 @@ torch.save([o.cpu() for o in outs], "/tmp/_rep_%s.pt" % __import__("os").environ
     for fa, fb in zip(a, b):
         assert rel(fa, fb) < 6e-3, rel(fa, fb)
         assert not torch.equal(fa, fb)                       # the fold really ran (different rounding), not the same plan twice
+
+
+def test_full_size_training_steps_stay_finite():
+    """The bench configuration itself (yolov7 kfiou nc=16, 800x800, batch 64, train.py's N(0, 0.02) init, SGD lr 0.01): three
+    full training steps; every gradient of the first backward is finite, the gradient of the largest activation (stem output,
+    41 M rows) has no stray values, and the loss is still finite after the updates.  Regression test for a per-wave vmcnt
+    accounting race in the generic LDS-DMA GEMM ring (BN = 32 tiles: a handful of garbage rows in 41 M at this size only)."""
+    import bench
+    from ryolov4_amd.lib.loss import ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import synth_batch
+    torch.manual_seed(42)
+    m = Yolo(16, CFG, "kfiou", "yolov7")
+    m.apply(bench.weights_init_normal)
+    m.to(DEV).train()
+    rt = m.runtime()
+    crit = ComputeKFIoULoss(m, HYP)
+    imgs, tg = synth_batch(64, 800, 16, False, seed=42)
+    imgs, tg = imgs.to(DEV), tg.to(DEV)
+    losses = []
+    for step in range(3):
+        loss, _ = crit(m(imgs, training=True), tg)
+        loss.backward()
+        if step == 0:
+            bad = [n for n, p in m.named_parameters() if not torch.isfinite(p.grad).all()]
+            assert not bad, bad[:5]
+            y, z, x = rt.graph(64, 800, 800, True).debug[id(m.backbone.cbs0.conv[0])]
+            assert float(z.buf.grad_tensor().float().abs().max()) < 1.0          # 4e-4 when every row is written; garbage was 1e23+
+        rt.sgd_step(0.01)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)), losses
+    assert bool(torch.isfinite(rt.flat).all())
