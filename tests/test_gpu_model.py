@@ -316,3 +316,39 @@ def test_full_size_training_steps_stay_finite():
         losses.append(float(loss))
     assert all(np.isfinite(losses)), losses
     assert bool(torch.isfinite(rt.flat).all())
+
+
+@pytest.mark.parametrize("ver,mode,size,nc", [("yolov7", "kfiou", 800, 16), ("yolov4", "csl", 608, 2), ("yolov5", "kfiou", 800, 16)])
+def test_full_size_training_step_is_bitwise_deterministic(ver, mode, size, nc):
+    """Two independent runs of the bench configuration's first training step (same seed, fresh model, fresh buffers) produce
+    bit-identical gradients and head maps.  Every kernel of the step is deterministic by construction (fixed-order partial sums, no
+    float atomics), so ANY difference is a race: a missed wait in an LDS-DMA ring, a hazard between the two backward streams, a read
+    of an unwritten row.  Small-size parity tests cannot see those (the one found this round corrupted 2 rows in 41 M)."""
+    import bench
+    from ryolov4_amd.lib.loss import ComputeCSLLoss, ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import synth_batch
+    imgs, tg = synth_batch(64, size, nc, mode == "csl", seed=42)
+    imgs, tg = imgs.to(DEV), tg.to(DEV)
+    res = []
+    for run in range(2):
+        torch.manual_seed(42)
+        m = Yolo(nc, CFG, mode, ver)
+        m.apply(bench.weights_init_normal)
+        m.to(DEV).train()
+        crit = (ComputeCSLLoss if mode == "csl" else ComputeKFIoULoss)(m, HYP)
+        if run == 1:
+            junk = torch.full((1 << 28,), float("nan"), device=DEV)      # shift the allocator: run 2 gets different (dirty) memory
+        outs = m(imgs, training=True)
+        heads = [o.clone() for o in outs]
+        loss, _ = crit(outs, tg)
+        loss.backward()
+        res.append((heads, m.runtime().gflat.clone(), float(loss)))
+        del m, crit, outs
+        torch.cuda.empty_cache()
+    (ha, ga, la), (hb, gb, lb) = res
+    assert la == lb
+    for a, b in zip(ha, hb):
+        assert torch.equal(a, b)
+    assert torch.isfinite(ga).all()
+    assert torch.equal(ga, gb), float((ga - gb).abs().max())
