@@ -352,3 +352,29 @@ def test_full_size_training_step_is_bitwise_deterministic(ver, mode, size, nc):
         assert torch.equal(a, b)
     assert torch.isfinite(ga).all()
     assert torch.equal(ga, gb), float((ga - gb).abs().max())
+
+
+def test_full_size_inference_is_bitwise_deterministic():
+    """BASELINE config C5 per GPU (yolov7 kfiou, 1024x1024, batch 8): eval plan (folded BN epilogues, re-parameterised RepConv) +
+    decode + post_process, twice on fresh models / dirty memory: identical detections."""
+    from ryolov4_amd.lib.general import post_process
+    from ryolov4_amd.model.yolo import Yolo
+    x = torch.rand(8, 3, 1024, 1024, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = []
+    for run in range(2):
+        m = Yolo(16, CFG, "kfiou", "yolov7")
+        m.load_state_dict(fill_state(m.state_dict()))
+        m.to(DEV).eval()
+        if run == 1:
+            junk = torch.full((1 << 27,), float("nan"), device=DEV)
+        with torch.no_grad():
+            _, inf = m(x, training=False)
+            inf = inf.clone()
+            dets = post_process(inf.clone(), 0.05, 0.4)
+        res.append((inf, dets))
+        del m
+        torch.cuda.empty_cache()
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
+    assert sum(d.shape[0] for d in res[0][1]) > 0
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
