@@ -733,7 +733,8 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.gx = (int)ry_cdiv(p.Cout, 128);
     g.gc = p.Cin / 32;
     if (g.Mp >= (1ll << 31)) return false;                        // 32-bit stream coordinates
-    int64_t sk = ry_cdiv(512, (int64_t)g.gx * g.gc);             // 2 resident workgroups x 256 CUs
+    static const int w3_target = getenv("RYOLO_W3_BLOCKS") ? atoi(getenv("RYOLO_W3_BLOCKS")) : 512;   // 2 resident workgroups x 256 CUs (A/B knob)
+    int64_t sk = ry_cdiv(w3_target, (int64_t)g.gx * g.gc);
     static const int minsteps = getenv("RYOLO_W3_MINSTEPS") ? atoi(getenv("RYOLO_W3_MINSTEPS")) : 24;   // measured 24 / 48 / 128: shorter splits fill the chip, the two-halo prologue still amortises
     const int64_t maxsplit = g.Mp / ((int64_t)minsteps * 32);      // K-steps per split: the ring prologue (2 halos) must amortise
     if (sk > maxsplit) sk = maxsplit;
