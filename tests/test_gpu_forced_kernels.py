@@ -13,6 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_block_and_network_parity_with_3x3_kernels_forced():
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()                       # the child process cannot reuse this process's cached blocks
     env = dict(os.environ, RYOLO_GEMM_PIPE="0x601", RYOLO_W3_FORCE="1")           # 0x200 patch kernel, 0x400 also for small grids
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "-q", "-m", "gpu", "-x",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
