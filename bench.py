@@ -224,15 +224,15 @@ def main():
     if not args.no_kernel_timing:
         timer = EventTimer()
         g.timer = timer
-        side_idx, g.side_idx = g.side_idx, set()          # every kernel alone on the GPU: the weight-gradient stream is folded back
-        barrier()                                         # into the main stream for this pass (overlapped kernels stretch each other)
+        g.serial = True                                   # every kernel alone on the GPU: the second stream is folded back into
+        barrier()                                         # the main stream for this pass (overlapped kernels stretch each other)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         dt_inst = time.perf_counter() - t1
         g.timer = None
-        g.side_idx = side_idx
+        g.serial = False
     loss_last = read_loss()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -97,6 +97,9 @@ class Graph:
         self.fwd, self.bwd = [], []            # tapes: lists of (fn_name, args...) closures
         self.keep = []                         # tensors/structs kept alive
         self.side_idx = set()                  # backward-tape entries launched on the weight-gradient stream
+        self.fwd_side = {}                     # forward-tape index -> True for the first entry of a forked branch, False for the rest
+        self.fwd_join = set()                  # forward-tape indices before which the main stream joins the forked branch
+        self.serial = False                    # True: everything on the main stream (per-kernel timing passes)
         self._side = None                      # (stream, event pool)
         self.stream = None
         self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
@@ -120,6 +123,29 @@ class Graph:
         t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.dev)
         self.keep.append(t)
         return t
+
+    def side_branch(self):
+        """`with g.side_branch(): <emit one branch of a block>` — the forward launches emitted inside run on the second stream, forked
+        from the main stream at the point of entry (they may read anything produced before it) while the main stream goes on with the
+        sibling branch; `g.join_side()` makes the main stream wait for them (call it before the consumer of the branch's output is
+        emitted).  Branches write disjoint channel slices of the concat buffer and own their statistics buffers: no ordering
+        between them is needed.  Backward is unaffected (its tape is serial on the main stream but for the weight gradients)."""
+        g = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.start = len(g.fwd)
+
+            def __exit__(self_, *exc):
+                if g.rt.fwd_fork:
+                    for i in range(self_.start, len(g.fwd)):
+                        g.fwd_side[i] = (i == self_.start)
+                return False
+        return _Ctx()
+
+    def join_side(self):
+        if self.fwd_side:
+            self.fwd_join.add(len(self.fwd))
 
     def _call(self, tape, name, *args):
         """args may contain ctypes structs (passed by reference); the stream is appended at run time."""
@@ -188,21 +214,41 @@ class Graph:
         (HBM-bound) that the main stream continues with.  The main stream joins the side stream before a gradient bucket is handed
         to RCCL and at the end of the tape."""
         st = hip.stream()
-        side_idx = self.side_idx if (tape is self.bwd and self.side_idx and self.dev.type == "cuda") else None
-        if side_idx:
+        cuda = self.dev.type == "cuda" and not self.serial
+        side_idx = self.side_idx if (tape is self.bwd and self.side_idx and cuda) else None
+        fork = self.fwd_side if (tape is self.fwd and self.fwd_side and cuda) else None
+        if side_idx or fork:
             if self._side is None:
-                self._side = (torch.cuda.Stream(device=self.dev), [torch.cuda.Event() for _ in range(len(tape))], torch.cuda.Event())
+                n = max(len(self.fwd), len(self.bwd)) + 1
+                self._side = (torch.cuda.Stream(device=self.dev), [torch.cuda.Event() for _ in range(2 * n)], torch.cuda.Event())
             side, evs, join = self._side
+            n_ev = len(evs) // 2
             main = torch.cuda.current_stream(self.dev)
             sst = side.cuda_stream
         tid = id(tape)
-        dirty = False
+        dirty, pending = False, None
         for i, (fn, args, name) in enumerate(tape):
-            on_side = side_idx is not None and i in side_idx
-            if on_side:
-                evs[i].record(main)
-                side.wait_event(evs[i])
-                dirty = True
+            on_side = False
+            if side_idx is not None:
+                on_side = i in side_idx
+                if on_side:                          # a weight gradient: its operands are final once everything before it ran
+                    evs[i].record(main)
+                    side.wait_event(evs[i])
+                    dirty = True
+            elif fork is not None:
+                if dirty and i in self.fwd_join:     # snapshot of the side stream at the join point (later forks are not waited for)
+                    pending = evs[n_ev + i]
+                    pending.record(side)
+                first = fork.get(i)
+                on_side = first is not None
+                if on_side:
+                    if first:                        # fork point of a branch: it may read everything enqueued so far
+                        evs[i].record(main)
+                        side.wait_event(evs[i])
+                    dirty = True
+                elif pending is not None:            # first main-stream launch after a join point
+                    main.wait_event(pending)
+                    pending = None
             kind, fl, by = self.meta.get((tid, i), (name, 0, 0)) if timer is not None else (name, 0, 0)
             if fl:
                 e0, e1 = timer.pair()

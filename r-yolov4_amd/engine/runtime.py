@@ -32,6 +32,7 @@ class Runtime:
         self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200)), 0)
         self.fuse_stem_bn = os.environ.get("RYOLO_FUSE_STEM_BN", "1") != "0"      # BN + act backward applied inside the stem wgrad kernel
         self.side_event = None            # set by Graph.run around a gradient-bucket hook: event of the weight-gradient stream
+        self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
 

@@ -124,10 +124,12 @@ class ELAN1(nn.Module):                 # model/utils.py:98-118
     def emit(self, g, x, out=None):
         h1, h2 = self.h1, self.h2
         cat = g.new(x.N, x.H, x.W, 2 * (h1 + h2))
-        self.cv1.emit(g, x, out=cat.slice(0, h1))
+        with g.side_branch():                               # cv1 is independent of the cv2 -> ... -> cv6 chain
+            self.cv1.emit(g, x, out=cat.slice(0, h1))
         x2 = self.cv2.emit(g, x, out=cat.slice(h1, h1))
         x3 = self.cv4.emit(g, self.cv3.emit(g, x2), out=cat.slice(2 * h1, h2))
         self.cv6.emit(g, self.cv5.emit(g, x3), out=cat.slice(2 * h1 + h2, h2))
+        g.join_side()
         return self.cv7.emit(g, cat, out=out)
 
 
@@ -147,10 +149,12 @@ class ELAN2(nn.Module):                 # model/utils.py:121-143
     def emit(self, g, x, out=None):
         h1, h2 = self.h1, self.h2
         cat = g.new(x.N, x.H, x.W, 2 * h1 + 4 * h2)
-        self.cv1.emit(g, x, out=cat.slice(0, h1))
+        with g.side_branch():                               # cv1 is independent of the cv2 -> ... -> cv6 chain
+            self.cv1.emit(g, x, out=cat.slice(0, h1))
         y = self.cv2.emit(g, x, out=cat.slice(h1, h1))
         for i, m in enumerate((self.cv3, self.cv4, self.cv5, self.cv6)):
             y = m.emit(g, y, out=cat.slice(2 * h1 + i * h2, h2))
+        g.join_side()
         return self.cv7.emit(g, cat, out=out)
 
 
@@ -166,8 +170,10 @@ class MaxConv(nn.Module):               # model/utils.py:146-160
 
     def emit(self, g, x, out=None):
         cat = out if out is not None else g.new(x.N, x.H // 2, x.W // 2, 2 * self.h)
-        self.cv1.emit(g, g.maxpool(x, 2, 2), out=cat.slice(0, self.h))
+        with g.side_branch():                               # pool -> 1x1 beside 1x1 -> 3x3 stride 2
+            self.cv1.emit(g, g.maxpool(x, 2, 2), out=cat.slice(0, self.h))
         self.cv3.emit(g, self.cv2.emit(g, x), out=cat.slice(self.h, self.h))
+        g.join_side()
         return cat
 
 
