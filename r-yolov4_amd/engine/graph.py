@@ -101,6 +101,7 @@ class Graph:
         self.fwd_join = set()                  # forward-tape indices before which the main stream joins the forked branch
         self.serial = False                    # True: everything on the main stream (per-kernel timing passes)
         self._side = None                      # (stream, event pool)
+        self._side2 = None                     # (stream, join event) of forward lane 2
         self.stream = None
         self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
         self._img_slot, self._img_structs = None, []
@@ -124,7 +125,7 @@ class Graph:
         self.keep.append(t)
         return t
 
-    def side_branch(self):
+    def side_branch(self, lane=1):
         """`with g.side_branch(): <emit one branch of a block>` — the forward launches emitted inside run on the second stream, forked
         from the main stream at the point of entry (they may read anything produced before it) while the main stream goes on with the
         sibling branch; `g.join_side()` makes the main stream wait for them (call it before the consumer of the branch's output is
@@ -139,7 +140,7 @@ class Graph:
             def __exit__(self_, *exc):
                 if g.rt.fwd_fork:
                     for i in range(self_.start, len(g.fwd)):
-                        g.fwd_side[i] = (i == self_.start)
+                        g.fwd_side[i] = (i == self_.start, lane)
                 return False
         return _Ctx()
 
@@ -226,7 +227,7 @@ class Graph:
             main = torch.cuda.current_stream(self.dev)
             sst = side.cuda_stream
         tid = id(tape)
-        dirty, pending = False, None
+        dirty, dirty2, pending, lane_stream = False, False, None, None
         for i, (fn, args, name) in enumerate(tape):
             on_side = False
             if side_idx is not None:
@@ -235,26 +236,36 @@ class Graph:
                     evs[i].record(main)
                     side.wait_event(evs[i])
                     dirty = True
+                    lane_stream, sst = side, side.cuda_stream
             elif fork is not None:
                 if dirty and i in self.fwd_join:     # snapshot of the side stream at the join point (later forks are not waited for)
                     pending = evs[n_ev + i]
                     pending.record(side)
-                first = fork.get(i)
-                on_side = first is not None
+                ent = fork.get(i)
+                on_side = ent is not None
                 if on_side:
+                    first, lane = ent
+                    if lane == 2:                    # long independent tails (detection heads): their own stream, joined at the end
+                        if self._side2 is None:
+                            self._side2 = (torch.cuda.Stream(device=self.dev), torch.cuda.Event())
+                        lane_stream = self._side2[0]
+                        dirty2 = True
+                    else:
+                        lane_stream = side
+                        dirty = True
                     if first:                        # fork point of a branch: it may read everything enqueued so far
                         evs[i].record(main)
-                        side.wait_event(evs[i])
-                    dirty = True
+                        lane_stream.wait_event(evs[i])
+                    sst = lane_stream.cuda_stream
                 elif pending is not None:            # first main-stream launch after a join point
                     main.wait_event(pending)
                     pending = None
             kind, fl, by = self.meta.get((tid, i), (name, 0, 0)) if timer is not None else (name, 0, 0)
             if fl:
                 e0, e1 = timer.pair()
-                e0.record(side if on_side else None)
+                e0.record(lane_stream if on_side else None)
                 rc = fn(*args, sst if on_side else st)
-                e1.record(side if on_side else None)
+                e1.record(lane_stream if on_side else None)
                 timer.note(kind, fl, e0, e1, by)
             else:
                 rc = fn(*args, sst if on_side else st)
@@ -273,6 +284,9 @@ class Graph:
         if dirty:
             join.record(side)
             main.wait_event(join)
+        if dirty2:
+            self._side2[1].record(self._side2[0])
+            main.wait_event(self._side2[1])
         self.rt.side_event = None
 
     # ------------------------------------------------------------------ convolution

@@ -216,10 +216,12 @@ class Neckv7(nn.Module):                # model/neck.py:150-217
         self.conv4.emit(g, d3, out=cat3.slice(0, 128))
         g.upsample(self.conv2.emit(g, p4), out=cat3.slice(128, 128))
         p3 = self.elan2.emit(g, cat3)
-        o_small = self._det(g, 1, p3, na, attrs)
+        with g.side_branch(lane=2):                       # the heads are tails: nothing in the network reads them
+            o_small = self._det(g, 1, p3, na, attrs)
         self.mc1.emit(g, p3, out=cat4b.slice(256, 256))
         q4 = self.elan3.emit(g, cat4b)
-        o_mid = self._det(g, 2, q4, na, attrs)
+        with g.side_branch(lane=2):
+            o_mid = self._det(g, 2, q4, na, attrs)
         self.mc2.emit(g, q4, out=self.cat5.slice(512, 512))
         q5 = self.elan4.emit(g, self.cat5)
         o_big = self._det(g, 3, q5, na, attrs)
