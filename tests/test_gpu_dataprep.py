@@ -108,3 +108,35 @@ def test_polygon_converters_and_detect_path(golden_dir):
     exp_b = np.concatenate([g["det_sq_boxes"], g["det_wide_boxes"]]); exp_p = np.concatenate([g["det_sq_polys"], g["det_wide_polys"]])
     np.testing.assert_allclose(boxes.cpu().numpy(), exp_b, rtol=2e-6, atol=1e-4)
     np.testing.assert_allclose(polys.cpu().numpy(), exp_p, rtol=0, atol=2e-3)
+
+
+def test_detect_path_end_to_end_against_the_oracle_chain():
+    """detect.py:57-61 + Detect.save_results / plot_boxes up to the drawing: network (eval) -> post_process -> rescale_boxes ->
+    xywha2xyxyxyxy, on the device, against the oracle chain fed with the SAME inference tensor (ref_ops.post_process with the C NMS,
+    ref_data.rescale_boxes, ref_data.xywha2xyxyxyxy): identical detection sets, polygons within 2e-3 px."""
+    from oracle import ref_ops
+    from ryolov4_amd.lib.general import post_process
+    from ryolov4_amd.lib.plot import detections_to_polys
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, fill_state
+    m = Yolo(2, CFG, "kfiou", "yolov7")
+    m.load_state_dict(fill_state(m.state_dict()))
+    m.to(DEV).eval()
+    x = torch.rand(3, 3, 160, 160, generator=torch.Generator().manual_seed(8)).to(DEV)
+    with torch.no_grad():
+        _, inf = m(x, training=False)
+    inf_cpu = inf.cpu().clone()
+    dets = post_process(inf, 0.3, 0.4)
+    shapes = [(480, 640), (600, 600), (1000, 750)]                       # original image sizes of the three letterboxed inputs
+    boxes, polys, counts = detections_to_polys(dets, 160, shapes)
+    exp = ref_ops.post_process(inf_cpu, 0.3, 0.4)
+    assert counts == [int(e.shape[0]) for e in exp] and sum(counts) > 0
+    ofs = 0
+    for b, e in enumerate(exp):
+        n = e.shape[0]
+        np.testing.assert_allclose(dets[b].cpu().numpy(), e.numpy(), rtol=1e-5, atol=1e-5)
+        rb = ref_data.rescale_boxes(e.clone(), 160, shapes[b])
+        np.testing.assert_allclose(boxes[ofs:ofs + n].cpu().numpy(), rb.numpy(), rtol=2e-6, atol=1e-3)
+        if n:
+            np.testing.assert_allclose(polys[ofs:ofs + n].cpu().numpy(), ref_data.xywha2xyxyxyxy(rb[:, :5]).numpy(), rtol=0, atol=2e-3)
+        ofs += n
