@@ -140,3 +140,33 @@ def test_detect_path_end_to_end_against_the_oracle_chain():
         if n:
             np.testing.assert_allclose(polys[ofs:ofs + n].cpu().numpy(), ref_data.xywha2xyxyxyxy(rb[:, :5]).numpy(), rtol=0, atol=2e-3)
         ofs += n
+
+
+@pytest.mark.parametrize("mode", ["kfiou", "csl"])
+def test_finalize_batch_feeds_a_training_step(mode):
+    """The data-side tail hands train.py:183-198 what the reference's collate_fn does: images [B,3,S,S] fp32 in [0,1] and targets
+    [n, 7 | 187] whose first column is the sample index — one training step on them runs and yields finite loss and gradients."""
+    from ryolov4_amd.datasets.base_dataset import finalize_batch
+    from ryolov4_amd.lib.loss import ComputeCSLLoss, ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, HYP, fill_state
+    from tests.golden.make_golden_data import synth_polys
+    B, S, nc = 4, 128, 2
+    g = np.random.default_rng(3)
+    imgs = torch.from_numpy(g.integers(0, 256, (B, S, S, 3), dtype=np.uint8)).to(DEV)
+    t = np.zeros((B * 6, 10), np.float32)
+    t[:, 0] = np.repeat(np.arange(B), 6)
+    t[:, 1] = g.integers(0, nc, B * 6)
+    t[:, 2:] = synth_polys(g, B * 6, S)
+    x, tg = finalize_batch(imgs, torch.from_numpy(t).to(DEV), torch.tensor([0, 1, 2, 3], dtype=torch.uint8), mode == "csl")
+    assert x.shape == (B, 3, S, S) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+    assert tg.shape[1] == (187 if mode == "csl" else 7) and set(tg[:, 0].cpu().tolist()) <= set(range(B))
+    assert bool((tg[:, 5] >= tg[:, 4]).all()) and bool((tg[:, 6] >= -np.pi / 2).all()) and bool((tg[:, 6] < np.pi / 2).all())
+    m = Yolo(nc, CFG, mode, "yolov7")
+    m.load_state_dict(fill_state(m.state_dict()))
+    m.to(DEV).train()
+    crit = (ComputeCSLLoss if mode == "csl" else ComputeKFIoULoss)(m, HYP)
+    loss, items = crit(m(x, training=True), tg)
+    loss.backward()
+    assert np.isfinite(items["total_loss"]) and items["total_loss"] > 0
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
