@@ -1,0 +1,57 @@
+"""GPU: the fused optimizer step (ryolo_sgd_nesterov, csrc/elementwise.hip) against torch.optim.SGD(momentum=0.937, nesterov=True)
+(train.py:156,201-202), and the reference-style loop — torch.optim.SGD driving the engine's Parameters — against the fused loop."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("gscale,zero", [(1.0, True), (0.125, False)])
+def test_fused_sgd_nesterov_matches_torch_optim(gscale, zero):
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S    # noqa: F401
+    g = torch.Generator().manual_seed(0)
+    n = 4096 + 64
+    p0 = torch.randn(n, generator=g)
+    p = p0.clone().to(DEV)
+    buf = torch.zeros(n, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.937, nesterov=True)
+    for step in range(4):
+        grad = torch.randn(n, generator=g)
+        gd = grad.clone().to(DEV)
+        hip.call("ryolo_sgd_nesterov", p.data_ptr(), gd.data_ptr(), buf.data_ptr(), n, 0.01, 0.937, gscale, 1 if zero else 0, hip.stream())
+        ref.grad = grad * gscale
+        opt.step()
+        torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+        assert bool((gd == 0).all()) == zero                      # optimizer.zero_grad() fused into the same pass
+
+
+def test_torch_optim_sgd_on_engine_parameters_equals_the_fused_loop():
+    """train.py's own loop (optimizer = torch.optim.SGD(model.parameters(), ...); loss.backward(); optimizer.step();
+    optimizer.zero_grad()) on this build's Yolo, against model.runtime().sgd_step: same parameters after three steps (the
+    Parameters are views of the flat buffer either way; 1e-6: the fused kernel uses fma contraction differently)."""
+    from ryolov4_amd.lib.loss import ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, HYP, fill_state, synth_targets
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(1)).to(DEV)
+    tg = synth_targets(2, 6, 2, False, seed=2, img_size=96).to(DEV)
+    finals = []
+    for fused in (True, False):
+        m = Yolo(2, CFG, "kfiou", "yolov7")
+        m.load_state_dict(fill_state(m.state_dict()))
+        m.to(DEV).eval()
+        m.frozen_bn = True                                        # well-conditioned (see test_full_network_backward_frozen_bn)
+        crit = ComputeKFIoULoss(m, HYP)
+        opt = None if fused else torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+        for step in range(3):
+            loss, _ = crit(m(x, training=True), tg)
+            loss.backward()
+            if fused:
+                m.runtime().sgd_step(0.01, 0.937, zero_grad=True)
+            else:
+                opt.step()
+                opt.zero_grad(set_to_none=False)
+        finals.append(torch.cat([p.detach().flatten() for p in m.parameters()]).cpu())
+    torch.testing.assert_close(finals[0], finals[1], rtol=2e-5, atol=2e-6)
