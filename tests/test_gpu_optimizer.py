@@ -55,3 +55,30 @@ def test_torch_optim_sgd_on_engine_parameters_equals_the_fused_loop():
                 opt.zero_grad(set_to_none=False)
         finals.append(torch.cat([p.detach().flatten() for p in m.parameters()]).cpu())
     torch.testing.assert_close(finals[0], finals[1], rtol=2e-5, atol=2e-6)
+
+
+def test_gradient_accumulation_over_two_backwards_is_the_sum():
+    """train.py:192-202 accumulates gradients over `accumulate` iterations before optimizer.step(): two backward passes without
+    zeroing leave grad(batch 1) + grad(batch 2) in the flat gradient buffer (weight gradients run on their own stream; the second
+    backward's `+=` must land after the first's)."""
+    from ryolov4_amd.lib.loss import ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, HYP, fill_state, synth_targets
+    m = Yolo(2, CFG, "kfiou", "yolov7")
+    m.load_state_dict(fill_state(m.state_dict()))
+    m.to(DEV).eval()
+    m.frozen_bn = True
+    crit = ComputeKFIoULoss(m, HYP)
+    rt = m.runtime()
+    batches = [(torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(s)).to(DEV),
+                synth_targets(2, 6, 2, False, seed=s, img_size=96).to(DEV)) for s in (1, 2)]
+    singles = []
+    for x, tg in batches:
+        loss, _ = crit(m(x, training=True), tg)
+        loss.backward()
+        singles.append(rt.gflat.clone())
+        rt.gflat.zero_()
+    for x, tg in batches:
+        loss, _ = crit(m(x, training=True), tg)
+        loss.backward()
+    torch.testing.assert_close(rt.gflat, singles[0] + singles[1], rtol=1e-5, atol=1e-7)
