@@ -59,7 +59,7 @@ def test_full_size_training_steps_stay_finite():
     assert bool(torch.isfinite(rt.flat).all())
 
 
-@pytest.mark.parametrize("ver,mode,size,nc", [("yolov7", "kfiou", 800, 16), ("yolov4", "csl", 608, 2), ("yolov5", "kfiou", 800, 16)])
+@pytest.mark.parametrize("ver,mode,size,nc", [("yolov7", "kfiou", 800, 16), ("yolov7", "csl", 800, 16), ("yolov4", "csl", 608, 2), ("yolov5", "kfiou", 800, 16)])
 def test_full_size_training_step_is_bitwise_deterministic(ver, mode, size, nc):
     """Two independent runs of the bench configuration's first training step (same seed, fresh model, fresh buffers) produce
     bit-identical gradients and head maps.  Every kernel of the step is deterministic by construction (fixed-order partial sums, no
