@@ -77,3 +77,34 @@ def test_pretrained_first_552_entries_rule(ver):
         if i < 552:
             assert torch.equal(got[k], v), k
     assert len(pretrained) >= 552
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_stream_plan_of_yolov7(training):
+    """Host-side bookkeeping of the multi-stream schedule (Graph.run): one forked forward branch per ELAN1 / ELAN2 / MaxConv block on
+    lane 1, the two early detection heads on lane 2, a join point on a main-stream entry after every lane-1 branch, and (training)
+    every regular weight gradient on the weight-gradient stream."""
+    from ryolov4_amd.model.blocks import ELAN1, ELAN2, MaxConv
+    m = Yolo(2, CFG, "kfiou", "yolov7")
+    m.train(training)
+    g = Runtime(m, torch.device("cpu")).graph(2, 64, 64, training)
+    nblocks = sum(1 for x in m.modules() if isinstance(x, (ELAN1, ELAN2, MaxConv)))
+    firsts = [i for i, (first, lane) in g.fwd_side.items() if first]
+    assert sum(1 for i in firsts if g.fwd_side[i][1] == 1) == nblocks
+    assert sum(1 for i in firsts if g.fwd_side[i][1] == 2) == 2
+    assert len(g.fwd_join) == nblocks
+    for j in g.fwd_join:
+        k = j
+        while k in g.fwd_side:                      # a join lands on the next main-stream entry (Graph.run defers it)
+            k += 1
+        assert k < len(g.fwd)
+    # forked entries are contiguous runs starting with a `first` entry
+    for i in sorted(g.fwd_side):
+        first, lane = g.fwd_side[i]
+        assert first or ((i - 1) in g.fwd_side and g.fwd_side[i - 1][1] == lane)
+    if training:
+        names = [n for _, _, n in g.bwd]
+        assert g.side_idx and all(names[i] == "ryolo_conv_wgrad" for i in g.side_idx)
+        assert len(g.side_idx) == names.count("ryolo_conv_wgrad")          # yolov7's stem runs the direct kernel: every conv_wgrad is regular
+    else:
+        assert not g.side_idx
