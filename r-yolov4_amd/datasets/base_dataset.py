@@ -16,10 +16,11 @@ from .. import hip
 
 
 def gaussian_label(label, num_class, u=0, sig=4.0):
-    x = np.arange(-num_class / 2, num_class / 2)
-    y_sig = np.exp(-(x - u) ** 2 / (2 * sig ** 2))
-    index = int(num_class / 2 - label)
-    return np.concatenate([y_sig[index:], y_sig[:index]], axis=0)
+    """Circular smooth label of one angle class (host numpy, same signature as the reference's): the gaussian window over the
+    class axis, rotated so that its peak sits at `label`; `int()` truncates toward zero exactly like the reference's index."""
+    half = num_class / 2
+    window = np.exp(-np.square(np.arange(-half, half) - u) / (2.0 * sig * sig))
+    return np.roll(window, -int(half - label))
 
 
 def finalize_batch(imgs_u8, targets10, flags=None, csl=False):

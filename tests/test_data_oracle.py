@@ -45,3 +45,13 @@ def test_rescale_and_polys_match_reference(golden_dir):
         b = ref_data.rescale_boxes(torch.from_numpy(g[f"det_{tag}_in"].copy()), int(g[f"det_{tag}_dim"]), tuple(int(v) for v in g[f"det_{tag}_shape"]))
         assert np.array_equal(b.numpy(), g[f"det_{tag}_boxes"]), tag
         assert np.array_equal(ref_data.xywha2xyxyxyxy(b[:, :5]).numpy(), g[f"det_{tag}_polys"]), tag
+
+
+def test_product_gaussian_label_equals_the_reference_rows(golden_dir):
+    """The host helper exported by ryolov4_amd.datasets.base_dataset (np.roll form) against the rows captured from the reference,
+    including negative shifts (angles above 90) and the truncation-toward-zero edge cases."""
+    from ryolov4_amd.datasets.base_dataset import gaussian_label
+    g = _g(golden_dir)
+    for a, row in zip(g["csl_angle"], g["csl_rows"]):
+        assert np.array_equal(gaussian_label(torch.tensor(a), 180, u=0, sig=6).astype(np.float32), row), a
+        assert np.array_equal(gaussian_label(float(a), 180, u=0, sig=6), ref_data.gaussian_label(float(a), 180, u=0, sig=6))
