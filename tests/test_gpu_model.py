@@ -287,3 +287,38 @@ torch.save([o.cpu() for o in outs], "/tmp/_rep_%s.pt" % __import__("os").environ
     for fa, fb in zip(a, b):
         assert rel(fa, fb) < 6e-3, rel(fa, fb)
         assert not torch.equal(fa, fb)                       # the fold really ran (different rounding), not the same plan twice
+
+
+@pytest.mark.parametrize("mode", ["csl", "kfiou"])
+def test_loss_gradient_with_many_duplicate_cells_vs_oracle_autograd(mode):
+    """Targets crowded into a few cells: many (image, anchor, cell) triples are matched by 3-10 targets, the case where the reference's
+    `pi[b, a, gj, gi]` gather back-propagates through index_put_(accumulate=True).  Loss items 1e-4, gradients rtol 2e-3 against the
+    oracle's autograd (fp32 CPU)."""
+    from ryolov4_amd.lib import loss as L
+
+    class M:
+        pass
+    nc, S, B = 4, 64, 2
+    m = M()
+    m.anchors, m.nc = ref_ops.make_anchors(CFG, mode), nc
+    crit = (L.ComputeCSLLoss if mode == "csl" else L.ComputeKFIoULoss)(m, HYP)
+    tg = synth_targets(B, 40, nc, mode == "csl", seed=21, img_size=S)
+    tg[:, 2:4] = 0.30 + 0.10 * tg[:, 2:4]                       # all centres inside a 6-pixel square -> the same 1-2 cells per scale
+    tg[:, 4:6] = tg[:, 4:6].clamp(max=0.5)
+    na = 3 if mode == "csl" else 18
+    attrs = (5 + 180 + nc) if mode == "csl" else (6 + nc)
+    g = torch.Generator().manual_seed(6)
+    base = [torch.randn(B, na, S // st, S // st, attrs, generator=g) * 0.5 for st in (8, 16, 32)]
+    outs = [b.clone().to(DEV).requires_grad_() for b in base]
+    loss, items = crit(outs, tg.to(DEV))
+    loss.backward()
+    recs = crit.debug_matches()
+    cells = np.concatenate([r[:, 6] + 10_000_000 * i for i, r in enumerate(recs)])
+    _, counts = np.unique(cells, return_counts=True)
+    assert counts.max() >= 3 and (counts >= 3).sum() >= 5        # the duplicate path is really exercised
+    outs_o = [b.clone().requires_grad_() for b in base]
+    loss_o, items_o = ref_ops.compute_loss(outs_o, tg, m.anchors, nc, mode, HYP)
+    loss_o.backward()
+    assert abs(items["total_loss"] - float(items_o["total_loss"])) < 1e-4 * abs(float(items_o["total_loss"]))
+    for a, b in zip(outs, outs_o):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-7)
