@@ -30,6 +30,9 @@ struct ScaleWs {
     float* tconf;             // [cells]
     float* part_match;        // [nblk_match][4]: reg_a, reg_b, cls, theta
     float* part_obj;          // [nblk_obj]
+    int* head;                // [cells]: most recently linked match of the cell (-1: none) — chains of duplicate matches
+    int* next;                // [cap]:   next match of the same cell
+    float* gbox;              // [cap][8]: d(loss)/d(x, y, w, h[, a] logits) of the match
     int cap, cells, nblk_match, nblk_obj;
 };
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -52,6 +55,9 @@ __host__ __device__ static inline void carve(const LossParams& p, ScaleWs* s, si
         s[i].tconf = reinterpret_cast<float*>(base + off); off += al256((size_t)cells * 4);
         s[i].part_match = reinterpret_cast<float*>(base + off); off += al256((size_t)(s[i].nblk_match > 0 ? s[i].nblk_match : 1) * 4 * 4);
         s[i].part_obj = reinterpret_cast<float*>(base + off); off += al256((size_t)s[i].nblk_obj * 4);
+        s[i].head = reinterpret_cast<int*>(base + off); off += al256((size_t)cells * 4);
+        s[i].next = reinterpret_cast<int*>(base + off); off += al256((size_t)cap * 4);
+        s[i].gbox = reinterpret_cast<float*>(base + off); off += al256((size_t)cap * 8 * 4);
     }
     *total = off;
 }
@@ -308,7 +314,6 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, Sca
         float* f = s.frec + (int64_t)e * 8;
         const int a = r[1], cell = r[6];
         const float* ps = p.head[scale] + (int64_t)cell * attrs;
-        float* gp = p.compute_grad ? p.grad[scale] + (int64_t)cell * attrs : nullptr;
         const float inv_n = 1.0f / (float)n;
         if (lane == 0) {
             const float aw = p.anchors[scale][a][0], ah = p.anchors[scale][a][1];
@@ -349,29 +354,26 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, Sca
             }
             f[5] = score;
             atomicMax(&s.owner[cell], e);                                        // last writer (largest e) wins
-            if (gp) {
-                for (int k = 0; k < 4; k++) atomicAdd(gp + k, g[k]);
-                if (p.mode == 1) atomicAdd(gp + 4, g[4]);
+            if (p.compute_grad) {
+                float* gb = s.gbox + (int64_t)e * 8;
+                for (int k = 0; k < 5; k++) gb[k] = g[k];
+                s.next[e] = atomicExch(&s.head[cell], e);                        // link into the cell's chain (any order: K2b sorts)
             }
         }
         // class BCE (nc > 1 only, lib/loss.py:223 / :399)
         const int c0 = p.mode == 0 ? 5 : 6;
         if (p.nc > 1) {
             const int tc = r[4];
-            const float kc = p.cls * inv_n / (float)p.nc;
             for (int k = lane; k < p.nc; k += 64) {
                 const float x = ps[c0 + k], t = (k == tc) ? 1.f : 0.f;
                 clsl += bce_val(x, t, p.cls_pw);
-                if (gp) atomicAdd(gp + c0 + k, kc * bce_grad(x, t, p.cls_pw));
             }
         }
         if (p.mode == 0) {                                                       // CSL theta BCE, lib/loss.py:231
             const float* tg = p.targets + (int64_t)r[5] * p.tcols + 7;
-            const float kt = p.theta_gain * inv_n / 180.f;
             for (int k = lane; k < 180; k += 64) {
                 const float x = ps[5 + p.nc + k], t = tg[k];
                 thl += bce_val(x, t, 1.0f);
-                if (gp) atomicAdd(gp + 5 + p.nc + k, kt * bce_grad(x, t, 1.0f));
             }
         }
     }
@@ -383,6 +385,70 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, Sca
         const float v = blk[0][threadIdx.x] + blk[1][threadIdx.x] + blk[2][threadIdx.x] + blk[3][threadIdx.x];
         s.part_match[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K2b per-cell gradient
+// d(loss)/d(logits) of the matched cells.  A cell matched by several targets (the reference gathers pi[b, a, gj, gi] with repeated
+// indices, autograd scatters with index_put_(accumulate=True)) gets the SUM of its matches' terms: the cell's owner (largest match
+// index) walks the chain K2 linked and adds the members in ASCENDING match order — a fixed order, so the gradient is bitwise
+// reproducible (float atomics in arrival order differed in the last bits whenever three or more targets shared a cell) — and writes
+// plain stores.  Chains are short (1 for almost every cell); the next member is found by selection (O(d^2) walks, no storage bound).
+__global__ __launch_bounds__(256) void loss_match_grad_kernel(const LossParams p, ScaleWs s, int scale)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    const int n = *s.count;
+    if (e >= n) return;
+    const int cell = s.rec[(int64_t)e * 8 + 6];
+    if (s.owner[cell] != e) return;                                              // one wave per matched cell
+    const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
+    const float* ps = p.head[scale] + (int64_t)cell * attrs;
+    float* gp = p.grad[scale] + (int64_t)cell * attrs;
+    const float inv_n = 1.0f / (float)n;
+    const int c0 = p.mode == 0 ? 5 : 6;
+    const float kc = p.cls * inv_n / (float)(p.nc > 0 ? p.nc : 1);
+    const float kt = p.theta_gain * inv_n / 180.f;
+    float gbox[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float gcls = 0.f, gth[3] = {0.f, 0.f, 0.f};
+    const float xc = (p.nc > 1 && lane < p.nc) ? ps[c0 + lane] : 0.f;             // nc <= 64 classes per lane pass (looped below if more)
+    float xt[3] = {0.f, 0.f, 0.f};
+    if (p.mode == 0)
+        for (int q = 0; q < 3; q++) { const int k = lane + 64 * q; if (k < 180) xt[q] = ps[5 + p.nc + k]; }
+    int prev = -1;
+    for (;;) {
+        int m = 0x7fffffff;
+        if (lane == 0)
+            for (int c = s.head[cell]; c >= 0; c = s.next[c])
+                if (c > prev && c < m) m = c;
+        m = __shfl(m, 0, 64);
+        if (m == 0x7fffffff) break;
+        prev = m;
+        const int* r = s.rec + (int64_t)m * 8;
+        if (lane == 0) {
+            const float* gb = s.gbox + (int64_t)m * 8;
+            for (int k = 0; k < 5; k++) gbox[k] += gb[k];
+        }
+        if (p.nc > 1) {
+            const int tc = r[4];
+            if (p.nc <= 64) {
+                if (lane < p.nc) gcls += kc * bce_grad(xc, lane == tc ? 1.f : 0.f, p.cls_pw);
+            } else {
+                for (int k = lane; k < p.nc; k += 64)                                  // wide class heads: accumulate in memory, same order
+                    gp[c0 + k] += kc * bce_grad(ps[c0 + k], k == tc ? 1.f : 0.f, p.cls_pw);
+            }
+        }
+        if (p.mode == 0) {
+            const float* tg = p.targets + (int64_t)r[5] * p.tcols + 7;
+            for (int q = 0; q < 3; q++) { const int k = lane + 64 * q; if (k < 180) gth[q] += kt * bce_grad(xt[q], tg[k], 1.0f); }
+        }
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 4; k++) gp[k] = gbox[k];
+        if (p.mode == 1) gp[4] = gbox[4];
+    }
+    if (p.nc > 1 && p.nc <= 64 && lane < p.nc) gp[c0 + lane] = gcls;
+    if (p.mode == 0)
+        for (int q = 0; q < 3; q++) { const int k = lane + 64 * q; if (k < 180) gp[5 + p.nc + k] = gth[q]; }
 }
 
 // ------------------------------------------------------------------------------------------------ K3 / K4
@@ -478,6 +544,7 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
     for (int i = 0; i < 3; i++) {
         if (!p.head[i] || (p.compute_grad && !p.grad[i])) return RY_ERR_ARG;
         if (hipMemsetAsync(s[i].owner, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
+        if (p.compute_grad && hipMemsetAsync(s[i].head, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
         if (p.compute_grad && hipMemsetAsync(p.grad[i], 0, (size_t)s[i].cells * attrs * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
     }
     if (p.nt > 0) {
@@ -485,6 +552,7 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
         hipLaunchKernelGGL(loss_targets_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
         for (int i = 0; i < 3; i++) {
             hipLaunchKernelGGL(loss_match_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
+            if (p.compute_grad) hipLaunchKernelGGL(loss_match_grad_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
             hipLaunchKernelGGL(loss_tconf_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, s[i]);
         }
     }

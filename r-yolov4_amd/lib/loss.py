@@ -106,6 +106,7 @@ class _ComputeLossBase:
             cnt = int(ws[off:off + 4].view("int32")[0]); off += 256
             rec = ws[off:off + cap * 32].view("int32").reshape(-1, 8)[:cnt].copy(); off += al(cap * 32)
             off += al(cap * 32) + al(cells * 4) * 2 + al(max(nbm, 1) * 16) + al(nbo * 4)
+            off += al(cells * 4) + al(cap * 4) + al(cap * 32)                  # head, next, gbox (duplicate-cell chains)
             out.append(rec.astype("int64"))
         return out
 
