@@ -4,13 +4,16 @@
 // and norm_angle (lib/general.py:7-20).
 //
 // The reference spends ~100 tiny launches, 4-5 device->host syncs (.cpu().item(), boolean-mask indexing) and an
-// O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 5 launches with no host round trip:
+// O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 7 launches per call (K2, K2b, K3 once per scale) with no host round trip:
 //   K1 loss_targets_*        32 workgroups per scale, two launches (count, then place): candidate (offset, anchor, target) triples
 //                            are tested and compacted IN THE REFERENCE'S ORDER with ballot/popcount prefix sums (bit-exact indices);
 //   K2 loss_match_kernel     one wavefront per match: lane 0 differentiates the box term with forward-mode dual numbers
 //                            (CIoU with constant alpha / KFIoU closed form), all 64 lanes run the class / 180-bin CSL
-//                            BCE with wave64 shuffle reductions; gradients are emitted directly (fused fwd+bwd);
-//                            duplicate cells are resolved last-writer-wins via an atomicMax owner grid;
+//                            BCE with wave64 shuffle reductions; the box-term gradient of the match is parked for K2b;
+//                            duplicate cells are resolved last-writer-wins via an atomicMax owner grid and linked
+//                            into a per-cell chain;
+//   K2b loss_match_grad_kernel  the owner of every matched cell sums the gradient terms of the cell's matches in ascending match
+//                            order (what autograd's index_put_(accumulate=True) does, in a FIXED order) and stores them;
 //   K3 loss_tconf_kernel     owners scatter their IoU score into the objectness target grid;
 //   K4 loss_obj_kernel       objectness BCE over every cell (the only HBM-heavy pass: one strided logit per cell);
 //   K5 loss_finalize_kernel  fixed-order sums -> the five loss items, already scaled (lib/loss.py:251-255, :410-413).
