@@ -4,7 +4,7 @@
 // and norm_angle (lib/general.py:7-20).
 //
 // The reference spends ~100 tiny launches, 4-5 device->host syncs (.cpu().item(), boolean-mask indexing) and an
-// O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 7 launches per call (K2, K2b, K3 once per scale) with no host round trip:
+// O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 7 kernels (15 launches: K2, K2b, K3, K4 once per scale) with no host round trip:
 //   K1 loss_targets_*        32 workgroups per scale, two launches (count, then place): candidate (offset, anchor, target) triples
 //                            are tested and compacted IN THE REFERENCE'S ORDER with ballot/popcount prefix sums (bit-exact indices);
 //   K2 loss_match_kernel     one wavefront per match: lane 0 differentiates the box term with forward-mode dual numbers
