@@ -81,6 +81,10 @@ __device__ __forceinline__ Cand cand_test(const LossParams& p, int i, int cnd, i
     c.a = r / nt;
     c.t = r - c.a * nt;
     const float* tg = p.targets + (int64_t)c.t * p.tcols;
+    // image index outside the batch (a stale collate index, a data-parallel shard whose targets were not re-indexed): the
+    // reference raises IndexError at pi[b, ...]; here the row is dropped instead of indexing the head maps out of bounds
+    const int tb = (int)tg[0];
+    if (tb < 0 || tb >= p.batch) return c;
     c.gx = tg[2] * fg; c.gy = tg[3] * fg; c.gw = tg[4] * fg; c.gh = tg[5] * fg;
     const float aw = p.anchors[i][c.a][0], ah = p.anchors[i][c.a][1];
     const float rw = c.gw / aw, rh = c.gh / ah;

@@ -109,7 +109,7 @@ class Graph:
         self.debug = {}
         self.meta = {}                         # (tape id, index) -> (kernel class, algorithmic flops)
         self.timer = None                      # set by bench.py: per-launch HIP-event timing of the conv kernels
-        self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by every weight-gradient launch (backward is serial)
+        self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by the weight-gradient launches of ONE stream (see _emit_wgrad)
         self.grad_writes = []                  # (backward tape index, [element offsets into Runtime.gflat it writes])
         self.wprep = []                        # launches that depend on the weights only (eval-mode BN folding); run before fwd
         self.static_weights = False            # True while a captured inference graph is recorded: pack + wprep already done
@@ -370,10 +370,19 @@ class Graph:
         p.zeros = self.rt.zeros.data_ptr()
         sk, need = S.I(), S.Z()
         hip.call("ryolo_conv_wgrad_plan", p, sk, need)
-        self._wgrad_ws_bytes = max(self._wgrad_ws_bytes, need.value)
-        self._wgrads.append(p)
+        on_side = bool(side and self.rt.wgrad_stream)
+        if on_side or not self.rt.wgrad_stream:
+            # launches of ONE stream are ordered, so they can share one split-K workspace
+            self._wgrad_ws_bytes = max(self._wgrad_ws_bytes, need.value)
+            self._wgrads.append(p)
+        else:
+            # a weight gradient that stays on the main stream (the im2col stem of yolov5) would race with the side-stream launches
+            # on a shared workspace: it gets its own slabs
+            own = torch.empty(max(need.value, 16), dtype=torch.uint8, device=self.dev)
+            self.keep.append(own)
+            p.partial = own.data_ptr()
         self._call(self.bwd, "ryolo_conv_wgrad", p)
-        if side and self.rt.wgrad_stream:
+        if on_side:
             self.side_idx.add(len(self.bwd) - 1)
 
     def conv_raw(self, conv, x, want_stats, fused=None):

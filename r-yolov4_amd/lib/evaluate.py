@@ -2,8 +2,9 @@
 
 `get_batch_statistics` (test.py:102-149) — the per-image / per-class Python loops with a detectron2 `pairwise_iou_rotated`
 call and `.item()` syncs each — is ONE kernel launch for the batch (csrc/evaluate.hip) and one device->host read.
-`ap_per_class` / `compute_ap` / `calculate_eval_stats` (test.py:16-99,152-164) are host-side numpy in the reference (they run
-once per evaluation on a few thousand rows) and are kept as host code with the same signatures and return values.
+`ap_per_class` / `compute_ap` / `calculate_eval_stats` (test.py:16-99,152-164) run once per evaluation on a few thousand rows:
+host-side numpy here as in the reference, same signatures and return values, written independently (class-grouped, all IoU
+thresholds at once) and bit-identical to the reference's numbers (fixture G8).
 """
 import ctypes
 
@@ -67,52 +68,68 @@ def get_batch_statistics(outputs, targets, iouv, niou):
     return stats
 
 
+# ------------------------------------------------------------------------------------------------ AP from the statistics
+# Same signatures and return values as test.py:16-99,152-164, written independently: predictions are grouped by class with ONE
+# stable sort (confidence order survives inside a class), the cumulative hit / miss counts come from a single cumsum (misses =
+# rank - hits, both exact integers), and the precision envelope + 101-point integral are evaluated for all IoU thresholds of a
+# class at once.  The floating-point expressions that define the metric (hits / (n_labels + 1e-16), hits / rank, np.interp on the
+# negated confidences, trapezoid over 101 points) are the reference's, so the results are bit-identical (fixture G8).
+_RECALL_GRID = np.linspace(0.0, 1.0, 101)
+_CONF_GRID = np.linspace(0.0, 1.0, 1000)
+
+
+def _envelope_ap(recall, precision):
+    """[n, T] recall / precision curves (one column per IoU threshold) -> (ap [T], envelope [n + 2, T], recall knots [n + 2, T])."""
+    n, T = recall.shape
+    knots = np.empty((n + 2, T))
+    knots[0], knots[1:-1], knots[-1] = 0.0, recall, recall[-1] + 0.01
+    env = np.empty((n + 2, T))
+    env[0], env[1:-1], env[-1] = 1.0, precision, 0.0
+    env = np.maximum.accumulate(env[::-1], axis=0)[::-1]            # running maximum from the right = precision envelope
+    ap = np.array([np.trapz(np.interp(_RECALL_GRID, knots[:, j], env[:, j]), _RECALL_GRID) for j in range(T)])
+    return ap, env, knots
+
+
 def compute_ap(recall, precision):
-    """test.py:73-99 (YOLOv7 metric: sentinels, precision envelope, 101-point interpolation)."""
-    mrec = np.concatenate(([0.0], recall, [recall[-1] + 0.01]))
-    mpre = np.concatenate(([1.0], precision, [0.0]))
-    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
-    x = np.linspace(0, 1, 101)
-    ap = np.trapz(np.interp(x, mrec, mpre), x)
-    return ap, mpre, mrec
+    """test.py:73-99 for one curve: (ap, envelope, recall knots)."""
+    ap, env, knots = _envelope_ap(np.asarray(recall, dtype=np.float64)[:, None], np.asarray(precision, dtype=np.float64)[:, None])
+    return ap[0], env[:, 0], knots[:, 0]
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls):
-    """test.py:16-70.  (p, r, ap [nc, niou], f1, classes) at the confidence of maximum mean F1."""
-    i = np.argsort(-conf)
-    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
-    unique_classes = np.unique(target_cls)
-    nc = unique_classes.shape[0]
-    px = np.linspace(0, 1, 1000)
-    ap, p, r = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
-    for ci, c in enumerate(unique_classes):
-        i = pred_cls == c
-        n_l = (target_cls == c).sum()
-        n_p = i.sum()
-        if n_p == 0 or n_l == 0:
+    """test.py:16-70.  (p, r, ap [nc, niou], f1, classes), p / r / f1 read at the confidence that maximises the mean F1."""
+    by_conf = np.argsort(-conf)
+    tp, conf, pred_cls = tp[by_conf], conf[by_conf], pred_cls[by_conf]
+    classes, n_labels = np.unique(target_cls, return_counts=True)
+    by_cls = np.argsort(pred_cls, kind="stable")
+    lo = np.searchsorted(pred_cls[by_cls], classes, side="left")
+    hi = np.searchsorted(pred_cls[by_cls], classes, side="right")
+    niou = tp.shape[1]
+    ap = np.zeros((len(classes), niou))
+    prec_at, rec_at = np.zeros((len(classes), _CONF_GRID.size)), np.zeros((len(classes), _CONF_GRID.size))
+    for k in range(len(classes)):
+        rows = by_cls[lo[k]:hi[k]]
+        if rows.size == 0 or n_labels[k] == 0:
             continue
-        fpc = (1 - tp[i]).cumsum(0)
-        tpc = tp[i].cumsum(0)
-        recall = tpc / (n_l + 1e-16)
-        r[ci] = np.interp(-px, -conf[i], recall[:, 0], left=0)
-        precision = tpc / (tpc + fpc)
-        p[ci] = np.interp(-px, -conf[i], precision[:, 0], left=1)
-        for j in range(tp.shape[1]):
-            ap[ci, j], _, _ = compute_ap(recall[:, j], precision[:, j])
-    f1 = 2 * p * r / (p + r + 1e-16)
-    i = f1.mean(0).argmax()
-    return p[:, i], r[:, i], ap, f1[:, i], unique_classes.astype("int32")
+        hits = tp[rows].cumsum(0)
+        rank = np.arange(1, rows.size + 1)[:, None]                  # hits + misses
+        recall = hits / (n_labels[k] + 1e-16)
+        precision = hits / rank
+        neg = -conf[rows]
+        rec_at[k] = np.interp(-_CONF_GRID, neg, recall[:, 0], left=0)
+        prec_at[k] = np.interp(-_CONF_GRID, neg, precision[:, 0], left=1)
+        ap[k] = _envelope_ap(recall, precision)[0]
+    f1 = 2 * prec_at * rec_at / (prec_at + rec_at + 1e-16)
+    best = f1.mean(0).argmax()
+    return prec_at[:, best], rec_at[:, best], ap, f1[:, best], classes.astype("int32")
 
 
 def calculate_eval_stats(stats, num_classes):
-    """test.py:152-164: (nt, p, r, ap50, ap, f1, ap_class, mp, mr, map50, map) from the concatenated statistics."""
-    p, r, f1, mp, mr, map50, map_ = 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0
-    ap50, ap, ap_class = [], [], []
-    if len(stats) and stats[0].any():
-        p, r, ap, f1, ap_class = ap_per_class(*stats)
-        ap50, ap = ap[:, 0], ap.mean(1)
-        mp, mr, map50, map_ = p.mean(), r.mean(), ap50.mean(), ap.mean()
-        nt = np.bincount(stats[3].astype(np.int64), minlength=num_classes)
-    else:
-        nt = torch.zeros(1)
-    return nt, p, r, ap50, ap, f1, ap_class, mp, mr, map50, map_
+    """test.py:152-164: (nt, p, r, ap50, ap, f1, ap_class, mp, mr, map50, map) from the concatenated statistics; the all-zero
+    tuple (with nt = zeros(1)) when there is not a single true positive at the first threshold."""
+    if not (len(stats) and stats[0].any()):
+        return torch.zeros(1), 0.0, 0.0, [], [], 0.0, [], 0.0, 0.0, 0.0, 0.0
+    p, r, ap_all, f1, ap_class = ap_per_class(*stats)
+    ap50, ap = ap_all[:, 0], ap_all.mean(1)
+    nt = np.bincount(stats[3].astype(np.int64), minlength=num_classes)
+    return nt, p, r, ap50, ap, f1, ap_class, p.mean(), r.mean(), ap50.mean(), ap.mean()

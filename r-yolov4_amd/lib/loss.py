@@ -18,11 +18,18 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, owner, targets, o0, o1, o2):
         grads, items = owner._run([o0, o1, o2], targets, True)
         ctx.grads = grads
+        ctx.consumed = False
         owner._last_items = items
         return items[4:5].clone()
 
     @staticmethod
     def backward(ctx, go):
+        if ctx.consumed:
+            # the saved gradients are scaled IN PLACE below (they are 1.3 GB at the benchmark size: no second copy); a second backward
+            # through the same node (retain_graph=True) would apply the incoming scale twice — refuse instead of returning wrong numbers
+            raise RuntimeError("ryolov4_amd loss: backward through the same loss node twice is not supported (gradients are "
+                               "scaled in place); call the criterion again for a second backward")
+        ctx.consumed = True
         g = ctx.grads
         # d(total)/d(logits) was produced by the fused kernel; chain rule with the incoming gradient (a [1] device tensor, 1.0 after a
         # plain loss.backward()): scaled in place on the device, and skipped there when the scalar is exactly 1 (no host read)

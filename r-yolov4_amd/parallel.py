@@ -132,10 +132,31 @@ class _Reducer:
         self.works = []
 
 
+class _Hook:
+    """What Yolo._grad_hook holds: forwards to the reducer unless the owner is inside `no_sync()`."""
+
+    def __init__(self, owner, reducer, overlapped):
+        self.owner, self.reducer, self.overlapped = owner, reducer, overlapped
+
+    def bucket_hooks(self, rt, g):
+        if not self.owner._sync or not self.overlapped:
+            return None
+        return self.reducer.bucket_hooks(rt, g)
+
+    def __call__(self, rt):
+        if self.owner._sync:
+            self.reducer(rt)
+
+
 class DataParallel:
     """Wraps a ryolov4_amd Yolo: broadcasts rank-0 parameters once, all-reduces the flat gradient buffer in ~25 MB buckets
     overlapped with the backward tape (overlap=False: one pass at the end of backward), and exposes `grad_scale` = 1/world for
-    the fused SGD step."""
+    the fused SGD step.
+
+    Gradient accumulation (train.py:198-202, `accumulate > 1`): the flat buffer keeps accumulating across backward passes, and the
+    all-reduce is IN PLACE — reducing after every micro-step would sum the already-reduced earlier micro-steps over the ranks again
+    (world*G1 + G2).  Run every micro-step but the last under `with dp.no_sync():` (same contract as torch DDP); the last backward
+    reduces the accumulated sum once."""
 
     def __init__(self, model, bucket_bytes=25 << 20, overlap=True, force=False):
         self.model = model
@@ -148,13 +169,27 @@ class DataParallel:
                 if b.dtype.is_floating_point:
                     dist.broadcast(b, src=0)
         self.overlap = overlap
+        self._sync = True
         self._reducer = _Reducer(bucket_bytes)
         # force: install the hooks even for a single rank (exercises the RCCL path on a one-GPU box: tools/dp_check.py)
-        model._grad_hook = (self._reducer if overlap else self._reduce) if (self.world > 1 or force) else None
+        model._grad_hook = _Hook(self, self._reducer if overlap else self._reduce, overlap) if (self.world > 1 or force) else None
         self.grad_scale = 1.0 / self.world
 
     def _reduce(self, rt):
         allreduce_flat(rt.gflat, self.bucket_bytes)
+
+    def no_sync(self):
+        """Context manager: backward passes inside it only accumulate into the local flat gradient buffer (no collective)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = old
+        return ctx()
 
     def __call__(self, *a, **k):
         return self.model(*a, **k)

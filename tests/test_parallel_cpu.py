@@ -132,3 +132,54 @@ def test_overlapped_reducer_gloo_world2():
         assert p.exitcode == 0
     for _, ok, fired, nb in res:
         assert ok and fired == [3, 7, 9] and nb == 5
+
+
+def _nosync_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ryolov4_amd import parallel
+    parallel.init_from_env(backend="gloo")
+
+    class RT:
+        flat = torch.zeros(300)
+        gflat = torch.zeros(300)
+        _pslice = {i: (o, 10, None) for i, o in enumerate(range(0, 300, 64))}
+
+    class Model:
+        _grad_hook = None
+
+        def runtime(self):
+            return RT
+
+        def buffers(self):
+            return []
+
+    m = Model()
+    dp = parallel.DataParallel(m, bucket_bytes=512, overlap=False)
+    g1 = torch.arange(300, dtype=torch.float32) * (rank + 1)
+    g2 = torch.ones(300) * (10 + rank)
+    # two micro-steps of gradient accumulation (train.py:198-202): backward = "accumulate into gflat, then the hook"
+    with dp.no_sync():
+        RT.gflat += g1
+        assert m._grad_hook.bucket_hooks(RT, None) is None
+        m._grad_hook(RT)                                          # no collective inside no_sync
+    RT.gflat += g2
+    m._grad_hook(RT)
+    expect = torch.arange(300, dtype=torch.float32) * 3 + 21.0    # sum over both ranks of (g1 + g2), each counted ONCE
+    q.put((rank, torch.equal(RT.gflat, expect)))
+    dist.destroy_process_group()
+
+
+def test_no_sync_accumulation_gloo_world2():
+    """the in-place all-reduce after EVERY micro-step would give world*G1 + G2; with no_sync() the accumulated sum is
+    reduced once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_nosync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -108,3 +108,23 @@ def test_stream_plan_of_yolov7(training):
         assert len(g.side_idx) == names.count("ryolo_conv_wgrad")          # yolov7's stem runs the direct kernel: every conv_wgrad is regular
     else:
         assert not g.side_idx
+
+
+@pytest.mark.parametrize("ver", ["yolov4", "yolov5", "yolov7"])
+def test_main_stream_wgrad_never_shares_the_split_k_workspace_with_the_side_stream(ver):
+    """Backward runs on two streams; launches of one stream are ordered, launches of different streams are not: a weight gradient
+    that stays on the main stream (yolov5's im2col stem) must not use the split-K slabs of the side-stream weight gradients."""
+    from ryolov4_amd.engine import structs as S
+    m = Yolo(2, CFG, "kfiou", ver)
+    m.train()
+    g = Runtime(m, torch.device("cpu")).graph(2, 64, 64, True)
+    side_ws, main_ws = set(), set()
+    for i, (fn, args, name) in enumerate(g.bwd):
+        if name != "ryolo_conv_wgrad":
+            continue
+        p = args[0]._obj
+        assert isinstance(p, S.WgradParams) and p.partial
+        (side_ws if i in g.side_idx else main_ws).add(p.partial)
+    assert side_ws and not (side_ws & main_ws)
+    if ver == "yolov5":
+        assert main_ws                                   # the 6x6 stride-2 stem goes through im2col + the generic wgrad on the main stream

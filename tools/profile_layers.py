@@ -41,13 +41,22 @@ for (tname, i, name), ms in best.items():
     tape = g.fwd if tname == "fwd" else g.bwd
     kind, fl, by = (tuple(g.meta.get((id(tape), i), (name, 0, 0))) + (0, 0))[:3]
     tot[(tname, kind)] += ms
-    detail.append((ms, tname, i, kind, fl, by))
+    shape = ""
+    a0 = tape[i][1][0] if tape[i][1] else None
+    st_ = getattr(a0, "_obj", None)
+    if isinstance(st_, S.ConvGemmParams):
+        shape = f"{st_.Cin}->{st_.Nout} taps{st_.cls[0].ntaps}x{st_.nclasses} {st_.OH}x{st_.OW} s{st_.sh} epi{st_.epi}"
+    elif isinstance(st_, S.WgradParams):
+        shape = f"{st_.Cin}->{st_.Cout} taps{st_.ntaps} {st_.OH}x{st_.OW} s{st_.sh}"
+    elif isinstance(st_, S.BnActParams):
+        shape = f"M{st_.M} C{st_.C}"
+    detail.append((ms, tname, i, kind, fl, by, shape))
 print("== totals per kernel class (ms per step, isolated launches) ==")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
     print(f"{k[0]:4s} {k[1]:34s} {v:8.3f} ms")
 print("sum", sum(tot.values()))
 print("== top launches ==")
 # recover shapes from the kept structs: walk keep list in order of creation for gemm/wgrad structs
-for ms, tname, i, kind, fl, by in sorted(detail, reverse=True)[:int(os.environ.get("TOP", 70))]:
-    print(f"{tname} #{i:4d} {kind:34s} {ms*1e3:9.1f} us  {fl/ms/1e9 if fl else 0:8.1f} TF/s  {by/ms/1e6 if by else 0:8.1f} GB/s  flops {fl/1e9:8.2f} G  bytes {by/1e6:8.1f} MB")
+for ms, tname, i, kind, fl, by, shape in sorted(detail, reverse=True)[:int(os.environ.get("TOP", 70))]:
+    print(f"{tname} #{i:4d} {kind:34s} {ms*1e3:9.1f} us  {fl/ms/1e9 if fl else 0:8.1f} TF/s  {by/ms/1e6 if by else 0:8.1f} GB/s  flops {fl/1e9:8.2f} G  bytes {by/1e6:8.1f} MB  {shape}")
 json.dump(detail, open("gpurun_out/layers.json", "w"))
