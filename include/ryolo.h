@@ -131,9 +131,18 @@ int ryolo_stem3x3_wgrad(const StemWgradParams* p, ryolo_stream_t stream);
  * mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running_mean/var updated in place (unbiased var). */
 int ryolo_bn_finalize(const float* partial, int rows, int C, double count, float eps, float momentum, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float* coeffs, ryolo_stream_t stream);
+/* the same for channels [c0, c0 + C) of partial rows that are [2][ld] wide: sibling convolutions of a block that read the same input
+ * (ELAN / CSP / C3 / SPPCSPC cv1 + cv2, model/utils.py:49-143,264-282) are emitted as ONE GEMM with concatenated output channels;
+ * each BatchNorm finalizes its own slice into its own coeffs [4][C] */
+int ryolo_bn_finalize_slice(const float* partial, int rows, int ld, int c0, int C, double count, float eps, float momentum,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var, float* coeffs,
+                            ryolo_stream_t stream);
 /* eval BatchNorm2d: coeffs from the running statistics */
 int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                          int C, float* coeffs, ryolo_stream_t stream);
+/* ... into channels [c0, c0 + C) of a shared coeffs [4][ld] (folded-BN epilogue of a shared GEMM launch) */
+int ryolo_bn_eval_coeffs_slice(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                               int C, float* coeffs, int ld, int c0, ryolo_stream_t stream);
 /* z = act(bn1(y1) [+ bn2(y2)]) [+ residual]   (Conv / RepConv / Bottleneck of model/utils.py) */
 int ryolo_bn_act_fwd(const BnActParams* p, ryolo_stream_t stream);
 int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_per_block);

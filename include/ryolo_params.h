@@ -44,6 +44,8 @@ typedef struct WgradParams {
     int splitk; int64_t kchunk;                      // pixels per split (multiple of BK) — filled by the library
     float* partial;                                  // split-K workspace [splitk][Cout][ntaps*Cin] fp32 (ryolo_conv_wgrad_plan)
     const bf16_t* zeros;                             // >= 64 zero bytes in device memory (LDS-DMA source of padding rows); null: generic kernel only
+    float* dW2; int Cout1;                           // dW2 != null: output channels >= Cout1 belong to a second parameter tensor (sibling
+                                                     // convolutions sharing one launch): row co of the GEMM goes to dW2[co - Cout1]
 } WgradParams;
 
 /* first layer (3x3 stride 1, Cin = 3) computed directly from the fp32 NCHW image: csrc/stem.hip */
@@ -98,7 +100,9 @@ typedef struct PoolParams {
 
 typedef struct UpParams { const bf16_t* x; int ldx; bf16_t* z; int ldz; int NB, H, W, C; int accum; } UpParams;
 
-typedef struct PackEntry { const float* src; bf16_t* wf; bf16_t* wd; int Cout, Cin, taps, CinP, CoutP, pad_; int64_t start; } PackEntry;
+/* ldWd: row length of the [Cin][taps][...] data-gradient image (0 = CoutP); larger when sibling convolutions share one image and
+ * this entry owns a column range of it (wd then points at its first column) */
+typedef struct PackEntry { const float* src; bf16_t* wf; bf16_t* wd; int Cout, Cin, taps, CinP, CoutP, ldWd; int64_t start; } PackEntry;
 
 typedef struct LossParams {
     int mode;                 // 0 csl, 1 kfiou

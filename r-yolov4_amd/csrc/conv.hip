@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
 // request-rate bound), an LDS pass folds the split lanes, and the [tap][cin] -> [cin][tap] transpose happens in LDS so the
 // read-modify-write of the torch-layout gradient is one contiguous CH*ntaps-float run.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splitk, int Cout, int Cin, int ntaps,
-                                                            int CH, int ZL, float* __restrict__ dW)
+                                                            int CH, int ZL, float* __restrict__ dW, float* __restrict__ dW2, int Cout1)
 {
     extern __shared__ float red[];                   // [ZL][ntaps][CH + 1]
     const int c4n = CH >> 2, P = ntaps * c4n;
@@ -743,7 +743,8 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
         const int cl = j / ntaps, tt = j - cl * ntaps;
         float sum = 0.f;
         for (int z = 0; z < ZL; z++) sum += red[((int64_t)z * ntaps + tt) * ldr + cl];
-        dW[((int64_t)co * Cin + cin0) * ntaps + j] += sum;
+        if (dW2 && co >= Cout1) dW2[((int64_t)(co - Cout1) * Cin + cin0) * ntaps + j] += sum;      // second parameter tensor of a shared launch
+        else dW[((int64_t)co * Cin + cin0) * ntaps + j] += sum;
     }
 }
 
@@ -759,7 +760,7 @@ static void launch_wgrad_reduce(const WgradParams& p, int splitk, hipStream_t st
     if (ZL > 32) ZL = 32;
     const size_t lds = (size_t)ZL * p.ntaps * (CH + 1) * sizeof(float);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.Cout, p.Cin / CH), dim3(1024), lds, stream, p.partial, splitk, p.Cout, p.Cin, p.ntaps,
-                       CH, ZL, p.dW);
+                       CH, ZL, p.dW, p.dW2, p.Cout1);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI

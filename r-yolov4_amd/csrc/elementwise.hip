@@ -110,7 +110,9 @@ static inline const float* fold_rows(const float* partial, int& rows, int KC, fl
 // ------------------------------------------------------------------------------------------------ BN finalize
 // partial [rows][2][C] (sum, sumsq of the stored bf16 conv output) -> mean/invstd/scale/shift; running stats update
 // (momentum 0.1, unbiased variance — nn.BatchNorm2d defaults used by model/utils.py:17)
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count, float eps,
+// ld / c0: the partial rows are [2][ld] wide and this BatchNorm owns channels [c0, c0 + C) of them (sibling convolutions that share
+// one GEMM launch share one statistics buffer; ld == C, c0 == 0 for a stand-alone layer)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int ld, int c0, int C, double count, float eps,
                                                            float momentum, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ out /*[4][C]*/)
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     double s = 0.0, q = 0.0;
     if (c < C)
         for (int r = rl; r < rows; r += 32) {
-            s += (double)partial[((int64_t)r * 2 + 0) * C + c];
-            q += (double)partial[((int64_t)r * 2 + 1) * C + c];
+            s += (double)partial[((int64_t)r * 2 + 0) * ld + c0 + c];
+            q += (double)partial[((int64_t)r * 2 + 1) * ld + c0 + c];
         }
     red[0][threadIdx.x] = s;
     red[1][threadIdx.x] = q;
@@ -148,13 +150,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 // eval mode: scale/shift from running statistics
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
-                                      float* out /*[4][C]*/)
+                                      float* out /*[4][ld], channels [c0, c0 + C)*/, int ld, int c0)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float invstd = 1.0f / sqrtf(rv[c] + eps);
     const float sc = gamma[c] * invstd;
-    out[0 * C + c] = rm[c]; out[1 * C + c] = invstd; out[2 * C + c] = sc; out[3 * C + c] = beta[c] - rm[c] * sc;
+    float* o = out + c0 + c;
+    o[0] = rm[c]; o[ld] = invstd; o[2 * ld] = sc; o[3 * ld] = beta[c] - rm[c] * sc;
 }
 
 // ------------------------------------------------------------------------------------------------ BN + act forward
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
         if (e.wd)
             for (int i = threadIdx.x; i < 32 * run; i += 256) {      // Wd[c][t][co]: co fastest
                 const int r = i & 31, tp = (i >> 5) % e.taps, c = i / run;
-                if (co0 + r < e.Cout) e.wd[((int64_t)(c0 + c) * e.taps + tp) * e.CoutP + co0 + r] = f2bf(tile[r][c * e.taps + tp]);
+                if (co0 + r < e.Cout) e.wd[((int64_t)(c0 + c) * e.taps + tp) * (e.ldWd ? e.ldWd : e.CoutP) + co0 + r] = f2bf(tile[r][c * e.taps + tp]);
             }
     }
 }
@@ -1071,18 +1074,38 @@ static inline unsigned grid_rows(int64_t M, int C)
 }
 static inline unsigned grid_for(int64_t work_items) { int64_t g = ry_cdiv(work_items, 256); if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g; }
 
+// Statistics of channels [c0, c0 + C) of partial rows that are [2][ld] wide (several BatchNorms behind ONE GEMM launch: sibling
+// convolutions of a block that read the same input are emitted as one GEMM with concatenated output channels).  coeffs: this
+// BatchNorm's own [4][C].  Every slice call folds the full-width rows again when there are many (a few microseconds).
+extern "C" int ryolo_bn_finalize_slice(const float* partial, int rows, int ld, int c0, int C, double count, float eps, float momentum,
+                                       const float* gamma, const float* beta, float* running_mean, float* running_var, float* coeffs,
+                                       hipStream_t stream)
+{
+    if (!partial || !gamma || !beta || !coeffs || C <= 0 || rows <= 0 || c0 < 0 || c0 + C > ld) return RY_ERR_ARG;
+    // many rows: folded into a scratch area the caller appends to the partial buffer (rows + FOLD_S rows allocated)
+    if (rows > 4 * FOLD_S) {
+        float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * ld;
+        partial = fold_rows(partial, rows, 2 * ld, scratch, stream);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ry_cdiv(C, 32)), dim3(1024), 0, stream, partial, rows, ld, c0, C, count, eps,
+                       momentum, gamma, beta, running_mean, running_var, coeffs);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
 extern "C" int ryolo_bn_finalize(const float* partial, int rows, int C, double count, float eps, float momentum, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float* coeffs, hipStream_t stream)
 {
-    if (!partial || !gamma || !beta || !coeffs || C <= 0 || rows <= 0) return RY_ERR_ARG;
-    // rows > 256: fold in place into the first FOLD_S rows' worth of a scratch area appended by the caller?  The partial
-    // buffer itself is dead after this call, so its tail (rows >= FOLD_S) is reused as the folded output.
-    if (rows > 4 * FOLD_S) {
-        float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * C;      // caller allocates rows + FOLD_S rows
-        partial = fold_rows(partial, rows, 2 * C, scratch, stream);
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ry_cdiv(C, 32)), dim3(1024), 0, stream, partial, rows, C, count, eps, momentum,
-                       gamma, beta, running_mean, running_var, coeffs);
+    return ryolo_bn_finalize_slice(partial, rows, C, 0, C, count, eps, momentum, gamma, beta, running_mean, running_var, coeffs, stream);
+}
+
+// coeffs [4][ld]: this BatchNorm fills channels [c0, c0 + C) of every row
+extern "C" int ryolo_bn_eval_coeffs_slice(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                          float* coeffs, int ld, int c0, hipStream_t stream)
+{
+    if (!gamma || !beta || !rm || !rv || !coeffs || C <= 0 || c0 < 0 || c0 + C > ld) return RY_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, rm, rv, eps, C, coeffs,
+                       ld, c0);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -1090,10 +1113,7 @@ extern "C" int ryolo_bn_finalize(const float* partial, int rows, int C, double c
 extern "C" int ryolo_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                                     float* coeffs, hipStream_t stream)
 {
-    if (!gamma || !beta || !rm || !rv || !coeffs || C <= 0) return RY_ERR_ARG;
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, rm, rv, eps, C, coeffs);
-    RY_CHECK_LAUNCH();
-    return RY_OK;
+    return ryolo_bn_eval_coeffs_slice(gamma, beta, rm, rv, eps, C, coeffs, C, 0, stream);
 }
 
 static int check_bnact(const BnActParams& p) { return (!p.y1 || !p.co1 || p.C <= 0 || (p.C & 7) || (p.ld1 & 7) || p.M < 0) ? RY_ERR_ARG : RY_OK; }

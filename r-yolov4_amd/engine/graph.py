@@ -112,6 +112,7 @@ class Graph:
         self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by the weight-gradient launches of ONE stream (see _emit_wgrad)
         self.grad_writes = []                  # (backward tape index, [element offsets into Runtime.gflat it writes])
         self.wprep = []                        # launches that depend on the weights only (eval-mode BN folding); run before fwd
+        self._fork_open = False                # a side_branch() was emitted since the last join_side()
         self.static_weights = False            # True while a captured inference graph is recorded: pack + wprep already done
 
     # ------------------------------------------------------------------ helpers
@@ -136,6 +137,7 @@ class Graph:
         class _Ctx:
             def __enter__(self_):
                 self_.start = len(g.fwd)
+                g._fork_open = True
 
             def __exit__(self_, *exc):
                 if g.rt.fwd_fork:
@@ -145,8 +147,9 @@ class Graph:
         return _Ctx()
 
     def join_side(self):
-        if self.fwd_side:
+        if self.fwd_side and self._fork_open:
             self.fwd_join.add(len(self.fwd))
+        self._fork_open = False
 
     def _call(self, tape, name, *args):
         """args may contain ctypes structs (passed by reference); the stream is appended at run time."""
@@ -162,6 +165,7 @@ class Graph:
             hi = lo + self.rt.gflat.numel() * 4
             ptrs = [a for a in args if isinstance(a, int) and lo <= a < hi]
             ptrs += [a.dW for a in args if isinstance(a, S.WgradParams) and a.dW and lo <= a.dW < hi]
+            ptrs += [a.dW2 for a in args if isinstance(a, S.WgradParams) and a.dW2 and lo <= a.dW2 < hi]
             if ptrs:
                 self.grad_writes.append((len(tape) - 1, [(q - lo) // 4 for q in ptrs]))
 
@@ -532,6 +536,99 @@ class Graph:
                     conv_bwd(need_dx=not stem)
             self._pending_bwd.append(backward)
         return z
+
+    def conv_bn_act_group(self, mods, x, outs):
+        """Two sibling `Conv` blocks (model/utils.py:6-32) that read the same input with the same kernel / stride — cv1 + cv2 of ELAN1 /
+        ELAN2 / CSP / C3 / SPPCSPC (model/utils.py:49-143,264-282) — as ONE GEMM with concatenated output channels: forward and the
+        weight gradient read x once instead of twice, and the data gradient is one launch with K = Ca + Cb that stores dx instead
+        of a store followed by a read-modify-write.  Each member keeps its own BatchNorm (statistics of its channel slice of the
+        shared partial rows), its own activation pass into its own destination (`outs[i]`: a concat slice, or None for a new
+        buffer), its own fp32 master weights and .grad.  Returns the members' activation TRefs."""
+        rt = self.rt
+        convs = [m.conv[0] for m in mods]
+        c0 = convs[0]
+        ok = (rt.merge_siblings and len(mods) == 2 and all(m.has_bn for m in mods) and c0.in_channels % 32 == 0 and c0.stride[0] == 1
+              and all(c.kernel_size == c0.kernel_size and c.stride == c0.stride and c.padding == c0.padding and
+                      c.in_channels == c0.in_channels and c.out_channels % 32 == 0 for c in convs))
+        if ok and not self.training:
+            # inference: ONE folded-BatchNorm + activation epilogue -> same activation, destinations adjacent in one buffer
+            ok = (all(o is not None for o in outs) and outs[0].buf is outs[1].buf and outs[1].c0 == outs[0].c0 + outs[0].C
+                  and mods[0].act == mods[1].act)
+        if not ok:
+            return [m.emit(self, x, out=o) for m, o in zip(mods, outs)]
+        bns = [m.conv[1] for m in mods]
+        couts = [c.out_channels for c in convs]
+        ctot = sum(couts)
+        cin = c0.in_channels
+        k, s_, pad, OH, OW = self._conv_geom(c0, x)
+        grp = rt.packed_group(convs)
+        taps = [(_taps_fwd(k, pad), 0, 0)]
+        if not self.training:
+            co = self.f32(4, ctot)
+            off = 0
+            for bn, cout in zip(bns, couts):
+                self._call(self.wprep, "ryolo_bn_eval_coeffs_slice", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                           bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr(), ctot, off)
+                off += cout
+            z = TRef(outs[0].buf, outs[0].c0, ctot)
+            self._gemm(self.fwd, x, x.ptr(), grp["wf"], ctot, k * k, cin, OH, OW, s_, taps, S.EPI_AFFINE_ACT, z.ptr(), z.ld, coeffs=co,
+                       act=S.ACT[mods[0].act])
+            for conv, o in zip(convs, outs):
+                self.debug[id(conv)] = (o, o, x)
+            return list(outs)
+        bstat = self.batch_stats
+        y = self.new(x.N, OH, OW, ctot)
+        stats = self._gemm(self.fwd, x, x.ptr(), grp["wf"], ctot, k * k, cin, OH, OW, s_, taps, S.EPI_STATS if bstat else S.EPI_RAW,
+                           y.ptr(), y.ld)
+        zs, parts, off = [], [], 0
+        for m, conv, bn, cout, out in zip(mods, convs, bns, couts, outs):
+            ys = y.slice(off, cout)
+            co = self.f32(4, cout)
+            if bstat:
+                self._call(self.fwd, "ryolo_bn_finalize_slice", stats.data_ptr(), stats.shape[0], ctot, off, cout, float(y.M), float(bn.eps),
+                           float(bn.momentum), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                           bn.running_var.data_ptr(), co.data_ptr())
+                rt.bn_counters.append(bn)
+            else:
+                self._call(self.fwd, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                           bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
+            z = out if out is not None else self.new(y.N, y.H, y.W, cout)
+            assert z.C == cout and z.M == y.M
+            self.debug[id(conv)] = (ys, z, x)
+            p = S.BnActParams()
+            p.y1, p.ld1, p.co1 = ys.ptr(), ys.ld, co.data_ptr()
+            p.z, p.ldz, p.M, p.C, p.act = z.ptr(), z.ld, y.M, cout, S.ACT[m.act]
+            self._call(self.fwd, "ryolo_bn_act_fwd", p)
+            zs.append(z)
+            parts.append((p, ys, z, bn, cout))
+            off += cout
+
+        def backward():
+            for p, ys, z, bn, cout in parts:
+                nblk, rpb = S.I(), S.I()
+                hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
+                partial = self.f32(nblk.value + 64, 2, cout)
+                bco = self.f32(3, cout)
+                q = S.BnActParams()
+                C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
+                q.dz, q.lddz = z.gptr(), z.ld
+                q.dy1, q.lddy1 = ys.gptr(), ys.ld
+                q.partial = partial.data_ptr()
+                self._call(self.bwd, "ryolo_bn_act_bwd", q, rt.grad_ptr(bn.weight), rt.grad_ptr(bn.bias), None, None, bco.data_ptr(),
+                           1 if self.frozen else 0)
+            w = S.WgradParams()
+            w.dY, w.ldY, w.Cout, w.CoutPad = y.gptr(), y.ld, ctot, ctot
+            w.X, w.NB, w.IH, w.IW, w.Cin, w.ldX = x.ptr(), x.N, x.H, x.W, cin, x.ld
+            w.OH, w.OW, w.sh, w.sw = OH, OW, s_, s_
+            tp = _taps_fwd(k, pad)
+            w.ntaps = len(tp)
+            for i, (dh, dw, _) in enumerate(tp):
+                w.dh[i], w.dw[i] = dh, dw
+            w.dW, w.dW2, w.Cout1 = rt.grad_ptr(convs[0].weight), rt.grad_ptr(convs[1].weight), couts[0]
+            self._emit_wgrad(w, side=True)
+            self._dgrad(c0, {"wd": grp["wd"]}, y, y.gptr(), ctot, x)
+        self._pending_bwd.append(backward)
+        return zs
 
     # RepConv: silu(bn(conv3x3(x)) + bn(conv1x1(x)) [+ bn(x)])  (model/utils.py:189-215)
     def repconv(self, rep, x):

@@ -35,6 +35,10 @@ class Runtime:
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
+        # sibling convolutions of a block that read the same input (ELAN / CSP / C3 / SPPCSPC cv1 + cv2) as ONE GEMM with
+        # concatenated output channels: the input is read once instead of twice (forward and weight gradient) and its gradient is
+        # written once instead of store + read-modify-write (Graph.conv_bn_act_group)
+        self.merge_siblings = os.environ.get("RYOLO_MERGE_SIBLINGS", "1") != "0"
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -108,16 +112,46 @@ class Runtime:
             self._pack_table = None
         return pk
 
+    def packed_group(self, convs):
+        """One pair of bf16 GEMM images for several convolutions with the same input, kernel and stride: Wf [sum Cout][taps][Cin]
+        (each member owns a row range) and Wd [Cin][taps][sum Cout] (each member owns a column range, PackEntry.ldWd).  The members'
+        fp32 masters, state_dict keys and .grad stay separate tensors."""
+        key = ("grp",) + tuple(id(c) for c in convs)
+        grp = self._packed.get(key)
+        if grp is None:
+            c0 = convs[0]
+            cin, taps = c0.in_channels, c0.kernel_size[0] * c0.kernel_size[1]
+            assert cin % 32 == 0 and all(c.in_channels == cin and c.kernel_size == c0.kernel_size and c.out_channels % 32 == 0 for c in convs)
+            ctot = sum(c.out_channels for c in convs)
+            wf = torch.zeros((ctot, taps, cin), dtype=torch.bfloat16, device=self.device)
+            wd = torch.zeros((cin, taps, ctot), dtype=torch.bfloat16, device=self.device)
+            members, off = [], 0
+            for c in convs:
+                co = c.out_channels
+                members.append(dict(conv=c, wf=wf[off:off + co], wd=wd[:, :, off:off + co], Cout=co, Cin=cin, taps=taps, CinP=cin, CoutP=co, ldWd=ctot))
+                off += co
+            grp = dict(group=True, wf=wf, wd=wd, Ctot=ctot, members=members)
+            self._packed[key] = grp
+            self._pack_table = None
+        return grp
+
+    def _pack_entries(self):
+        ents = []
+        for pk in self._packed.values():
+            ents.extend(pk["members"] if pk.get("group") else [pk])
+        return ents
+
     def pack(self):
         """fp32 masters -> bf16 GEMM images ([Cout][tap][Cin] for fwd/wgrad, [Cin][tap][Cout] for dgrad); one launch."""
         if self._pack_table is None:
-            ents = list(self._packed.values())
+            ents = self._pack_entries()
             arr = (S.PackEntry * len(ents))()
             start = 0
             for e, pk in zip(arr, ents):
                 e.src, e.wf = pk["conv"].weight.data_ptr(), pk["wf"].data_ptr()
                 e.wd = pk["wd"].data_ptr() if pk["wd"] is not None else None
                 e.Cout, e.Cin, e.taps, e.CinP, e.CoutP, e.start = pk["Cout"], pk["Cin"], pk["taps"], pk["CinP"], pk["CoutP"], start
+                e.ldWd = pk.get("ldWd", 0)
                 if pk["CinP"] != pk["Cin"]:
                     start += (pk["Cout"] * pk["CinP"] + 255) // 256          # stem: 256-element tiles
                 else:

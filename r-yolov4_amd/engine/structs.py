@@ -26,7 +26,7 @@ class WgradParams(C.Structure):
     _fields_ = [("dY", P), ("ldY", I), ("Cout", I), ("CoutPad", I),
                 ("X", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldX", I),
                 ("OH", I), ("OW", I), ("sh", I), ("sw", I), ("ntaps", I), ("dh", C.c_byte * MAX_TAPS), ("dw", C.c_byte * MAX_TAPS),
-                ("dW", P), ("splitk", I), ("kchunk", L), ("partial", P), ("zeros", P)]
+                ("dW", P), ("splitk", I), ("kchunk", L), ("partial", P), ("zeros", P), ("dW2", P), ("Cout1", I)]
 
 
 class StemParams(C.Structure):
@@ -57,7 +57,7 @@ class UpParams(C.Structure):
 
 
 class PackEntry(C.Structure):
-    _fields_ = [("src", P), ("wf", P), ("wd", P), ("Cout", I), ("Cin", I), ("taps", I), ("CinP", I), ("CoutP", I), ("pad_", I),
+    _fields_ = [("src", P), ("wf", P), ("wd", P), ("Cout", I), ("Cin", I), ("taps", I), ("CinP", I), ("CoutP", I), ("ldWd", I),
                 ("start", L)]
 
 
@@ -81,6 +81,8 @@ for _name, _sig in {
     "ryolo_stem3x3_wgrad": [_PTR(StemWgradParams), P],
     "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
     "ryolo_bn_eval_coeffs": [P, P, P, P, F, I, P, P],
+    "ryolo_bn_finalize_slice": [P, I, I, I, I, D, F, F, P, P, P, P, P, P],
+    "ryolo_bn_eval_coeffs_slice": [P, P, P, P, F, I, P, I, I, P],
     "ryolo_bn_act_fwd": [_PTR(BnActParams), P],
     "ryolo_bn_act_bwd_blocks": [L, I, _PTR(I), _PTR(I)],
     "ryolo_bn_act_bwd": [_PTR(BnActParams), P, P, P, P, P, I, P],

@@ -46,6 +46,19 @@ class Bottleneck(nn.Module):            # model/utils.py:35-46
         return self.cv2.emit(g, self.cv1.emit(g, x), out=out, residual=x if self.add else None)
 
 
+def _siblings(g, a, b, x, out_a=None, out_b=None, fork=False):
+    """cv1 + cv2 of a block: both read x with the same kernel — one shared GEMM launch (Graph.conv_bn_act_group) unless switched
+    off (RYOLO_MERGE_SIBLINGS=0: two launches; `fork` then puts the first on the second forward stream as before; the caller joins)."""
+    if g.rt.merge_siblings:
+        return g.conv_bn_act_group([a, b], x, [out_a, out_b])
+    if fork:
+        with g.side_branch():
+            za = a.emit(g, x, out=out_a)
+    else:
+        za = a.emit(g, x, out=out_a)
+    return [za, b.emit(g, x, out=out_b)]
+
+
 def _chain(n, c, shortcut, act):
     return nn.Sequential(*[Bottleneck(c, c, shortcut, e=1.0, act=act) for _ in range(n)])
 
@@ -70,8 +83,8 @@ class CSP(nn.Module):                   # model/utils.py:49-64
 
     def emit(self, g, x, out=None):
         cat = g.new(x.N, x.H, x.W, 2 * self.h)
-        self.cv3.emit(g, _emit_chain(g, self.m, self.cv1.emit(g, x)), out=cat.slice(0, self.h))
-        self.cv2.emit(g, x, out=cat.slice(self.h, self.h))
+        x1, _ = _siblings(g, self.cv1, self.cv2, x, None, cat.slice(self.h, self.h))
+        self.cv3.emit(g, _emit_chain(g, self.m, x1), out=cat.slice(0, self.h))
         return self.cv4.emit(g, cat, out=out)
 
 
@@ -103,8 +116,8 @@ class C3(nn.Module):                    # model/utils.py:83-95
 
     def emit(self, g, x, out=None):
         cat = g.new(x.N, x.H, x.W, 2 * self.h)
-        _emit_chain(g, self.m, self.cv1.emit(g, x), out=cat.slice(0, self.h))
-        self.cv2.emit(g, x, out=cat.slice(self.h, self.h))
+        x1, _ = _siblings(g, self.cv1, self.cv2, x, None, cat.slice(self.h, self.h))
+        _emit_chain(g, self.m, x1, out=cat.slice(0, self.h))
         return self.cv3.emit(g, cat, out=out)
 
 
@@ -124,9 +137,7 @@ class ELAN1(nn.Module):                 # model/utils.py:98-118
     def emit(self, g, x, out=None):
         h1, h2 = self.h1, self.h2
         cat = g.new(x.N, x.H, x.W, 2 * (h1 + h2))
-        with g.side_branch():                               # cv1 is independent of the cv2 -> ... -> cv6 chain
-            self.cv1.emit(g, x, out=cat.slice(0, h1))
-        x2 = self.cv2.emit(g, x, out=cat.slice(h1, h1))
+        _, x2 = _siblings(g, self.cv1, self.cv2, x, cat.slice(0, h1), cat.slice(h1, h1), fork=True)
         x3 = self.cv4.emit(g, self.cv3.emit(g, x2), out=cat.slice(2 * h1, h2))
         self.cv6.emit(g, self.cv5.emit(g, x3), out=cat.slice(2 * h1 + h2, h2))
         g.join_side()
@@ -149,9 +160,7 @@ class ELAN2(nn.Module):                 # model/utils.py:121-143
     def emit(self, g, x, out=None):
         h1, h2 = self.h1, self.h2
         cat = g.new(x.N, x.H, x.W, 2 * h1 + 4 * h2)
-        with g.side_branch():                               # cv1 is independent of the cv2 -> ... -> cv6 chain
-            self.cv1.emit(g, x, out=cat.slice(0, h1))
-        y = self.cv2.emit(g, x, out=cat.slice(h1, h1))
+        _, y = _siblings(g, self.cv1, self.cv2, x, cat.slice(0, h1), cat.slice(h1, h1), fork=True)
         for i, m in enumerate((self.cv3, self.cv4, self.cv5, self.cv6)):
             y = m.emit(g, y, out=cat.slice(2 * h1 + i * h2, h2))
         g.join_side()
@@ -262,10 +271,10 @@ class SPPCSPC(nn.Module):               # model/utils.py:264-282; cat order [x1,
     def emit(self, g, x, out=None):
         h = self.h
         cat4 = g.new(x.N, x.H, x.W, 4 * h)
-        x1 = self.cv4.emit(g, self.cv3.emit(g, self.cv1.emit(g, x)), out=cat4.slice(0, h))
+        cat2 = g.new(x.N, x.H, x.W, 2 * h)
+        t1, _ = _siblings(g, self.cv1, self.cv2, x, None, cat2.slice(h, h))
+        x1 = self.cv4.emit(g, self.cv3.emit(g, t1), out=cat4.slice(0, h))
         for i, k in enumerate(self.k):
             g.maxpool(x1, k, 1, out=cat4.slice((i + 1) * h, h))
-        cat2 = g.new(x.N, x.H, x.W, 2 * h)
         self.cv6.emit(g, self.cv5.emit(g, cat4), out=cat2.slice(0, h))
-        self.cv2.emit(g, x, out=cat2.slice(h, h))
         return self.cv7.emit(g, cat2, out=out)

@@ -35,17 +35,22 @@ def test_plan_builds(ver, mode, nc, training):
     direct_stem = names.count("ryolo_stem3x3_fwd")                 # 3x3 stride-1 stems (v4, v7) bypass im2col + GEMM
     assert direct_stem == (0 if ver == "yolov5" else 1)
     # eval plans re-parameterise every RepConv (3x3 + 1x1 -> one 3x3 GEMM); training plans keep both branches
-    from ryolov4_amd.model.blocks import RepConv
+    from ryolov4_amd.model.blocks import C3, CSP, ELAN1, ELAN2, SPPCSPC, RepConv
     nrep = sum(1 for x in m.modules() if isinstance(x, RepConv))
     assert nrep == (3 if ver == "yolov7" else 0)
-    assert names.count("ryolo_conv_gemm") == nconv - direct_stem - (0 if training else nrep)
+    # cv1 + cv2 of these blocks read the same input: ONE GEMM launch (training plans: every such block; eval plans: only where the two
+    # outputs are adjacent concat slices, i.e. the ELAN blocks — the folded-BN epilogue writes one destination)
+    npair = sum(1 for x in m.modules() if isinstance(x, (ELAN1, ELAN2) if not training else (ELAN1, ELAN2, CSP, C3, SPPCSPC)))
+    assert npair > 0 or (not training and ver != "yolov7")
+    assert names.count("ryolo_conv_gemm") == nconv - direct_stem - (0 if training else nrep) - npair
     if not training:
         assert [n for _, _, n in g.wprep].count("ryolo_repconv_fold") == nrep
     if training:
         bnames = [n for _, _, n in g.bwd]
-        assert bnames.count("ryolo_conv_wgrad") + bnames.count("ryolo_stem3x3_wgrad") == nconv
+        assert bnames.count("ryolo_conv_wgrad") + bnames.count("ryolo_stem3x3_wgrad") == nconv - npair
         assert bnames.count("ryolo_stem3x3_wgrad") == direct_stem
-        assert bnames.count("ryolo_conv_gemm") == nconv - 1          # every conv but the stem has a data gradient
+        assert bnames.count("ryolo_conv_gemm") == nconv - 1 - npair  # every conv but the stem has a data gradient (shared by siblings)
+        assert names.count("ryolo_bn_finalize_slice") == 2 * npair
         for p in m.parameters():
             assert rt.grad_view(p).shape == p.shape
     else:
@@ -88,7 +93,7 @@ def test_stream_plan_of_yolov7(training):
     m = Yolo(2, CFG, "kfiou", "yolov7")
     m.train(training)
     g = Runtime(m, torch.device("cpu")).graph(2, 64, 64, training)
-    nblocks = sum(1 for x in m.modules() if isinstance(x, (ELAN1, ELAN2, MaxConv)))
+    nblocks = sum(1 for x in m.modules() if isinstance(x, MaxConv))        # (the ELAN siblings share one GEMM launch: nothing to fork)
     firsts = [i for i, (first, lane) in g.fwd_side.items() if first]
     assert sum(1 for i in firsts if g.fwd_side[i][1] == 1) == nblocks
     assert sum(1 for i in firsts if g.fwd_side[i][1] == 2) == 2
