@@ -87,11 +87,22 @@ int ryolo_decode(int mode, const float* head, float* infer_out, int batch, int n
 int ryolo_pp_score(float* pred, int batch, int64_t M, int nc, float conf_thres, float* key, float* cls,
                    int32_t* count, ryolo_stream_t stream);
 
-/* sorted_key/order = stable descending sort of key along M.  Writes the top-K rows: dets [batch,K,7] =
+/* Score ordering on the device (csrc/topk.hip) — the `argsort(descending=True)[:max_nms]` of lib/general.py:166-168 and the score
+ * sort inside detectron2's nms_rotated, ties broken by ascending index.  Workspace for both: ryolo_sort_workspace_bytes
+ * (rows, n) with n = K resp. N.
+ * ryolo_topk_desc: per row of key [batch, M] the K <= 16384 largest entries in (key desc, index asc) order -> skey [batch, K]
+ * (-inf padded), order [batch, K] (-1 padded), nsel [batch] = entries selected (null ok); key == -inf is never selected.
+ * ryolo_argsort_desc: order [N] = stable descending argsort of scores [N]. */
+int ryolo_sort_workspace_bytes(int rows, int64_t n_sorted, size_t* bytes);
+int ryolo_topk_desc(const float* key, int batch, int64_t M, int K, float* skey, int64_t* order, int32_t* nsel, void* workspace,
+                    size_t workspace_bytes, ryolo_stream_t stream);
+int ryolo_argsort_desc(const float* scores, int64_t N, int64_t* order, void* workspace, size_t workspace_bytes, ryolo_stream_t stream);
+
+/* sorted_key/order (row stride `stride` >= K) = the top-K of key along M in (key desc, index asc) order.  Writes dets [batch,K,7] =
  * (x,y,w,h,theta_rad,score,cls) and rboxes [batch,K,5] = NMS boxes with class offset cls*max_wh on x,y and theta in
  * degrees (lib/general.py:166-174); count[b] is clamped to K. */
 int ryolo_pp_gather(const float* pred, const float* sorted_key, const int64_t* order, const float* cls, int batch,
-                    int64_t M, int nc, int64_t K, float max_wh, float* dets, float* rboxes, int32_t* count,
+                    int64_t M, int nc, int64_t K, int64_t stride, float max_wh, float* dets, float* rboxes, int32_t* count,
                     ryolo_stream_t stream);
 
 /* out [batch, keep_stride, 7]: out[b,j] = dets[b, keep[b,j]] for j < num_keep[b], zeros after (lib/general.py:181). */
@@ -125,6 +136,10 @@ int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
 int ryolo_stem3x3_plan(int NB, int H, int W, int Cout, int* stats_rows, size_t* wgrad_workspace_bytes);
 int ryolo_stem3x3_fwd(const StemParams* p, ryolo_stream_t stream);
 int ryolo_stem3x3_wgrad(const StemWgradParams* p, ryolo_stream_t stream);
+/* the whole backward of that layer (BatchNorm + activation backward, BatchNorm parameter gradients, weight gradient) in one pass over
+ * dz with the conv output recomputed from the image: Cout == 32, W % 32 == 0 (ryolo_stem3x3_bwd_plan returns UNSUPPORTED otherwise) */
+int ryolo_stem3x3_bwd_plan(int NB, int H, int W, int Cout, size_t* workspace_bytes);
+int ryolo_stem3x3_bwd(const StemBwdParams* p, ryolo_stream_t stream);
 
 /* training BatchNorm2d (eps, momentum of nn.BatchNorm2d; model/utils.py:17): partial [rows][2][C] (the buffer must have
  * room for 64 more rows: fold scratch for big layers) -> coeffs [4][C] =
@@ -183,7 +198,7 @@ int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int Ci
 /* torch.optim.SGD(momentum, nesterov=True) of train.py:156 over flat buffers: buf = mu*buf + g; p -= lr*(g + mu*buf) */
 int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, float mu, float gscale, int zero_grad,
                        ryolo_stream_t stream);   /* g is scaled by gscale on read; zero_grad=1 clears it (optimizer.zero_grad fused) */
-int ryolo_struct_sizes(int* sizes /* [10] */);
+int ryolo_struct_sizes(int* sizes /* [11] */);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Loss — replaces ComputeCSLLoss.__call__/build_targets (lib/loss.py:191-331) and ComputeKFIoULoss (:368-492),

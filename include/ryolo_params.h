@@ -52,8 +52,10 @@ typedef struct WgradParams {
 typedef struct StemParams {
     const float* img; int NB, H, W;                  // [NB, 3, H, W] fp32 (what train.py:186 hands over)
     const bf16_t* wf; int Cout;                      // packed weights [Cout][32], k = (r*3 + s)*3 + c, zero padded 27 -> 32; Cout <= 32
-    int epi;                                         // 0 raw, 1 BatchNorm statistics, 2 folded BN + activation
-    bf16_t* out; int ldC;
+    int epi;                                         // 0 raw, 1 BatchNorm statistics, 2 folded BN + activation (fp32 accumulator),
+                                                     // 5 the same on the bf16-ROUNDED conv output (training: bit-identical to storing the
+                                                     // raw output and running ryolo_bn_act_fwd over it)
+    bf16_t* out; int ldC;                            // out == null with epi 1: statistics only, nothing is stored
     float* stats;                                    // epi 1: [rows][2][Cout], rows from ryolo_stem3x3_plan
     const float* scale; const float* shift; int act; // epi 2
 } StemParams;
@@ -70,6 +72,21 @@ typedef struct StemWgradParams {
     const float* co;                                 // [4][Cout]: mean, invstd, scale, shift (ryolo_bn_finalize / ryolo_bn_eval_coeffs)
     const float* bco;                                // [2][Cout]: mean g, mean g*xhat (ryolo_bn_act_bwd with dy1 == null)
 } StemWgradParams;
+
+/* Whole backward of the first layer in ONE pass over dz (csrc/stem.hip): the raw conv output is RECOMPUTED from the image (K = 27),
+ * never stored; BatchNorm-backward sums, the BatchNorm parameter gradients and the weight gradient come out of the same pass:
+ * dW = sc*G + A*(W.XX) + B*X1 with G = sum g (x) patch, XX = sum patch (x) patch, g = dz*act'(sc*y + sh) (linear in g, so no second
+ * pass with the finished statistics is needed). */
+typedef struct StemBwdParams {
+    const float* img; int NB, H, W;                  // [NB, 3, H, W] fp32, W % 32 == 0
+    const bf16_t* dz; int lddz;                      // gradient of the layer's activation output [NB*H*W][lddz], 32 channels
+    const bf16_t* wf;                                // packed forward weights [32][32] (k = (r*3 + s)*3 + c, zero padded)
+    const float* co;                                 // [4][32]: mean, invstd, scale, shift
+    int act, frozen;                                 // frozen: fixed affine map (no coupling through the batch statistics)
+    float* workspace;                                // ryolo_stem3x3_bwd_plan bytes
+    float* dW;                                       // fp32 [32][3][3][3] (torch layout), accumulated
+    float* dgamma; float* dbeta;                     // accumulated; may be null
+} StemBwdParams;
 
 typedef struct BnActParams {
     const bf16_t* y1; int ld1; const float* co1;      // co = [4][C]: mean, invstd, scale, shift

@@ -492,8 +492,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
 {
     constexpr int DYS = CO64 ? 4096 : 8192;                       // bytes of one dY stage: [quarters][32 px][64 B]
     constexpr int NDY = CO64 ? 1 : 2;                             // dY pieces per wave per step
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cow = CO64 ? (wave & 1) : wave;                     // 32-channel quarter of this wave
     const int kh = CO64 ? (wave >> 1) : 0;                        // CO64: the 16-pixel half of each K step this wave multiplies
@@ -624,21 +622,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
         // 18 (16-pixel half, tap) MFMAs per step; the B fragment of MFMA i+PF is read while MFMA i runs (a software pipeline PF
         // fragments deep: all-reads-first exposes the LDS latency once per half and needs 36 live registers, the compiler's own
         // schedule double-buffers by one fragment and waits on every MFMA)
-        auto read_a = [&](int ks) {
-            const unsigned char* a = da + (ks * 16 + fr_row) * 64 + fr_col;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
-            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        };
+        // (transposed reads through inline asm + counted lgkmcnt: the builtin makes hipcc drain vmcnt(0) — this step's freshly issued
+        // DMA for step s + 2 — before the first read of every step, see conv_internal.h)
+        const unsigned da_a = lds_addr(da) + (unsigned)(fr_row * 64 + fr_col);
+        const unsigned xr_a = lds_addr(xring) + (unsigned)fr_col;
+        auto read_a = [&](int ks) { return lds_tr16x2(da_a + (unsigned)(ks * 16 * 64), 256u); };
         auto read_b = [&](int i) {
             const int ks = i / 9, t = i % 9;
             const unsigned qq = q0 + (unsigned)(g.toff[t] + ks * 16 + fr_row);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xring + (qq & rmask) * 64 + fr_col));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xring + ((qq + 4u) & rmask) * 64 + fr_col));
+            const ry_s16x4 lo = lds_tr16(xr_a + (qq & rmask) * 64u), hi = lds_tr16(xr_a + ((qq + 4u) & rmask) * 64u);
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
         constexpr int PF = 4;
         if constexpr (!CO64) {
+            // issue order: a0, b0..b3, a1, then b(i+4) in front of MFMA i.  Reads (two per fragment) issued AFTER the fragment MFMA i
+            // needs: i < 4: the rest of b0..b3, a1 and b4..b(i+4) = 10; 4 <= i < 14: four fragments = 8; then 6, 4, 2, 0.
             bf16x8 af[2], bq[18];
             af[0] = read_a(0);
 #pragma unroll
@@ -648,6 +646,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
             for (int i = 0; i < 18; i++) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + PF < 18) bq[i + PF] = read_b(i + PF);
+                if (i < 4) lds_wait2<10>(af[0], bq[i]);
+                else if (i < 14) lds_wait2<8>(af[1], bq[i]);
+                else if (i == 14) lds_wait<6>(bq[i]);
+                else if (i == 15) lds_wait<4>(bq[i]);
+                else if (i == 16) lds_wait<2>(bq[i]);
+                else lds_wait<0>(bq[i]);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
                 // -DW3_DMA_SHADOW: the step's DMA instructions between the MFMAs instead of at the top of the step — measured
@@ -663,14 +667,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
                 }
             }
         } else {
+            // (<= 64 output channels: 9 MFMAs per step and wave — here the compiler's own just-in-time lgkmcnt schedule around the
+            // builtin reads measured FASTER than the counted asm reads, 1.80 vs 2.02 ms at 64->64 @400^2, so this variant keeps it)
+            typedef __attribute__((address_space(3))) ry_s16x4 lds_s16x4;
+            auto read_a_b = [&](int ks) {
+                const unsigned char* a = da + (ks * 16 + fr_row) * 64 + fr_col;
+                const ry_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+                const ry_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 256));
+                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+            auto read_b_b = [&](int i) {
+                const int ks = i / 9, t = i % 9;
+                const unsigned qq = q0 + (unsigned)(g.toff[t] + ks * 16 + fr_row);
+                const ry_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xring + (qq & rmask) * 64 + fr_col));
+                const ry_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xring + ((qq + 4u) & rmask) * 64 + fr_col));
+                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
             bf16x8 bq[9];
-            const bf16x8 af = read_a(kh);
+            const bf16x8 af = read_a_b(kh);
 #pragma unroll
-            for (int i = 0; i < PF; i++) bq[i] = read_b(kh * 9 + i);
+            for (int i = 0; i < PF; i++) bq[i] = read_b_b(kh * 9 + i);
 #pragma unroll
             for (int i = 0; i < 9; i++) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (i + PF < 9) bq[i + PF] = read_b(kh * 9 + i + PF);
+                if (i + PF < 9) bq[i + PF] = read_b_b(kh * 9 + i + PF);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[i], acc[i], 0, 0, 0);
                 if (i == 2 || i == 5) {

@@ -9,7 +9,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-enum { EPI_RAW = 0, EPI_STATS = 1, EPI_AFFINE_ACT = 2, EPI_F32_BIAS = 3, EPI_ACCUM = 4 };
+enum { EPI_RAW = 0, EPI_STATS = 1, EPI_AFFINE_ACT = 2, EPI_F32_BIAS = 3, EPI_ACCUM = 4,
+       EPI_AFFINE_ACT_R = 5 };      // stem only: the conv output is rounded to bf16 BEFORE the affine map (= what the two-pass training path stores)
 enum { ACT_LINEAR = 0, ACT_MISH = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
 
 __device__ __forceinline__ float act_fwd(float u, int act)
@@ -38,6 +39,31 @@ __device__ __forceinline__ float act_bwd(float u, int act)
     }
     return 1.f;
 }
+
+// ---- LDS transposed reads (ds_read_b64_tr_b16) next to LDS-DMA -----------------------------------------------------------------
+// hipcc's waitcnt pass does not know what the ds_read_tr BUILTIN reads, so with LDS-DMA (global_load_lds) in flight it puts an
+// s_waitcnt vmcnt(0) in front of the first transposed read of every loop iteration: the DMA just issued for a LATER stage is
+// drained before the current stage is consumed, i.e. every K step pays a full memory round trip (seen in the ISA of the 3x3
+// ring weight gradient and of the stem backward; plain ds_read_b128 / ds_read_b32 through ordinary pointers are not affected).
+// Kernels that prefetch with LDS-DMA therefore issue their transposed reads through inline asm and count lgkmcnt themselves:
+// lds_wait<N>(frag) = "at most N of MY later LDS reads may still be in flight", tied to the fragment so that its consumer cannot be
+// scheduled above the wait.  (Reads the compiler issues on its own only make these waits more conservative: LDS returns in order.)
+typedef __attribute__((ext_vector_type(4))) short ry_s16x4;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ ry_s16x4 lds_tr16(unsigned addr)
+{
+    ry_s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+// 8 consecutive K values (pixels) of one channel: two transposed reads, `second` bytes apart
+__device__ __forceinline__ bf16x8 lds_tr16x2(unsigned addr, unsigned second)
+{
+    const ry_s16x4 lo = lds_tr16(addr), hi = lds_tr16(addr + second);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_wait2(bf16x8& f, bf16x8& g) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(g) : "n"(N)); }
 
 // bijective XCD remap (cdna guide T1): workgroup b runs on XCD b%8; give each XCD a contiguous tile range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)

@@ -1355,11 +1355,11 @@ extern "C" int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, flo
     return RY_OK;
 }
 
-extern "C" int ryolo_struct_sizes(int* sizes /*[10]*/)
+extern "C" int ryolo_struct_sizes(int* sizes /*[11]*/)
 {
     if (!sizes) return RY_ERR_ARG;
     sizes[0] = (int)sizeof(BnActParams); sizes[1] = (int)sizeof(PoolParams); sizes[2] = (int)sizeof(UpParams); sizes[3] = (int)sizeof(PackEntry);
     sizes[4] = (int)sizeof(ConvGemmParams); sizes[5] = (int)sizeof(WgradParams); sizes[6] = (int)sizeof(LossParams); sizes[7] = (int)sizeof(TapClass);
-    sizes[8] = (int)sizeof(StemParams); sizes[9] = (int)sizeof(StemWgradParams);
+    sizes[8] = (int)sizeof(StemParams); sizes[9] = (int)sizeof(StemWgradParams); sizes[10] = (int)sizeof(StemBwdParams);
     return RY_OK;
 }

@@ -4,7 +4,7 @@
 //
 //   pp_score_kernel   cls *= obj IN PLACE (lib/general.py:155 mutates its input — kept), max over classes with the
 //                     first-max rule, conf > conf_thres filter (strict, :161) encoded as key = -inf, per-image count.
-//   (stable descending sort of the keys: see r-yolov4_amd/lib/general.py)
+//   (top-K of the keys by (score desc, index asc): csrc/topk.hip)
 //   pp_gather_kernel  top-K rows in sorted order -> dets[B,K,7] and the NMS boxes (class offset 4096 px, rad->deg).
 //   pp_emit_kernel    dets[keep] -> compact output rows.
 // HBM-bound: algorithmic bytes = 4*B*M*(nc+6) read + 4*B*M*nc written back (the in-place product) + O(K).
@@ -37,14 +37,14 @@ __global__ void pp_score_kernel(float* __restrict__ pred /*[B,M,nc+6] mutated*/,
 
 __global__ void pp_gather_kernel(const float* __restrict__ pred, const float* __restrict__ sorted_key /*[B,M] desc*/,
                                  const int64_t* __restrict__ order /*[B,M]*/, const float* __restrict__ cls, int B, int64_t M, int nc,
-                                 int64_t K, float max_wh, float* __restrict__ dets /*[B,K,7]*/, float* __restrict__ rboxes /*[B,K,5]*/,
+                                 int64_t K, int64_t stride /*row stride of sorted_key / order*/, float max_wh, float* __restrict__ dets /*[B,K,7]*/, float* __restrict__ rboxes /*[B,K,5]*/,
                                  int32_t* __restrict__ count /*[B] in: #pass, out: min(#pass,K)*/)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (k == 0) { const int c = count[b]; if (c > K) count[b] = (int32_t)K; }   // readers use min(count,K) themselves
     if (k >= K) return;
-    const float s = sorted_key[(int64_t)b * M + k];
+    const float s = sorted_key[(int64_t)b * stride + k];
     float* d = dets + ((int64_t)b * K + k) * 7;
     float* r = rboxes + ((int64_t)b * K + k) * 5;
     if (!(s > -INFINITY)) {
@@ -52,7 +52,7 @@ __global__ void pp_gather_kernel(const float* __restrict__ pred, const float* __
         for (int j = 0; j < 5; j++) r[j] = 0.f;
         return;
     }
-    const int64_t src = order[(int64_t)b * M + k];
+    const int64_t src = order[(int64_t)b * stride + k];
     const float* p = pred + ((int64_t)b * M + src) * (nc + 6);
     const float c = cls[(int64_t)b * M + src];
     const float x = p[0], y = p[1], w = p[2], h = p[3], th = p[4];
@@ -93,14 +93,14 @@ extern "C" int ryolo_pp_score(float* pred, int batch, int64_t M, int nc, float c
 }
 
 extern "C" int ryolo_pp_gather(const float* pred, const float* sorted_key, const int64_t* order, const float* cls, int batch,
-                               int64_t M, int nc, int64_t K, float max_wh, float* dets, float* rboxes, int32_t* count,
+                               int64_t M, int nc, int64_t K, int64_t stride, float max_wh, float* dets, float* rboxes, int32_t* count,
                                hipStream_t stream)
 {
-    if (batch < 0 || M < 0 || K < 0 || K > M) return RY_ERR_ARG;
+    if (batch < 0 || M < 0 || K < 0 || K > M || stride < K) return RY_ERR_ARG;
     if (batch == 0 || K == 0) return RY_OK;
     if (!pred || !sorted_key || !order || !cls || !dets || !rboxes || !count) return RY_ERR_ARG;
     hipLaunchKernelGGL(pp_gather_kernel, dim3((unsigned)ry_cdiv(K, 256), batch), dim3(256), 0, stream, pred, sorted_key, order, cls,
-                       batch, M, nc, K, max_wh, dets, rboxes, count);
+                       batch, M, nc, K, stride, max_wh, dets, rboxes, count);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -15,6 +15,9 @@
 // Both are memory streams (0.5 + 2.6 GB each); nothing here is worth an LDS tile.
 #include "conv_internal.h"
 #include <type_traits>
+#include <stdlib.h>
+
+#define STEM_BWD_SLAB 2112                 // floats per slab of the fused backward: G 1024 + XX 1024 + S0 32 + S1 32
 
 // k -> (channel, row tap, column tap) of the im2col ordering k = (r*3 + s)*3 + c
 __device__ __forceinline__ void stem_k(int k, int& c, int& r, int& s)
@@ -112,12 +115,18 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) v[q] = acc[4 * g4 + q];
-            if (p.epi == EPI_AFFINE_ACT && c0 < p.Cout) {
+            if (p.epi == EPI_AFFINE_ACT_R) {
+                // training: the raw output as the two-pass path would have stored it (bf16), then BatchNorm + activation on THAT
+                const uint2 r = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+                v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+            }
+            if ((p.epi == EPI_AFFINE_ACT || p.epi == EPI_AFFINE_ACT_R) && c0 < p.Cout) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) v[q] = act_fwd(v[q] * p.scale[c0 + q] + p.shift[c0 + q], p.act);
             }
             const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            *reinterpret_cast<uint2*>(&otile[wave][px_l][c0]) = w;             // staged: the lane's 8-byte piece of its pixel row
+            if (p.out) *reinterpret_cast<uint2*>(&otile[wave][px_l][c0]) = w;  // staged: the lane's 8-byte piece of its pixel row
             if (p.epi == EPI_STATS && live) {
                 const float f0 = __uint_as_float(w.x << 16), f1 = __uint_as_float(w.x & 0xffff0000u);
                 const float f2 = __uint_as_float(w.y << 16), f3 = __uint_as_float(w.y & 0xffff0000u);
@@ -129,16 +138,251 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
         }
         // whole pixel rows to HBM: lane -> (pixel = lane >> 2 (+16), 16-byte slot = lane & 3); one instruction = 16 rows x 64 B.
         // (direct 8-byte stores from the MFMA layout touched 32 rows per instruction, 16 B each: request-rate bound)
+        if (p.out) {
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int pr = half * 16 + (lane >> 2), sl = lane & 3;
-            const int64_t opix = tt * 32 + pr;
-            const uint4 o = *reinterpret_cast<const uint4*>(&otile[wave][pr][sl * 8]);
-            if (opix < M && sl * 8 < p.Cout) *reinterpret_cast<uint4*>(p.out + opix * p.ldC + sl * 8) = o;
+            for (int half = 0; half < 2; half++) {
+                const int pr = half * 16 + (lane >> 2), sl = lane & 3;
+                const int64_t opix = tt * 32 + pr;
+                const uint4 o = *reinterpret_cast<const uint4*>(&otile[wave][pr][sl * 8]);
+                if (opix < M && sl * 8 < p.Cout) *reinterpret_cast<uint4*>(p.out + opix * p.ldC + sl * 8) = o;
+            }
         }
     }
     if (p.epi == EPI_STATS) {
         // fold the 32 pixel lanes of each half-wave, then the 4 waves; one partial-statistics row per workgroup
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float a = ssum[e], b = ssq[e];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            if (px_l == 0) {
+                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                red[wave][0][c] = a;
+                red[wave][1][c] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * 32) {
+            const int c = tid & 31, which = tid >> 5;
+            if (c < p.Cout) p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- LDS patch scheme
+// (W % 32 == 0: a 32-pixel tile never leaves its image row.)  The gather above keeps 16 loaded floats per lane alive per tile and
+// the kernel runs at the latency of one tile per wave (128+ VGPRs -> 2-4 waves per SIMD, ~2.7 TB/s).  Here the 3 channels x 3 rows x
+// 40 columns around a tile (90 16-byte pieces) arrive by LDS-DMA — two instructions per wave, no VGPRs, zero page for the image border —
+// into a wave-private double buffer, one tile AHEAD of the one being computed (nothing register-resident crosses the loop back
+// edge, so hipcc's waitcnt pass leaves the counted vmcnt alone).  MFMA operands are then built from LDS with compile-time offsets.
+__device__ __attribute__((aligned(16))) float stem_zero_page[64];                               // DMA source of out-of-image elements
+
+#define SP_ROW 40                                                  // floats per (channel, row): columns ow0 - 4 ... ow0 + 35
+#define SP_PIECES 90                                               // 9 (channel, row) lines x ten 16-byte pieces
+#define SP_BYTES 2048                                              // two 1-KiB DMA instructions (the second one 26 lanes wide)
+
+// 16-byte pieces: ow0 % 32 == 0 and W % 32 == 0 make every piece of a line 16-byte aligned in the image, and a piece is either
+// completely inside or completely outside the image (first / last piece of a line at the left / right border, whole lines at the
+// top / bottom) -> outside pieces come from a zero page.  (The first version moved dwords: five instructions of 256 bytes per tile;
+// an LDS-DMA instruction costs 100-185 issue cycles whatever its width.)
+struct StemPatchLane { int off[2]; unsigned flg[2]; };             // per lane: piece j = 64 u + lane of the patch
+
+__device__ __forceinline__ void stem_patch_lane(StemPatchLane& L, int lane, int H, int W)
+{
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int j = 64 * u + lane;
+        const int line = j / 10, pc = j - line * 10;              // line = c*3 + r
+        const int c = line / 3, r = line - c * 3;
+        L.off[u] = (c * H + (r - 1)) * W + 4 * pc - 4;
+        L.flg[u] = (j < SP_PIECES ? 1u : 0u) | (r == 0 ? 2u : 0u) | (r == 2 ? 4u : 0u) | (pc == 0 ? 8u : 0u) | (pc == 9 ? 16u : 0u);
+    }
+}
+
+// issue the patch of the tile at (n, oh, ow0): base = (n*3*H + oh)*W + ow0
+__device__ __forceinline__ void stem_patch_issue(const StemPatchLane& L, const float* __restrict__ img, int base, int oh, int ow0, int H, int W,
+                                                 unsigned char* lds)
+{
+    unsigned bad = 0;                                              // flag bits that make a piece fall outside the image
+    if (oh < 1) bad |= 2u;
+    if (oh + 1 >= H) bad |= 4u;
+    if (ow0 < 1) bad |= 8u;
+    if (ow0 + 32 >= W) bad |= 16u;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const bool ok = (L.flg[u] & 1u) && !(L.flg[u] & bad);
+        const float* src = ok ? img + base + L.off[u] : stem_zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(lds + u * 1024), 16, 0, 0);
+    }
+}
+
+// patch index of im2col position k (= (r*3 + s)*3 + c) for the pixel at column 0 of the tile: (c*3 + r)*40 + s + 3
+__host__ __device__ constexpr int sp_kidx(int k) { return ((k % 3) * 3 + (k / 3) / 3) * SP_ROW + (k / 3) % 3 + 3; }
+
+// K order of the 27-tap contraction.  The order of a GEMM's K dimension is free as long as both operands agree, so it is chosen
+// for the LDS reads: lane (pixel l31, half h) owns 16 slots whose patch offsets are COMPILE-TIME constants relative to two
+// per-lane bases (no address VALU per read — the first version spent ~60 VALU instructions per tile on selects and adds):
+//   slots 0-8   channel h,  (r, s) = (j / 3, j % 3)            base A = l31 + 120 h  (one channel = 3 lines of 40 floats)
+//   slots 9-14  channel 2,  r = (j - 9) / 3 + h, s = (j - 9) % 3   base B = l31 + 40 h   (h = 1 starts one line lower; its r = 1
+//               slots duplicate h = 0's and carry ZERO weights)
+//   slot 15     unused (zero weight)
+__host__ __device__ constexpr int sp_slot_imm(int j) { return j < 9 ? (j / 3) * SP_ROW + j % 3 + 3 : (6 + (j - 9) / 3) * SP_ROW + (j - 9) % 3 + 3; }
+// im2col index k of slot j for half h, -1: zero weight
+__host__ __device__ constexpr int sp_slot_k(int h, int j)
+{
+    return j < 9 ? ((j / 3) * 3 + j % 3) * 3 + h
+                 : (j < 15 ? ((h && (j - 9) / 3 == 0) ? -1 : ((((j - 9) / 3 + h) * 3 + (j - 9) % 3) * 3 + 2)) : -1);
+}
+
+// weight fragments in slot order for output channel `co` (row / column l31 of the operand), half h
+__device__ __forceinline__ void stem_slot_weights(const bf16_t* __restrict__ wf, int co, int h, bool live, bf16x8& w0, bf16x8& w1)
+{
+    unsigned short v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int k0 = sp_slot_k(0, j), k1 = sp_slot_k(1, j);
+        const int k = h ? k1 : k0;
+        v[j] = (live && k >= 0) ? wf[co * 32 + (k >= 0 ? k : 0)] : (unsigned short)0;
+    }
+    w0 = __builtin_bit_cast(bf16x8, make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)));
+    w1 = __builtin_bit_cast(bf16x8, make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16)));
+}
+
+// the 16 patch values of lane (pixel l31, half h) in slot order, packed as the two K16 operands; pa / pb = LDS byte address of the
+// patch + base A / base B.  Inline-asm reads with their own lgkmcnt wait: next to the LDS staging stores of the forward kernel hipcc
+// otherwise drains vmcnt(0) — the prefetch of the NEXT tile — in front of the first read of every tile (conv_internal.h).
+template <int J> __device__ __forceinline__ float sp_read(unsigned pa, unsigned pb)
+{
+    float r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(J < 9 ? pa : pb), "n"(sp_slot_imm(J) * 4) : "memory");
+    return r;
+}
+__device__ __forceinline__ void stem_patch_pixel_frags(unsigned pa, unsigned pb, bf16x8& f0, bf16x8& f1)
+{
+    float v0 = sp_read<0>(pa, pb), v1 = sp_read<1>(pa, pb), v2 = sp_read<2>(pa, pb), v3 = sp_read<3>(pa, pb), v4 = sp_read<4>(pa, pb);
+    float v5 = sp_read<5>(pa, pb), v6 = sp_read<6>(pa, pb), v7 = sp_read<7>(pa, pb), v8 = sp_read<8>(pa, pb), v9 = sp_read<9>(pa, pb);
+    float v10 = sp_read<10>(pa, pb), v11 = sp_read<11>(pa, pb), v12 = sp_read<12>(pa, pb), v13 = sp_read<13>(pa, pb), v14 = sp_read<14>(pa, pb);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9), "+v"(v10), "+v"(v11),
+                   "+v"(v12), "+v"(v13), "+v"(v14));
+    f0 = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(v0, v1), pack_bf2(v2, v3), pack_bf2(v4, v5), pack_bf2(v6, v7)));
+    f1 = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(v8, v9), pack_bf2(v10, v11), pack_bf2(v12, v13), pack_bf2(v14, 0.f)));
+}
+
+// (image, row, first column) of a wave's current tile, advanced by a fixed number of tiles with carries: no division in the loop
+struct StemWalk {
+    int n, oh, ow, an, ah, aw;
+    __device__ __forceinline__ void init(int64_t tile, int64_t stride_tiles, int H, int W)
+    {
+        const int HW = H * W;
+        const int64_t p0 = tile * 32;
+        n = (int)(p0 / HW);
+        const int rem = (int)(p0 - (int64_t)n * HW);
+        oh = rem / W;
+        ow = rem - oh * W;
+        const int64_t adv = stride_tiles * 32;
+        an = (int)(adv / HW);
+        const int ar = (int)(adv - (int64_t)an * HW);
+        ah = ar / W;
+        aw = ar - ah * W;
+    }
+    __device__ __forceinline__ void step(int H, int W)
+    {
+        ow += aw; oh += ah; n += an;
+        if (ow >= W) { ow -= W; oh++; }
+        if (oh >= H) { oh -= H; n++; }
+    }
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void stem3x3_fwd_lds_kernel(const StemParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char patch[4][2][SP_BYTES];
+    __shared__ float red[4][2][32];
+    __shared__ __attribute__((aligned(16))) bf16_t otile[4][32][40];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px_l = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int64_t M = (int64_t)p.NB * HW;
+    const int64_t ntiles = M >> 5;
+    StemPatchLane L;
+    stem_patch_lane(L, lane, H, W);
+    bf16x8 wfrag[2];
+    stem_slot_weights(p.wf, px_l, h, px_l < p.Cout, wfrag[0], wfrag[1]);
+    constexpr bool affine = EPI == EPI_AFFINE_ACT || EPI == EPI_AFFINE_ACT_R;
+    float sc[16], sh[16];                                          // this lane's 16 channels: c = 8*g4 + 4*h + q
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+        sc[e] = affine && c < p.Cout ? p.scale[c] : 1.f;
+        sh[e] = affine && c < p.Cout ? p.shift[c] : 0.f;
+    }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tt = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    StemWalk nx;                                                   // the tile whose patch is issued next
+    nx.init(tt < ntiles ? tt : 0, stride, H, W);
+    auto issue = [&](int buf) { stem_patch_issue(L, p.img, (nx.n * 3 * H + nx.oh) * W + nx.ow, nx.oh, nx.ow, H, W, &patch[wave][buf][0]); };
+    if (tt < ntiles) issue(0);
+    const int offA = (px_l + 120 * h) * 4, offB = (px_l + 40 * h) * 4;
+    int buf = 0;
+    for (; tt < ntiles; tt += stride, buf ^= 1) {
+        // prefetch the next tile (always 2 DMA instructions: past the end they re-read the last tile), then wait for everything older
+        if (tt + stride < ntiles) nx.step(H, W);
+        issue(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        bf16x8 f0, f1;
+        const unsigned pbase = lds_addr(&patch[wave][buf][0]);
+        stem_patch_pixel_frags(pbase + (unsigned)offA, pbase + (unsigned)offB, f0, f1);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[0], f0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[1], f1, acc, 0, 0, 0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int c0 = 8 * g4 + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = acc[4 * g4 + q];
+            if (EPI == EPI_AFFINE_ACT_R) {
+                const uint2 r = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+                v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+            }
+            if (affine) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = act_fwd(v[q] * sc[4 * g4 + q] + sh[4 * g4 + q], p.act);
+            }
+            const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (p.out) *reinterpret_cast<uint2*>(&otile[wave][px_l][c0]) = w;
+            if (EPI == EPI_STATS) {
+                const float f0s = __uint_as_float(w.x << 16), f1s = __uint_as_float(w.x & 0xffff0000u);
+                const float f2s = __uint_as_float(w.y << 16), f3s = __uint_as_float(w.y & 0xffff0000u);
+                ssum[4 * g4 + 0] += f0s; ssq[4 * g4 + 0] += f0s * f0s;
+                ssum[4 * g4 + 1] += f1s; ssq[4 * g4 + 1] += f1s * f1s;
+                ssum[4 * g4 + 2] += f2s; ssq[4 * g4 + 2] += f2s * f2s;
+                ssum[4 * g4 + 3] += f3s; ssq[4 * g4 + 3] += f3s * f3s;
+            }
+        }
+        if (p.out) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int pr = half * 16 + (lane >> 2), sl = lane & 3;
+                const int64_t opix = tt * 32 + pr;
+                const uint4 o = *reinterpret_cast<const uint4*>(&otile[wave][pr][sl * 8]);
+                if (sl * 8 < p.Cout) *reinterpret_cast<uint4*>(p.out + opix * p.ldC + sl * 8) = o;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (EPI == EPI_STATS) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             float a = ssum[e], b = ssq[e];
@@ -314,8 +558,201 @@ __global__ __launch_bounds__(1024) void stem_fold_kernel(const float* __restrict
     out[(int64_t)blockIdx.x * 1024 + i] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------- fused backward
+// The layer's whole backward in ONE pass over dz (2.6 GB at 800^2 x 64) + the image (0.5 GB): before, the raw conv output y was
+// stored by the forward (2.6 GB), re-read by the BatchNorm pass, by the BatchNorm-backward reduction (with dz) and by the weight
+// gradient (with dz again): 8 tensor passes over the largest activation of the network.  Here y is RECOMPUTED (K = 27: two MFMAs
+// per 32 pixels) and everything that needs the finished batch statistics is moved behind the pass by linearity:
+//     dy = sc*g + A*y + B          (g = dz * act'(sc*y + sh);  A, B from S0 = sum g, S1 = sum g*y)
+//     dW = sum dy (x) patch = sc * G + A * Yx + B * X1,   G = sum g (x) patch,  Yx = sum y (x) patch = W . XX,  XX = sum patch (x) patch
+// One wave = 32 consecutive pixels of an image row per step.
+//   recompute   D[px][c] = patch[px][k] . W[c][k]: the lane = (pixel, k half) gather of the forward kernel as the A operand, the weight
+//               fragments as B -> a lane ends with ONE channel (lane & 31) and 16 pixels {4h + 8m + q}: per-channel constants are
+//               four registers, the BatchNorm sums two scalar accumulators;
+//   dz          LDS-DMA (2 KiB tile) + four transposed reads deliver exactly those (channel, 16 pixels) per lane;
+//   G, XX       K = pixels.  The A operand (g) is packed straight from the registers above — the K order of a GEMM is free as long as
+//               both operands agree, so the B operand (patch column k = lane & 31) loads the SAME pixel set: two runs of 4
+//               consecutive floats per K16 step.  No LDS round trip, no second pass.  Column k = 27 carries ones: XX[27][k] = X1[k].
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void stem3x3_bwd_kernel(const StemBwdParams p, float* __restrict__ slabs)
+{
+    // wave-private double buffers: image patch (LDS-patch scheme above) + the dz tile [32 px][32 ch] bf16; reused for the final fold
+    constexpr int WAVE_BYTES = 2 * (SP_BYTES + 2048);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * WAVE_BYTES > 4 * 32 * 33 * 4 ? 4 * WAVE_BYTES : 4 * 32 * 33 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int64_t M = (int64_t)p.NB * HW;
+    const int64_t ntiles = M >> 5;                                 // W % 32 == 0: every tile lies in one image row
+    unsigned char* const wbase = lds + wave * WAVE_BYTES;
+    auto patch_buf = [&](int b) { return wbase + b * (SP_BYTES + 2048); };
+    auto dz_buf = [&](int b) { return wbase + b * (SP_BYTES + 2048) + SP_BYTES; };
+    StemPatchLane L;
+    stem_patch_lane(L, lane, H, W);
+    bf16x8 wfrag[2];                                               // B operand of the recompute: column = output channel l31, slot order
+    stem_slot_weights(p.wf, l31, h, true, wfrag[0], wfrag[1]);
+    const float sc = p.co[2 * 32 + l31], sh = p.co[3 * 32 + l31];
+    // patch column of the K = pixels GEMMs: lane = (k = l31, pixel group h) reads patch[krun + 8*rr + e]
+    const bool kok = l31 < 27;
+    const float kfill = l31 == 27 ? 1.f : 0.f;                     // column 27 carries ones: XX[27][k] = X1[k]
+    const int krun = (kok ? sp_kidx(l31) : 0) + 4 * h;
+    // transposed read of dz: 16-lane group -> (channel half, pixel group h); quad m adds 8*m pixel rows
+    const int s16 = lane & 15, grp = lane >> 4;
+    const int tr_off = ((grp >> 1) * 4 + (s16 >> 2)) * 64 + (16 * (grp & 1) + 4 * (s16 & 3)) * 2;
+    const int d_row = lane >> 2, d_slot = lane & 3;
+
+    f32x16 accG, accX;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { accG[e] = 0.f; accX[e] = 0.f; }
+    float s0 = 0.f, s1 = 0.f;
+
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tt = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    StemWalk nx;                                                   // the tile whose operands are issued next
+    nx.init(tt < ntiles ? tt : 0, stride, H, W);
+    const bf16_t* dz_lane = p.dz + (int64_t)d_row * p.lddz + d_slot * 8;
+    auto issue = [&](int b) {                                       // 4 DMA instructions: the patch (2) + the 2-KiB dz tile (2)
+        stem_patch_issue(L, p.img, (nx.n * 3 * H + nx.oh) * W + nx.ow, nx.oh, nx.ow, H, W, patch_buf(b));
+        const int64_t t0 = ((int64_t)nx.n * H + nx.oh) * W + nx.ow;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(dz_lane + (t0 + 16 * u) * (int64_t)p.lddz), (lds_void_t*)(dz_buf(b) + u * 1024), 16, 0, 0);
+    };
+    if (tt < ntiles) issue(0);
+    const int offA = (l31 + 120 * h) * 4, offB = (l31 + 40 * h) * 4;
+    int buf = 0;
+    for (; tt < ntiles; tt += stride, buf ^= 1) {
+        if (tt + stride < ntiles) nx.step(H, W);
+        issue(buf ^ 1);                                            // next tile in flight (past the end: a harmless re-read of the last)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // this tile has landed (wave-private buffers: no barrier)
+        const float* patch = reinterpret_cast<const float*>(patch_buf(buf));
+        // dz for this lane's (channel, 16 pixels): four transposed reads, through inline asm (the builtin would make hipcc drain the
+        // prefetch just issued, conv_internal.h); waited for below, after the recompute
+        ry_s16x4 dq[4];
+        const unsigned dz_a = lds_addr(dz_buf(buf)) + (unsigned)tr_off;
+#pragma unroll
+        for (int m = 0; m < 4; m++) dq[m] = lds_tr16(dz_a + (unsigned)(m * 8 * 64));
+        // y[px][c] on this lane: channel l31, pixels q + 8m + 4h at acc[4m + q]
+        bf16x8 f0, f1;
+        const unsigned pbase = lds_addr(patch_buf(buf));
+        stem_patch_pixel_frags(pbase + (unsigned)offA, pbase + (unsigned)offB, f0, f1);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wfrag[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, wfrag[1], acc, 0, 0, 0);
+        // patch column runs: pixels {8*rr + 4h + e}
+        float xr[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float x = patch[krun + 8 * (i >> 2) + (i & 3)];
+            xr[i] = kok ? x : kfill;
+        }
+        unsigned gp[8];                                              // g packed: pairs (e, e+1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint2 d2 = __builtin_bit_cast(uint2, dq[m]);
+            const unsigned dd[2] = {d2.x, d2.y};
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const unsigned yr = pack_bf2(acc[4 * m + 2 * hh], acc[4 * m + 2 * hh + 1]);        // raw output as stored by the two-pass path
+                const float y0 = __uint_as_float(yr << 16), y1 = __uint_as_float(yr & 0xffff0000u);
+                const float d0 = __uint_as_float(dd[hh] << 16), d1 = __uint_as_float(dd[hh] & 0xffff0000u);
+                const float g0 = d0 * act_bwd(y0 * sc + sh, p.act), g1 = d1 * act_bwd(y1 * sc + sh, p.act);
+                s0 += g0 + g1;
+                s1 += g0 * y0 + g1 * y1;
+                gp[2 * m + hh] = pack_bf2(g0, g1);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(gp[4 * s2], gp[4 * s2 + 1], gp[4 * s2 + 2], gp[4 * s2 + 3]));
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(xr[8 * s2 + 0], xr[8 * s2 + 1]), pack_bf2(xr[8 * s2 + 2], xr[8 * s2 + 3]),
+                                                                   pack_bf2(xr[8 * s2 + 4], xr[8 * s2 + 5]), pack_bf2(xr[8 * s2 + 6], xr[8 * s2 + 7])));
+            accG = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accG, 0, 0, 0);
+            accX = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, bf, accX, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- one slab per workgroup: G [32][32], XX [32][32], S0 [32], S1 [32]
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(lds);
+    float* slab = slabs + (int64_t)blockIdx.x * STEM_BWD_SLAB;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e++) red[wave][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = pass ? accX[e] : accG[e];
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            slab[pass * 1024 + i] = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c];
+        }
+    }
+    __syncthreads();
+    red[wave][h][l31] = s0;
+    red[wave][2 + h][l31] = s1;
+    __syncthreads();
+    if (tid < 64) {
+        const int c = tid & 31, which = tid >> 5;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) t += red[w][2 * which][c] + red[w][2 * which + 1][c];
+        slab[2048 + which * 32 + c] = t;
+    }
+}
+
+// out[g][width] = sum of slabs g, g + G, g + 2G, ... (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void stem_fold_wide_kernel(const float* __restrict__ slabs, int nslab, int width, float* __restrict__ out)
+{
+    for (int i = threadIdx.x; i < width; i += 1024) {
+        float s = 0.f;
+        for (int z = blockIdx.x; z < nslab; z += gridDim.x) s += slabs[(int64_t)z * width + i];
+        out[(int64_t)blockIdx.x * width + i] = s;
+    }
+}
+
+// folded slab -> BatchNorm coefficients of the backward, dgamma / dbeta, and dW = sc*G + A*(W.XX) + B*X1 into the torch-layout .grad
+__global__ __launch_bounds__(1024) void stem_bwd_finalize_kernel(const float* __restrict__ part /*[64][SLAB]*/, const StemBwdParams p, double count)
+{
+    __shared__ double G[32][33], XX[32][33], S[2][32];
+    const int i = threadIdx.x, r = i >> 5, c = i & 31;
+    double g = 0.0, x = 0.0;
+    for (int z = 0; z < 64; z++) {
+        g += (double)part[(int64_t)z * STEM_BWD_SLAB + i];
+        x += (double)part[(int64_t)z * STEM_BWD_SLAB + 1024 + i];
+    }
+    G[r][c] = g;
+    XX[r][c] = x;
+    if (i < 64) {
+        double t = 0.0;
+        for (int z = 0; z < 64; z++) t += (double)part[(int64_t)z * STEM_BWD_SLAB + 2048 + i];
+        S[i >> 5][i & 31] = t;
+    }
+    __syncthreads();
+    // thread (r = output channel, c = k)
+    const double mu = p.co[r], is = p.co[32 + r], scd = p.co[64 + r];
+    const double S0 = S[0][r], S1 = S[1][r];
+    const double gx = is * (S1 - mu * S0);                          // sum g * xhat
+    const double mg = p.frozen ? 0.0 : S0 / count, mx = p.frozen ? 0.0 : gx / count;
+    if (c == 0) {
+        if (p.dgamma) p.dgamma[r] += (float)gx;
+        if (p.dbeta) p.dbeta[r] += (float)S0;
+    }
+    if (c < 27) {
+        double yx = 0.0;
+        for (int k = 0; k < 27; k++) yx += (double)bf2f(p.wf[r * 32 + k]) * XX[k][c];
+        const double A = -scd * is * mx, B = scd * (is * mx * mu - mg);
+        const double dw = scd * G[r][c] + A * yx + B * XX[27][c];
+        const int tap = c / 3, cin = c - tap * 3;
+        p.dW[(r * 3 + cin) * 9 + tap] += (float)dw;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------- C ABI
 static int stem_blocks(int64_t M) { const int64_t t = ry_cdiv(M, 32 * 4 * 8); return (int)(t > 2048 ? 2048 : (t < 1 ? 1 : t)); }
+// LDS-patch kernels: the grid is what is resident at once (256 CUs x up to 4 workgroups), every wave walks its tiles with a prefetch
+static int stem_lds_blocks(int64_t M, int per_cu = 4) { const int64_t t = ry_cdiv(M, 32 * 4 * 2), cap = 256 * per_cu; return (int)(t > cap ? cap : (t < 1 ? 1 : t)); }
+static bool stem_no_lds() { static const bool v = getenv("RYOLO_STEM_NO_LDS") != nullptr; return v; }   // A/B: the register-gather forward
 
 static bool stem_ok(int NB, int H, int W, int Cout)
 {
@@ -326,19 +763,27 @@ extern "C" int ryolo_stem3x3_plan(int NB, int H, int W, int Cout, int* stats_row
 {
     if (!stem_ok(NB, H, W, Cout)) return RY_ERR_UNSUPPORTED;
     const int nb = stem_blocks((int64_t)NB * H * W);
-    if (stats_rows) *stats_rows = nb;
+    if (stats_rows) *stats_rows = (W % 32 == 0 && !stem_no_lds()) ? stem_lds_blocks((int64_t)NB * H * W) : nb;
     if (wgrad_workspace_bytes) *wgrad_workspace_bytes = (size_t)(nb + 64) * 1024 * sizeof(float);
     return RY_OK;
 }
 
 extern "C" int ryolo_stem3x3_fwd(const StemParams* pp, hipStream_t stream)
 {
-    if (!pp || !pp->img || !pp->wf || !pp->out) return RY_ERR_ARG;
+    if (!pp || !pp->img || !pp->wf) return RY_ERR_ARG;
     const StemParams& p = *pp;
-    if (!stem_ok(p.NB, p.H, p.W, p.Cout) || p.ldC % 8 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return RY_ERR_UNSUPPORTED;
-    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT) return RY_ERR_ARG;
-    if ((p.epi == EPI_STATS && !p.stats) || (p.epi == EPI_AFFINE_ACT && (!p.scale || !p.shift))) return RY_ERR_ARG;
-    hipLaunchKernelGGL(stem3x3_fwd_kernel, dim3((unsigned)stem_blocks((int64_t)p.NB * p.H * p.W)), dim3(256), 0, stream, p);
+    if (!p.out && p.epi != EPI_STATS) return RY_ERR_ARG;          // statistics-only pass: nothing stored
+    if (!stem_ok(p.NB, p.H, p.W, p.Cout) || (p.out && (p.ldC % 8 || (reinterpret_cast<uintptr_t>(p.out) & 15)))) return RY_ERR_UNSUPPORTED;
+    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT && p.epi != EPI_AFFINE_ACT_R) return RY_ERR_ARG;
+    if ((p.epi == EPI_STATS && !p.stats) || ((p.epi == EPI_AFFINE_ACT || p.epi == EPI_AFFINE_ACT_R) && (!p.scale || !p.shift))) return RY_ERR_ARG;
+    if (p.W % 32 == 0 && !stem_no_lds()) {
+        const dim3 g((unsigned)stem_lds_blocks((int64_t)p.NB * p.H * p.W)), b(256);
+        if (p.epi == EPI_STATS) hipLaunchKernelGGL(stem3x3_fwd_lds_kernel<EPI_STATS>, g, b, 0, stream, p);
+        else if (p.epi == EPI_AFFINE_ACT) hipLaunchKernelGGL(stem3x3_fwd_lds_kernel<EPI_AFFINE_ACT>, g, b, 0, stream, p);
+        else if (p.epi == EPI_AFFINE_ACT_R) hipLaunchKernelGGL(stem3x3_fwd_lds_kernel<EPI_AFFINE_ACT_R>, g, b, 0, stream, p);
+        else hipLaunchKernelGGL(stem3x3_fwd_lds_kernel<EPI_RAW>, g, b, 0, stream, p);
+    } else
+        hipLaunchKernelGGL(stem3x3_fwd_kernel, dim3((unsigned)stem_blocks((int64_t)p.NB * p.H * p.W)), dim3(256), 0, stream, p);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -358,6 +803,28 @@ extern "C" int ryolo_stem3x3_wgrad(const StemWgradParams* pp, hipStream_t stream
     float* part = p.workspace + (size_t)nb * 1024;                 // two-level fold: 64 groups, then one
     hipLaunchKernelGGL(stem_fold_kernel, dim3(64), dim3(1024), 0, stream, p.workspace, nb, part);
     hipLaunchKernelGGL(stem_fold_kernel, dim3(1), dim3(1024), 0, stream, part, 64, p.scratch);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_stem3x3_bwd_plan(int NB, int H, int W, int Cout, size_t* workspace_bytes)
+{
+    if (!stem_ok(NB, H, W, Cout) || Cout != 32 || W % 32) return RY_ERR_UNSUPPORTED;
+    const int nb = stem_lds_blocks((int64_t)NB * H * W, 3);       // 158 VGPRs: three workgroups per CU
+    if (workspace_bytes) *workspace_bytes = (size_t)(nb + 64) * STEM_BWD_SLAB * sizeof(float);
+    return RY_OK;
+}
+
+extern "C" int ryolo_stem3x3_bwd(const StemBwdParams* pp, hipStream_t stream)
+{
+    if (!pp || !pp->img || !pp->dz || !pp->wf || !pp->co || !pp->workspace || !pp->dW) return RY_ERR_ARG;
+    const StemBwdParams& p = *pp;
+    if (!stem_ok(p.NB, p.H, p.W, 32) || p.W % 32 || p.lddz % 8 || (reinterpret_cast<uintptr_t>(p.dz) & 15)) return RY_ERR_UNSUPPORTED;
+    const int nb = stem_lds_blocks((int64_t)p.NB * p.H * p.W, 3);
+    hipLaunchKernelGGL(stem3x3_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, p.workspace);
+    float* part = p.workspace + (size_t)nb * STEM_BWD_SLAB;
+    hipLaunchKernelGGL(stem_fold_wide_kernel, dim3(64), dim3(1024), 0, stream, p.workspace, nb, STEM_BWD_SLAB, part);
+    hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(1), dim3(1024), 0, stream, part, p, (double)p.NB * p.H * p.W);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -164,8 +164,12 @@ class Graph:
             lo = self.rt.gflat.data_ptr()
             hi = lo + self.rt.gflat.numel() * 4
             ptrs = [a for a in args if isinstance(a, int) and lo <= a < hi]
-            ptrs += [a.dW for a in args if isinstance(a, S.WgradParams) and a.dW and lo <= a.dW < hi]
-            ptrs += [a.dW2 for a in args if isinstance(a, S.WgradParams) and a.dW2 and lo <= a.dW2 < hi]
+            for a in args:
+                if isinstance(a, (S.WgradParams, S.StemBwdParams)):
+                    for f in ("dW", "dW2", "dgamma", "dbeta"):
+                        q = getattr(a, f, None)
+                        if q and lo <= q < hi:
+                            ptrs.append(q)
             if ptrs:
                 self.grad_writes.append((len(tape) - 1, [(q - lo) // 4 for q in ptrs]))
 
@@ -473,6 +477,58 @@ class Graph:
             self._call(self.bwd, "ryolo_unpack_wgrad", scratch.data_ptr(), cout, 3, k * k, kp, rt.grad_ptr(conv.weight))
         return y, stats, backward
 
+    def _stem_recompute(self, conv, bn, actc, out):
+        """Training plan of a 3x3 stride-1 first layer without its raw output: [statistics-only conv pass -> bn_finalize ->] conv pass
+        with BatchNorm + activation applied to the bf16-rounded accumulator (bit-identical to storing y and running bn_act_fwd), and
+        ONE fused backward pass (ryolo_stem3x3_bwd).  Returns None when the shape is not eligible (caller falls back)."""
+        rt = self.rt
+        k, s, pad, cout = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.out_channels
+        pk = rt.packed(conv)
+        wsb = S.Z()
+        if (k, s, pad, conv.in_channels, cout, pk["CinP"]) != (3, 1, 1, 3, 32, 32) or self.B * 3 * self.Hin * self.Win >= 2 ** 31:
+            return None
+        if hip.lib().ryolo_stem3x3_bwd_plan(self.B, self.Hin, self.Win, cout, C.byref(wsb)) != 0:
+            return None
+        rows = S.I()
+        hip.call("ryolo_stem3x3_plan", self.B, self.Hin, self.Win, cout, rows, None)
+        z = out if out is not None else self.new(self.B, self.Hin, self.Win, cout)
+        co = self.f32(4, cout)
+
+        def params(epi):
+            p = S.StemParams()
+            p.img, p.NB, p.H, p.W = self.img.data_ptr(), self.B, self.Hin, self.Win
+            p.wf, p.Cout, p.epi = pk["wf"].data_ptr(), cout, epi
+            self._img_structs.append(p)
+            return p
+        if self.batch_stats:
+            p0 = params(S.EPI_STATS)                      # out stays null: statistics only
+            stats = self.f32(rows.value + 64, 2, cout)[:rows.value]
+            p0.stats = stats.data_ptr()
+            self._call(self.fwd, "ryolo_stem3x3_fwd", p0)
+            self._call(self.fwd, "ryolo_bn_finalize", stats.data_ptr(), stats.shape[0], cout, float(z.M), float(bn.eps), float(bn.momentum),
+                       bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), co.data_ptr())
+            rt.bn_counters.append(bn)
+        else:
+            self._call(self.fwd, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                       bn.running_var.data_ptr(), float(bn.eps), cout, co.data_ptr())
+        p1 = params(S.EPI_AFFINE_ACT_R)
+        p1.out, p1.ldC = z.ptr(), z.ld
+        p1.scale, p1.shift, p1.act = co.data_ptr() + 2 * cout * 4, co.data_ptr() + 3 * cout * 4, actc
+        self._call(self.fwd, "ryolo_stem3x3_fwd", p1)
+        self.debug[id(conv)] = (z, z, None)
+
+        def backward():
+            ws = self.f32(wsb.value // 4)
+            q = S.StemBwdParams()
+            q.img, q.NB, q.H, q.W = self.img.data_ptr(), self.B, self.Hin, self.Win
+            q.dz, q.lddz, q.wf, q.co, q.act, q.frozen = z.gptr(), z.ld, pk["wf"].data_ptr(), co.data_ptr(), actc, 1 if self.frozen else 0
+            q.workspace, q.dW = ws.data_ptr(), rt.grad_ptr(conv.weight)
+            q.dgamma, q.dbeta = rt.grad_ptr(bn.weight), rt.grad_ptr(bn.bias)
+            self._call(self.bwd, "ryolo_stem3x3_bwd", q)
+            self._img_structs.append(q)
+        self._pending_bwd.append(backward)
+        return z
+
     # ------------------------------------------------------------------ Conv = conv -> BN -> act (+ residual)
     def conv_bn_act(self, conv, bn, act, x, out=None, residual=None, stem=False):
         """model/utils.py:6-32.  x None => stem on the staged input image.  Returns the activation TRef."""
@@ -495,6 +551,10 @@ class Graph:
             (self.stem_raw(conv, False, fused) if stem else self.conv_raw(conv, x, False, fused))
             self.debug[id(conv)] = (z, z, x)
             return z
+        if stem and residual is None and rt.stem_recompute:
+            z = self._stem_recompute(conv, bn, actc, out)
+            if z is not None:
+                return z
         y, stats, conv_bwd = (self.stem_raw(conv, bstat) if stem else self.conv_raw(conv, x, bstat))
         co = self.f32(4, cout)
         if bstat:

@@ -31,6 +31,9 @@ class Runtime:
         # 0x200: 3x3 stride-1 layers run the halo-patch kernel (csrc/conv3x3.hip)
         self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200)), 0)
         self.fuse_stem_bn = os.environ.get("RYOLO_FUSE_STEM_BN", "1") != "0"      # BN + act backward applied inside the stem wgrad kernel
+        # 3x3 stride-1 first layer (yolov4 / yolov7): the raw conv output is never stored — statistics pass + fused BN/activation
+        # forward, and ONE backward pass over dz that recomputes it from the image (csrc/stem.hip: stem3x3_bwd_kernel)
+        self.stem_recompute = os.environ.get("RYOLO_STEM_RECOMPUTE", "1") != "0"
         self.side_event = None            # set by Graph.run around a gradient-bucket hook: event of the weight-gradient stream
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)

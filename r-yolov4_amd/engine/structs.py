@@ -6,7 +6,7 @@ from .. import hip
 
 P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 MAX_TAPS = 9
-EPI_RAW, EPI_STATS, EPI_AFFINE_ACT, EPI_F32_BIAS, EPI_ACCUM = range(5)
+EPI_RAW, EPI_STATS, EPI_AFFINE_ACT, EPI_F32_BIAS, EPI_ACCUM, EPI_AFFINE_ACT_R = range(6)
 ACT = {"linear": 0, "mish": 1, "leaky": 2, "swish": 3}
 
 
@@ -37,6 +37,11 @@ class StemParams(C.Structure):
 class StemWgradParams(C.Structure):
     _fields_ = [("img", P), ("NB", I), ("H", I), ("W", I), ("dY", P), ("ldY", I), ("Cout", I), ("scratch", P), ("workspace", P),
                 ("y", P), ("ldy", I), ("act", I), ("co", P), ("bco", P)]
+
+
+class StemBwdParams(C.Structure):
+    _fields_ = [("img", P), ("NB", I), ("H", I), ("W", I), ("dz", P), ("lddz", I), ("wf", P), ("co", P), ("act", I), ("frozen", I),
+                ("workspace", P), ("dW", P), ("dgamma", P), ("dbeta", P)]
 
 
 class BnActParams(C.Structure):
@@ -79,6 +84,8 @@ for _name, _sig in {
     "ryolo_stem3x3_plan": [I, I, I, I, _PTR(I), _PTR(Z)],
     "ryolo_stem3x3_fwd": [_PTR(StemParams), P],
     "ryolo_stem3x3_wgrad": [_PTR(StemWgradParams), P],
+    "ryolo_stem3x3_bwd_plan": [I, I, I, I, _PTR(Z)],
+    "ryolo_stem3x3_bwd": [_PTR(StemBwdParams), P],
     "ryolo_bn_finalize": [P, I, I, D, F, F, P, P, P, P, P, P],
     "ryolo_bn_eval_coeffs": [P, P, P, P, F, I, P, P],
     "ryolo_bn_finalize_slice": [P, I, I, I, I, D, F, F, P, P, P, P, P, P],
@@ -114,9 +121,9 @@ def check_layouts():
     global _checked
     if _checked:
         return
-    sizes = (I * 10)()
+    sizes = (I * 11)()
     hip.call("ryolo_struct_sizes", sizes)
-    want = [BnActParams, PoolParams, UpParams, PackEntry, ConvGemmParams, WgradParams, LossParams, TapClass, StemParams, StemWgradParams]
+    want = [BnActParams, PoolParams, UpParams, PackEntry, ConvGemmParams, WgradParams, LossParams, TapClass, StemParams, StemWgradParams, StemBwdParams]
     for k, t in enumerate(want):
         if sizes[k] != C.sizeof(t):
             raise RuntimeError(f"ryolov4_amd: struct layout mismatch for {t.__name__}: C {sizes[k]} vs ctypes {C.sizeof(t)}")

@@ -23,7 +23,10 @@ _SIGNATURES = {
     "ryolo_head_permute": [_P, _P, _I, _I, _I, _I, _P],
     "ryolo_decode": [_I, _P, _P, _I, _I, _I, _I, _F, ctypes.POINTER(_F), _L, _L, _P],
     "ryolo_pp_score": [_P, _I, _L, _I, _F, _P, _P, _P, _P],
-    "ryolo_pp_gather": [_P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _P, _P, _P],
+    "ryolo_pp_gather": [_P, _P, _P, _P, _I, _L, _I, _L, _L, _F, _P, _P, _P, _P],
+    "ryolo_sort_workspace_bytes": [_I, _L, ctypes.POINTER(_Z)],
+    "ryolo_topk_desc": [_P, _I, _L, _I, _P, _P, _P, _P, _Z, _P],
+    "ryolo_argsort_desc": [_P, _L, _P, _P, _Z, _P],
     "ryolo_pp_emit": [_P, _P, _P, _I, _L, _L, _P, _P],
     "ryolo_map_match_workspace_bytes": [_L, _L, ctypes.POINTER(_Z)],
     "ryolo_map_match": [_P, _P, _P, _P, _I, _L, _L, _P, _I, _I, _P, _P, _Z, _P],

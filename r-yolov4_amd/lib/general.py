@@ -66,6 +66,36 @@ def _nms_sorted_batched(rboxes, counts, iou_thres, gt_only, max_keep):
     return keep, num
 
 
+def argsort_desc(scores):
+    """Stable descending argsort of a score vector on the device (csrc/topk.hip: LDS bitonic sort of (score, ~index) composites,
+    global merge steps beyond 16 384): what detectron2's nms_rotated does first; equal scores keep ascending index order."""
+    hip.require_device(scores, "argsort_desc")
+    sc = scores.float().contiguous()
+    n = sc.shape[0]
+    order = torch.empty(n, dtype=torch.int64, device=sc.device)
+    if n:
+        need = hip._Z()
+        hip.call("ryolo_sort_workspace_bytes", 1, n, need)
+        ws = torch.empty(need.value, dtype=torch.uint8, device=sc.device)
+        hip.call("ryolo_argsort_desc", hip.ptr(sc), n, hip.ptr(order), hip.ptr(ws), need.value, hip.stream())
+    return order
+
+
+def topk_desc(key, K):
+    """key [B, M] fp32 -> (skey [B, K], order [B, K] int64): per row the K largest in (key desc, index asc) order, -inf entries never
+    selected (padding: -inf / -1).  Radix select + LDS sort, one workgroup per row (csrc/topk.hip)."""
+    hip.require_device(key, "topk_desc")
+    B, M = key.shape
+    skey = torch.empty((B, K), dtype=torch.float32, device=key.device)
+    order = torch.empty((B, K), dtype=torch.int64, device=key.device)
+    if B and K:
+        need = hip._Z()
+        hip.call("ryolo_sort_workspace_bytes", B, K, need)
+        ws = torch.empty(need.value, dtype=torch.uint8, device=key.device)
+        hip.call("ryolo_topk_desc", hip.ptr(key), B, M, K, hip.ptr(skey), hip.ptr(order), None, hip.ptr(ws), need.value, hip.stream())
+    return skey, order
+
+
 def nms_rotated(boxes, scores, iou_threshold, gt_only=True):
     """Drop-in for detectron2.layers.nms.nms_rotated (call site lib/general.py:177).
     gt_only=True suppresses iff IoU > thr (detectron2's CUDA kernel, what the reference runs on GPU);
@@ -76,7 +106,7 @@ def nms_rotated(boxes, scores, iou_threshold, gt_only=True):
     n = boxes.shape[0]
     if n == 0:
         return torch.empty(0, dtype=torch.int64, device=boxes.device)
-    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    order = argsort_desc(scores)
     sb = boxes.float()[order].contiguous().unsqueeze(0)
     keep, num = _nms_sorted_batched(sb, None, iou_threshold, gt_only, None)
     k = int(num.item())
@@ -129,13 +159,13 @@ def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
     cls = torch.empty((B, M), dtype=torch.float32, device=dev)
     count = torch.empty(B, dtype=torch.int32, device=dev)
     hip.call("ryolo_pp_score", hip.ptr(predictions), B, M, nc, float(conf_thres), hip.ptr(key), hip.ptr(cls), hip.ptr(count), st)
-    # Stable descending sort of the candidate scores (ties: ascending candidate index — the reference's
-    # argsort(descending=True) at lib/general.py:166 leaves tie order undefined; SURVEY §7 fixes it).
-    skey, order = torch.sort(key, dim=1, descending=True, stable=True)
+    # The max_nms best candidates in (score desc, candidate index asc) order — the reference's argsort(descending=True)[:max_nms] at
+    # lib/general.py:166-168 leaves tie order undefined; SURVEY §7 fixes it.  Radix select + LDS sort on the device (csrc/topk.hip).
     K = min(M, MAX_NMS)
+    skey, order = topk_desc(key, K)
     dets = torch.empty((B, K, 7), dtype=torch.float32, device=dev)
     rboxes = torch.empty((B, K, 5), dtype=torch.float32, device=dev)
-    hip.call("ryolo_pp_gather", hip.ptr(predictions), hip.ptr(skey), hip.ptr(order), hip.ptr(cls), B, M, nc, K, MAX_WH,
+    hip.call("ryolo_pp_gather", hip.ptr(predictions), hip.ptr(skey), hip.ptr(order), hip.ptr(cls), B, M, nc, K, K, MAX_WH,
              hip.ptr(dets), hip.ptr(rboxes), hip.ptr(count), st)
     keep, num = _nms_sorted_batched(rboxes, count, iou_thres, gt_only, MAX_DET)
     ks = keep.shape[1]

@@ -120,3 +120,35 @@ def test_post_process_random_vs_oracle_and_empty():
     for a, b in zip(exp, got):
         assert a.shape == b.shape
         np.testing.assert_allclose(b.cpu().numpy(), a.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("B,M,K", [(1, 1, 1), (2, 63, 63), (3, 5000, 5000), (2, 39375, 5000), (2, 387072, 5000), (1, 70000, 16384), (2, 9000, 100)])
+@pytest.mark.parametrize("ninf_frac", [0.0, 0.7, 1.0])
+def test_topk_desc_equals_stable_sort(B, M, K, ninf_frac):
+    """csrc/topk.hip (radix select + LDS bitonic sort) against torch's STABLE descending sort: the K best of every row in (key desc,
+    index asc) order, bit for bit, with heavy ties (keys quantised to 1/64), -0.0 / +0.0, and -inf rows (never selected: -inf / -1
+    padding).  Sizes: the reference cap 5000 (lib/general.py:148) out of 39 375 (C4) and 387 072 (C5) candidates."""
+    from ryolov4_amd.lib import general
+    g = torch.Generator().manual_seed(B * 131 + M + K)
+    key = (torch.randint(-8, 64, (B, M), generator=g).float() / 64.0)
+    key[key == 0] = -0.0
+    key[torch.rand(B, M, generator=g) < 0.01] = 0.0
+    key[torch.rand(B, M, generator=g) < ninf_frac] = float("-inf")
+    key = key.cuda()
+    skey, order = general.topk_desc(key, K)
+    ref_k, ref_o = torch.sort(key, dim=1, descending=True, stable=True)
+    ref_k, ref_o = ref_k[:, :K], ref_o[:, :K]
+    sel = ref_k > float("-inf")
+    assert torch.equal(skey[sel], ref_k[sel]) and torch.equal(order[sel], ref_o[sel])
+    assert bool((skey[~sel] == float("-inf")).all()) and bool((order[~sel] == -1).all())
+
+
+@pytest.mark.parametrize("N", [1, 2, 100, 4097, 10000, 16384, 16385, 50000, 200000])
+def test_argsort_desc_equals_stable_sort(N):
+    """Full descending argsort (nms_rotated's score sort): LDS sort up to 16 384, global bitonic merge steps beyond."""
+    from ryolov4_amd.lib import general
+    g = torch.Generator().manual_seed(N)
+    sc = (torch.randint(0, max(2, N // 3), (N,), generator=g).float() / 7.0).cuda()          # every value ~3 times: ties matter
+    got = general.argsort_desc(sc)
+    ref = torch.sort(sc, descending=True, stable=True)[1]
+    assert torch.equal(got, ref)

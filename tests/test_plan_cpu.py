@@ -32,8 +32,10 @@ def test_plan_builds(ver, mode, nc, training):
     assert [tuple(h["out"].shape) for h in g.heads] == [(2, na, 8, 8, attrs), (2, na, 4, 4, attrs), (2, na, 2, 2, attrs)]
     nconv = sum(1 for x in m.modules() if isinstance(x, torch.nn.Conv2d))
     names = [n for _, _, n in g.fwd]
-    direct_stem = names.count("ryolo_stem3x3_fwd")                 # 3x3 stride-1 stems (v4, v7) bypass im2col + GEMM
-    assert direct_stem == (0 if ver == "yolov5" else 1)
+    # 3x3 stride-1 stems (v4, v7) bypass im2col + GEMM; training plans run the direct kernel twice (statistics only, then with
+    # BatchNorm + activation fused: the raw output is never stored) and have ONE fused backward launch for the layer
+    direct_stem = 0 if ver == "yolov5" else 1
+    assert names.count("ryolo_stem3x3_fwd") == direct_stem * (2 if training else 1)
     # eval plans re-parameterise every RepConv (3x3 + 1x1 -> one 3x3 GEMM); training plans keep both branches
     from ryolov4_amd.model.blocks import C3, CSP, ELAN1, ELAN2, SPPCSPC, RepConv
     nrep = sum(1 for x in m.modules() if isinstance(x, RepConv))
@@ -47,8 +49,8 @@ def test_plan_builds(ver, mode, nc, training):
         assert [n for _, _, n in g.wprep].count("ryolo_repconv_fold") == nrep
     if training:
         bnames = [n for _, _, n in g.bwd]
-        assert bnames.count("ryolo_conv_wgrad") + bnames.count("ryolo_stem3x3_wgrad") == nconv - npair
-        assert bnames.count("ryolo_stem3x3_wgrad") == direct_stem
+        assert bnames.count("ryolo_conv_wgrad") + bnames.count("ryolo_stem3x3_bwd") == nconv - npair
+        assert bnames.count("ryolo_stem3x3_bwd") == direct_stem and bnames.count("ryolo_stem3x3_wgrad") == 0
         assert bnames.count("ryolo_conv_gemm") == nconv - 1 - npair  # every conv but the stem has a data gradient (shared by siblings)
         assert names.count("ryolo_bn_finalize_slice") == 2 * npair
         for p in m.parameters():
