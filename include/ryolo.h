@@ -129,6 +129,9 @@ int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_b
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
 /* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K, 1 the 3x3 stride-1 halo-ring kernel (needs p->zeros) */
 int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
+/* weights of a stride-2 3x3 (pad 1) data gradient in its space-to-depth form (ConvGemmParams.s2d_cin): w fp32 [Cout][Cin][3][3] ->
+ * out bf16 [4 * Cin][4][round_up(Cout, 32)] */
+int ryolo_pack_s2d(const float* w, int Cout, int Cin, bf16_t* out, ryolo_stream_t stream);
 
 /* first layer, 3x3 stride 1 pad 1 on the fp32 NCHW image (Cin = 3, Cout <= 32), without the im2col round trip (csrc/stem.hip);
  * _plan: partial-statistics rows of epilogue 1 and the weight-gradient workspace; _wgrad needs Cout == 32 and W % 16 == 0 and

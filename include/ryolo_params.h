@@ -33,6 +33,10 @@ typedef struct ConvGemmParams {
     int pipe;                                       // bits 0-7 mainloop of the generic kernel: 0 register-staged double buffer, 1 LDS-DMA ring;
                                                     // 0x100 force 32-channel stages; 0x200 3x3 stride-1 layers with >= 512 tiles run the halo-patch kernel (conv3x3.hip), 0x400 also smaller ones
     unsigned a_bytes, w_bytes;                      // byte extents of A / W (informational; reserved for buffer-descriptor addressing)
+    int s2d_cin;                                    // > 0: depth-to-space store of a stride-2 data gradient computed as ONE stride-1 GEMM over the dY
+                                                    // grid with Nout = 4 * s2d_cin columns (output parity ph, pw, then channel) and 2x2 taps (weights from
+                                                    // ryolo_pack_s2d): column n of row (img, a, b) goes to pixel (2a + ph, 2b + pw), channel n % s2d_cin —
+                                                    // every store instruction writes whole 128-byte pixel pairs (oh_mul = ow_mul = 2, bf16 epilogues only)
 } ConvGemmParams;
 
 typedef struct WgradParams {
@@ -133,6 +137,7 @@ typedef struct LossParams {
     void* ws; size_t ws_bytes;
     float* items;             // [5] device: reg, conf, cls, theta, total
     int compute_grad;
+    float fl_gamma, fl_alpha; // FocalLoss (lib/loss.py:10-33) around every BCE term when fl_gamma > 0 (hyp['fl_gamma']); alpha = 0.25 in the reference
 } LossParams;
 
 #endif /* RYOLO_PARAMS_H */

@@ -157,7 +157,7 @@ def build_targets(shapes, targets, anchors, mode):
         gwh = targets[:, 4:6] * torch.tensor([gx, gy], dtype=torch.float32)
         r = gwh[None, :, :] / an[:, None, :2]                                  # [na, nt, 2]
         ok = torch.max(r, 1.0 / r).max(2)[0] < 4.0                              # lib/loss.py:297-298
-        if mode == "kfiou":
+        if mode != "csl":
             d = torch.abs(torch.cos(targets[None, :, 6] - an[:, None, 2]))      # lib/loss.py:458-461
             ok = ok & (d > 0.866)
         a_idx, t_idx = ok.nonzero(as_tuple=True)                               # anchor-major, target-minor order
@@ -175,19 +175,29 @@ def build_targets(shapes, targets, anchors, mode):
         gj = gij[:, 1].clamp(0, gy - 1)
         # gi/gj are views of gij and clamp_ is in place (lib/loss.py:320,324) -> tbox sees the CLAMPED cell
         box = [fxy - torch.stack((gi, gj), 1).float(), gwh[t_f]]               # lib/loss.py:325
-        if mode == "kfiou":
+        if mode != "csl":
             box.append(targets[t_f, 6:7])
         res.append(dict(b=targets[t_f, 0].long(), a=a_f, gj=gj, gi=gi, c=targets[t_f, 1].long(), tidx=t_f,
                         tbox=torch.cat(box, 1), anch=an[a_f]))
     return res
 
 
-def _bce_mean(logits, target):
-    return F.binary_cross_entropy_with_logits(logits, target, reduction="mean")
+def _bce_mean(logits, target, pos_weight=1.0, gamma=0.0, alpha=0.25):
+    """nn.BCEWithLogitsLoss(pos_weight=[pw]) (lib/loss.py:163-165 / :342-343), wrapped in FocalLoss (lib/loss.py:10-33) when
+    hyp['fl_gamma'] > 0 (lib/loss.py:167-171 / :345-348); reduction 'mean' in both cases."""
+    pw = torch.tensor([float(pos_weight)])
+    if not gamma > 0:
+        return F.binary_cross_entropy_with_logits(logits, target, pos_weight=pw, reduction="mean")
+    loss = F.binary_cross_entropy_with_logits(logits, target, pos_weight=pw, reduction="none")
+    prob = torch.sigmoid(logits)
+    p_t = target * prob + (1 - target) * (1 - prob)
+    loss = loss * (target * alpha + (1 - target) * (1 - alpha)) * (1.0 - p_t) ** gamma
+    return loss.mean()
 
 
 def compute_loss(outputs, targets, anchors, nc, mode, hyp):
-    """ComputeCSLLoss.__call__ lib/loss.py:191-268 / ComputeKFIoULoss.__call__ lib/loss.py:368-425.
+    """ComputeCSLLoss.__call__ lib/loss.py:191-268 / ComputeKFIoULoss.__call__ lib/loss.py:368-425 (mode 'sl1iou': the kfiou path with
+    the regression term of sl1iou_loss — this build's extra mode, not reference code).
 
     outputs: list of 3 [B,na,gs,gs,attrs] (may require grad).  Returns (loss[1], dict of 0-d tensors)."""
     reg = torch.zeros(1)
@@ -196,6 +206,7 @@ def compute_loss(outputs, targets, anchors, nc, mode, hyp):
     theta = torch.zeros(1)
     tg = build_targets([(o.shape[2], o.shape[3]) for o in outputs], targets, anchors, mode)
     obj_ch = 4 if mode == "csl" else 5
+    fl = float(hyp.get("fl_gamma", 0.0))
     for i, pi in enumerate(outputs):
         m = tg[i]
         tconf = torch.zeros(pi.shape[:4])
@@ -209,6 +220,12 @@ def compute_loss(outputs, targets, anchors, nc, mode, hyp):
                 reg = reg + (1.0 - iou).mean()
                 score = iou.detach().clamp(0)
                 c0 = 5
+            elif mode == "sl1iou":                                                         # extra mode (no reference code): see sl1iou_loss
+                pa = norm_angle((ps[:, 4:5].sigmoid() - 0.5) * 1.1 + m["anch"][:, 2:])
+                l, iou = sl1iou_loss(torch.cat((pxy, pwh, pa), -1), m["tbox"])
+                reg = reg + l.to(reg.dtype)
+                score = iou.clamp(0).to(pi.dtype)
+                c0 = 6
             else:
                 pa = norm_angle((ps[:, 4:5].sigmoid() - 0.5) * 1.1 + m["anch"][:, 2:])   # lib/loss.py:390
                 l, kfiou = kf_loss(torch.cat((pxy, pwh, pa), -1), m["tbox"])
@@ -223,10 +240,10 @@ def compute_loss(outputs, targets, anchors, nc, mode, hyp):
             if nc > 1:
                 onehot = torch.zeros(n, nc)
                 onehot[torch.arange(n), m["c"]] = 1
-                cls = cls + _bce_mean(ps[:, c0:c0 + nc], onehot)
+                cls = cls + _bce_mean(ps[:, c0:c0 + nc], onehot, hyp.get("cls_pw", 1.0), fl)
             if mode == "csl":
-                theta = theta + _bce_mean(ps[:, 5 + nc:], targets[m["tidx"], 7:187])
-        conf = conf + _bce_mean(pi[..., obj_ch], tconf)
+                theta = theta + _bce_mean(ps[:, 5 + nc:], targets[m["tidx"], 7:187], 1.0, fl)
+        conf = conf + _bce_mean(pi[..., obj_ch], tconf, hyp.get("obj_pw", 1.0), fl)
     reg = hyp["box"] * reg
     conf = hyp["obj"] * conf
     cls = hyp["cls"] * cls
@@ -238,6 +255,26 @@ def compute_loss(outputs, targets, anchors, nc, mode, hyp):
         loss = loss + theta
     items["total_loss"] = loss
     return loss, items
+
+
+def sl1iou_loss(pred, target):
+    """Smooth-L1-IoU regression of the EXTRA mode `sl1iou` (ryolov4_amd.lib.loss.ComputeSL1IoULoss).  NO REFERENCE ORACLE EXISTS:
+    the reference only names the loss (Readme.md:4,12-13, formula images) and ships no code for it; the definition below is this
+    build's reading of R3Det (arXiv 1908.05612, eq. 5):   L_n = (S_n / |S_n|) * |-log(SkewIoU_n)|,   S_n = sum_j smooth_l1(p_nj - t_nj)
+    over (x, y, w, h in grid units, theta in rad), beta = 1; the IoU (detectron2 semantics, oracle/rotated_iou.c) is detached.
+    pred, target [n, 5]; returns (mean loss, iou[n])."""
+    from oracle import pairwise_iou_rotated
+    import numpy as np
+    d = pred.double() - target.double()
+    ad = d.abs()
+    S = torch.where(ad < 1, 0.5 * d * d, ad - 0.5).sum(1)
+    deg = 57.29577951308232
+    bp = torch.cat((pred[:, :4], pred[:, 4:5] * deg), 1).detach().float().numpy()
+    bt = torch.cat((target[:, :4], target[:, 4:5] * deg), 1).detach().float().numpy()
+    iou = torch.from_numpy(np.array([pairwise_iou_rotated(bp[k:k + 1], bt[k:k + 1])[0, 0] for k in range(bp.shape[0])], dtype=np.float64))
+    w = -torch.log(iou.clamp(min=1e-6))
+    loss = torch.where(S > 0, S / S.detach().clamp(min=1e-300) * w, torch.zeros_like(S))
+    return loss.mean(), iou
 
 
 # ---------------------------------------------------------------------------------------------- post_process

@@ -409,6 +409,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             const int64_t pix = out_pixel(m);
             uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
             bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
+            if (p.s2d_cin) {                                       // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
+                const int q = n / p.s2d_cin, ci = n - q * p.s2d_cin;
+                o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
+            }
             if (p.epi == EPI_ACCUM) {
                 const uint4 old = *reinterpret_cast<const uint4*>(o);
                 const unsigned* a = reinterpret_cast<const unsigned*>(&v);
@@ -783,8 +787,40 @@ extern "C" int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* ro
     return RY_OK;
 }
 
+// Stride-2 3x3 (pad 1) data gradient as ONE stride-1 GEMM over the dY grid (space-to-depth on the output): dx[2a + ph][2b + pw][ci] =
+// sum over (da, db) in {0,1}^2 and co of dY[a + da][b + db][co] * W[co][ci][ph + 1 - 2 da][pw + 1 - 2 db] (taps outside the 3x3 kernel are
+// structural zeros: 9 of 16 live).  out [4 * Cin][4 taps][CoutP] bf16, row n = (2 ph + pw) * Cin + ci, tap = 2 da + db.  For narrow layers
+// (Cin <= 32) the four 32-column parity classes of the exact formulation ran the 256x32 tile at 6 % of the MFMA peak and wrote each
+// 128-byte line in two 64-byte halves at different times; this form has a full 128-wide N tile and stores whole pixel pairs.
+__global__ void pack_s2d_kernel(const float* __restrict__ w /*[Cout][Cin][3][3]*/, int Cout, int Cin, int CoutP, bf16_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = 4 * Cin * 4 * CoutP;
+    if (i >= total) return;
+    const int co = i % CoutP, tap = (i / CoutP) & 3, n = i / (4 * CoutP);
+    const int q = n / Cin, ci = n - q * Cin;
+    const int ph = q >> 1, pw = q & 1, da = tap >> 1, db = tap & 1;
+    const int r = ph + 1 - 2 * da, s = pw + 1 - 2 * db;
+    float v = 0.f;
+    if (co < Cout && (unsigned)r < 3u && (unsigned)s < 3u) v = w[((co * Cin + ci) * 3 + r) * 3 + s];
+    out[i] = f2bf(v);
+}
+
+extern "C" int ryolo_pack_s2d(const float* w, int Cout, int Cin, bf16_t* out, hipStream_t stream)
+{
+    if (!w || !out || Cout <= 0 || Cin <= 0) return RY_ERR_ARG;
+    const int CoutP = (Cout + 31) / 32 * 32;
+    const int total = 4 * Cin * 4 * CoutP;
+    hipLaunchKernelGGL(pack_s2d_kernel, dim3((unsigned)ry_cdiv(total, 256)), dim3(256), 0, stream, w, Cout, Cin, CoutP, out);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
 static int gemm_check(const ConvGemmParams& p)
 {
+    if (p.s2d_cin && (p.s2d_cin % 8 || p.Nout != 4 * p.s2d_cin || p.oh_mul != 2 || p.ow_mul != 2 || p.nclasses != 1 ||
+                      (p.epi != EPI_RAW && p.epi != EPI_ACCUM)))
+        return RY_ERR_ARG;
     if (!p.A || !p.W || !p.out || p.Cin <= 0 || p.Cin % BK || p.ldA % 8 || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4)
         return RY_ERR_ARG;
     return RY_OK;

@@ -20,6 +20,7 @@
 // Compiled with -ffp-contract=off so the float comparisons of target assignment match torch-CPU bit for bit.
 #include "common.h"
 #include "params.h"
+#include "rotated_iou.h"
 
 #define PI_F 3.14159265358979323846f
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ Cand cand_test(const LossParams& p, int i, int cnd, i
     const float rw = c.gw / aw, rh = c.gh / ah;
     const float mw = fmaxf(rw, 1.0f / rw), mh = fmaxf(rh, 1.0f / rh);
     bool ok = fmaxf(mw, mh) < 4.0f;                                                    // lib/loss.py:297-298 / :454-455
-    if (p.mode == 1) ok = ok && (fabsf(cosf(tg[6] - p.anchors[i][c.a][2])) > 0.866f);     // lib/loss.py:458-461
+    if (p.mode != 0) ok = ok && (fabsf(cosf(tg[6] - p.anchors[i][c.a][2])) > 0.866f);     // lib/loss.py:458-461
     if (ok && c.o > 0) {
         const float ix = fg - c.gx, iy = fg - c.gy;                                    // gxi = gain - gxy
         if (c.o == 1) ok = (c.gx - floorf(c.gx) < 0.5f) && (c.gx > 1.0f);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(1024) void loss_targets_kernel(const LossParams p, 
             r[7] = 0;
             float* f = s.frec + (int64_t)e * 8;
             f[0] = gx - (float)gi; f[1] = gy - (float)gj; f[2] = gw; f[3] = gh;              // tbox (lib/loss.py:325 / :488)
-            f[4] = p.mode == 1 ? tg[6] : 0.f;
+            f[4] = p.mode != 0 ? tg[6] : 0.f;
             f[5] = 0.f; f[6] = 0.f; f[7] = 0.f;
         }
         __syncthreads();
@@ -242,6 +243,26 @@ __device__ __forceinline__ float bce_grad(float x, float t, float pw)
 {
     const float w = 1.f + (pw - 1.f) * t;
     return (1.f - t) - w * (1.f - sigm(x));
+}
+// FocalLoss wrapper of lib/loss.py:10-33 (active when hyp['fl_gamma'] > 0, lib/loss.py:167-171 / :345-348; alpha = 0.25 is the
+// constructor default the reference uses): element = BCE * (t a + (1 - t)(1 - a)) * (1 - p_t)^gamma, p_t = t p + (1 - t)(1 - p).
+// Targets are soft (objectness = IoU score, CSL labels), so the general-t formulas are kept.
+__device__ __forceinline__ float fl_val(float x, float t, float pw, float gamma, float alpha)
+{
+    const float l = bce_val(x, t, pw);
+    if (!(gamma > 0.f)) return l;
+    const float pr = sigm(x), q = 1.f - (t * pr + (1.f - t) * (1.f - pr));
+    return l * (t * alpha + (1.f - t) * (1.f - alpha)) * powf(q, gamma);
+}
+__device__ __forceinline__ float fl_grad(float x, float t, float pw, float gamma, float alpha)
+{
+    const float dl = bce_grad(x, t, pw);
+    if (!(gamma > 0.f)) return dl;
+    const float pr = sigm(x), q = 1.f - (t * pr + (1.f - t) * (1.f - pr));
+    const float af = t * alpha + (1.f - t) * (1.f - alpha);
+    const float m = powf(q, gamma);
+    const float dm = q > 0.f ? -gamma * powf(q, gamma - 1.f) * (2.f * t - 1.f) * pr * (1.f - pr) : 0.f;
+    return af * (dl * m + bce_val(x, t, pw) * dm);
 }
 
 // CIoU (lib/loss.py:36-78) with alpha constant; inputs 4 duals (x,y,w,h), target floats
@@ -337,6 +358,38 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, Sca
                 g[1] = k * c.d[1] * 2.f * sy * (1.f - sy);
                 g[2] = k * c.d[2] * 8.f * sw * sw * (1.f - sw) * aw;
                 g[3] = k * c.d[3] * 8.f * sh * sh * (1.f - sh) * ah;
+            } else if (p.mode == 2) {
+                // smooth-L1-IoU regression (EXTRA mode: the reference names it, Readme.md:4,12-13, but ships no code for it; the
+                // definition is this build's): per match  (L_sl1 / |L_sl1|) * |-log(SkewIoU)|  (R3Det, arXiv 1908.05612
+                // eq. 5): the smooth-L1 of (x, y, w, h, theta) gives the DIRECTION, the exact rotated IoU of the decoded box against
+                // its target (detached) the magnitude; the objectness target is that IoU.
+                const float sa = sigm(ps[4]);
+                float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];
+                const float hpi = (float)(3.14159265358979323846 / 2);
+                if (pa >= hpi) pa = pa - PI_F;
+                if (pa < -hpi) pa = pa + PI_F;
+                const float pv[5] = {sx * 2.f - 0.5f, sy * 2.f - 0.5f, (sw * 2.f) * (sw * 2.f) * aw, (sh * 2.f) * (sh * 2.f) * ah, pa};
+                float S = 0.f, dS[5];
+                for (int j = 0; j < 5; j++) {
+                    const float d = pv[j] - f[j], ad = fabsf(d);
+                    S += ad < 1.f ? 0.5f * d * d : ad - 0.5f;                    // smooth L1, beta = 1
+                    dS[j] = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+                }
+                const float bp[5] = {pv[0], pv[1], pv[2], pv[3], pv[4] * 57.29577951308232f};
+                const float bt[5] = {f[0], f[1], f[2], f[3], f[4] * 57.29577951308232f};
+                BoxPrep A, Bx;
+                box_prep(bp, A);
+                box_prep(bt, Bx);
+                const float iou = rotated_iou_pair(A, Bx);
+                const float w = -logf(fmaxf(iou, 1e-6f));
+                reg_a = S > 0.f ? w : 0.f;
+                score = fmaxf(iou, 0.f);
+                const float k = S > 0.f ? p.box * inv_n * w / S : 0.f;
+                g[0] = k * dS[0] * 2.f * sx * (1.f - sx);
+                g[1] = k * dS[1] * 2.f * sy * (1.f - sy);
+                g[2] = k * dS[2] * 8.f * sw * sw * (1.f - sw) * aw;
+                g[3] = k * dS[3] * 8.f * sh * sh * (1.f - sh) * ah;
+                g[4] = k * dS[4] * 1.1f * sa * (1.f - sa);
             } else {
                 const float sa = sigm(ps[4]);
                 float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];          // lib/loss.py:390
@@ -373,14 +426,14 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, Sca
             const int tc = r[4];
             for (int k = lane; k < p.nc; k += 64) {
                 const float x = ps[c0 + k], t = (k == tc) ? 1.f : 0.f;
-                clsl += bce_val(x, t, p.cls_pw);
+                clsl += fl_val(x, t, p.cls_pw, p.fl_gamma, p.fl_alpha);
             }
         }
         if (p.mode == 0) {                                                       // CSL theta BCE, lib/loss.py:231
             const float* tg = p.targets + (int64_t)r[5] * p.tcols + 7;
             for (int k = lane; k < 180; k += 64) {
                 const float x = ps[5 + p.nc + k], t = tg[k];
-                thl += bce_val(x, t, 1.0f);
+                thl += fl_val(x, t, 1.0f, p.fl_gamma, p.fl_alpha);
             }
         }
     }
@@ -438,20 +491,20 @@ __global__ __launch_bounds__(256) void loss_match_grad_kernel(const LossParams p
         if (p.nc > 1) {
             const int tc = r[4];
             if (p.nc <= 64) {
-                if (lane < p.nc) gcls += kc * bce_grad(xc, lane == tc ? 1.f : 0.f, p.cls_pw);
+                if (lane < p.nc) gcls += kc * fl_grad(xc, lane == tc ? 1.f : 0.f, p.cls_pw, p.fl_gamma, p.fl_alpha);
             } else {
                 for (int k = lane; k < p.nc; k += 64)                                  // wide class heads: accumulate in memory, same order
-                    gp[c0 + k] += kc * bce_grad(ps[c0 + k], k == tc ? 1.f : 0.f, p.cls_pw);
+                    gp[c0 + k] += kc * fl_grad(ps[c0 + k], k == tc ? 1.f : 0.f, p.cls_pw, p.fl_gamma, p.fl_alpha);
             }
         }
         if (p.mode == 0) {
             const float* tg = p.targets + (int64_t)r[5] * p.tcols + 7;
-            for (int q = 0; q < 3; q++) { const int k = lane + 64 * q; if (k < 180) gth[q] += kt * bce_grad(xt[q], tg[k], 1.0f); }
+            for (int q = 0; q < 3; q++) { const int k = lane + 64 * q; if (k < 180) gth[q] += kt * fl_grad(xt[q], tg[k], 1.0f, p.fl_gamma, p.fl_alpha); }
         }
     }
     if (lane == 0) {
         for (int k = 0; k < 4; k++) gp[k] = gbox[k];
-        if (p.mode == 1) gp[4] = gbox[4];
+        if (p.mode != 0) gp[4] = gbox[4];
     }
     if (p.nc > 1 && p.nc <= 64 && lane < p.nc) gp[c0 + lane] = gcls;
     if (p.mode == 0)
@@ -477,8 +530,8 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
     for (int i = blockIdx.x * 256 + threadIdx.x; i < s.cells; i += gridDim.x * 256) {
         const float x = p.head[scale][(int64_t)i * attrs + och];
         const float t = s.tconf[i];
-        acc += bce_val(x, t, p.obj_pw);
-        if (p.compute_grad) p.grad[scale][(int64_t)i * attrs + och] = kg * bce_grad(x, t, p.obj_pw);
+        acc += fl_val(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
+        if (p.compute_grad) p.grad[scale][(int64_t)i * attrs + och] = kg * fl_grad(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

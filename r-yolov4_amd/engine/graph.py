@@ -182,7 +182,9 @@ class Graph:
             fl = 0
             for c in range(p.nclasses):
                 fl += 2 * p.NB * p.OH * p.OW * p.Nout * p.cls[c].ntaps * p.Cin
-            outb = p.NB * p.OHf * p.OWf * p.Nout * (4 if p.epi == S.EPI_F32_BIAS else 2) * (2 if p.epi == S.EPI_ACCUM else 1)
+            if p.s2d_cin:                                  # space-to-depth dgrad: 9 of the 16 (parity, tap) blocks are live — count the useful work
+                fl = 2 * p.NB * p.OH * p.OW * p.s2d_cin * 9 * p.Cin
+            outb = p.NB * p.OHf * p.OWf * (p.s2d_cin or p.Nout) * (4 if p.epi == S.EPI_F32_BIAS else 2) * (2 if p.epi == S.EPI_ACCUM else 1)
             by = p.NB * p.IH * p.IW * p.Cin * 2 + p.Nout * p.wtaps * p.Cin * 2 + outb
             kern = S.I()
             hip.call("ryolo_conv_gemm_plan", p, S.I(), kern)
@@ -299,7 +301,7 @@ class Graph:
 
     # ------------------------------------------------------------------ convolution
     def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,
-              coeffs=None, act=0, bias=None):
+              coeffs=None, act=0, bias=None, s2d=0):
         """Emit one ryolo_conv_gemm launch.  For epi == EPI_STATS the partial-statistics buffer is sized by the library's plan
         (one [2][Nout] row per M tile of the kernel it will run) and returned."""
         p = S.ConvGemmParams()
@@ -322,6 +324,7 @@ class Graph:
         p.zeros = self.rt.zeros.data_ptr()
         p.a_bytes, p.w_bytes = A.span_bytes, W.numel() * 2
         p.pipe = self.rt.gemm_pipe
+        p.s2d_cin = s2d
         stats = None
         if epi == S.EPI_STATS:
             rows = S.I()
@@ -347,6 +350,12 @@ class Graph:
         if s == 1:
             taps = [(pad - r, pad - c, r * k + c) for r in range(k) for c in range(k)]
             self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld)
+        elif (self.rt.s2d_dgrad and k == 3 and pad == 1 and cin <= 32 and cin % 8 == 0 and x.H % 2 == 0 and x.W % 2 == 0
+              and dy_cin % 32 == 0 and dy_cin == conv.out_channels):
+            # narrow stride-2 layer: ONE stride-1 GEMM over the dY grid, N = 4 parities x cin, 2x2 taps, depth-to-space store
+            taps = [(da, db, 2 * da + db) for da in range(2) for db in range(2)]
+            self._gemm(self.bwd, dy, dy_ptr, self.rt.packed_s2d(conv), 4 * cin, 4, dy_cin, x.H // 2, x.W // 2, 1, [(taps, 0, 0)], epi,
+                       x.gptr(), x.ld, full=(2, 2, x.H, x.W), s2d=cin)
         else:
             assert s == 2 and x.H % 2 == 0 and x.W % 2 == 0
             classes = []

@@ -34,6 +34,9 @@ class Runtime:
         # 3x3 stride-1 first layer (yolov4 / yolov7): the raw conv output is never stored — statistics pass + fused BN/activation
         # forward, and ONE backward pass over dz that recomputes it from the image (csrc/stem.hip: stem3x3_bwd_kernel)
         self.stem_recompute = os.environ.get("RYOLO_STEM_RECOMPUTE", "1") != "0"
+        # narrow stride-2 data gradients (<= 32 input channels: the second conv of yolov4 / yolov7) as one space-to-depth GEMM
+        self.s2d_dgrad = os.environ.get("RYOLO_S2D_DGRAD", "1") != "0"
+        self._s2d = {}                    # id(conv) -> (conv, bf16 image [4 Cin][4][CoutP]) refreshed with the other packed weights
         self.side_event = None            # set by Graph.run around a gradient-bucket hook: event of the weight-gradient stream
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
@@ -163,6 +166,16 @@ class Runtime:
             self._pack_table = (host.to(self.device), len(ents), start)
         tab, n, total = self._pack_table
         hip.call("ryolo_pack_weights", tab.data_ptr(), n, total, hip.stream())
+        for conv, img in self._s2d.values():
+            hip.call("ryolo_pack_s2d", conv.weight.data_ptr(), conv.out_channels, conv.in_channels, img.data_ptr(), hip.stream())
+
+    def packed_s2d(self, conv):
+        ent = self._s2d.get(id(conv))
+        if ent is None:
+            coutp = _round_up(conv.out_channels, 32)
+            ent = (conv, torch.zeros((4 * conv.in_channels, 4, coutp), dtype=torch.bfloat16, device=self.device))
+            self._s2d[id(conv)] = ent
+        return ent[1]
 
     # ------------------------------------------------------------------ plans
     def graph(self, B, H, W, training, frozen=False):

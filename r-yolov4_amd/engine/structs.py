@@ -19,7 +19,7 @@ class ConvGemmParams(C.Structure):
     _fields_ = [("A", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldA", I),
                 ("W", P), ("Nout", I), ("wtaps", I), ("OH", I), ("OW", I), ("sh", I), ("sw", I),
                 ("oh_mul", I), ("ow_mul", I), ("OHf", I), ("OWf", I), ("nclasses", I), ("cls", TapClass * 4),
-                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint)]
+                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint), ("s2d_cin", I)]
 
 
 class WgradParams(C.Structure):
@@ -70,7 +70,7 @@ class LossParams(C.Structure):
     _fields_ = [("mode", I), ("nc", I), ("na", I), ("batch", I), ("nt", I), ("tcols", I), ("targets", P),
                 ("head", P * 3), ("grad", P * 3), ("gs", I * 3), ("anchors", (F * 3 * 18) * 3),
                 ("box", F), ("obj", F), ("cls", F), ("theta_gain", F), ("obj_pw", F), ("cls_pw", F),
-                ("ws", P), ("ws_bytes", Z), ("items", P), ("compute_grad", I)]
+                ("ws", P), ("ws_bytes", Z), ("items", P), ("compute_grad", I), ("fl_gamma", F), ("fl_alpha", F)]
 
 
 _PTR = C.POINTER
@@ -103,6 +103,7 @@ for _name, _sig in {
     "ryolo_chan_add": [P, I, P, L, I, P, I, P],
     "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],
+    "ryolo_pack_s2d": [P, I, I, P, P],
     "ryolo_unpack_wgrad": [P, I, I, I, I, P, P],
     "ryolo_repconv_fold": [P, P, P, P, I, I, P, P, P],
     "ryolo_sgd_nesterov": [P, P, P, L, F, F, F, I, P],

@@ -3,8 +3,8 @@ loss kernels (csrc/loss.hip).  Same constructor `(model, hyp)`, same `.loss_item
 same keys, python floats), same `__call__(outputs, target) -> (loss[1], loss_items)`; works under torch.no_grad() and
 with zero targets.  One device->host read per call (the reference does 4-5); pass `sync_items=False` to skip even that
 (loss_items then holds 0-d device tensors) — the training benchmark uses this.
-FocalLoss (lib/loss.py:10-33) is inactive in the reference's configuration (fl_gamma: 0.0, data/hyp.yaml:12); a positive
-gamma raises NotImplementedError here instead of silently computing something else.
+FocalLoss (lib/loss.py:10-33; inactive in the reference's configuration, fl_gamma: 0.0, data/hyp.yaml:12) wraps every BCE term
+inside the same kernels when hyp['fl_gamma'] > 0.
 """
 import torch
 
@@ -44,8 +44,7 @@ class _ComputeLossBase:
     KEYS = ()
 
     def __init__(self, model, hyp):
-        if hyp.get("fl_gamma", 0.0) > 0:
-            raise NotImplementedError("FocalLoss (fl_gamma > 0) is not implemented on the HIP path; the reference runs fl_gamma = 0.0")
+        self.fl_gamma = float(hyp.get("fl_gamma", 0.0))        # > 0: FocalLoss around every BCE term (lib/loss.py:167-171, :345-348)
         self.hyp = {k: float(hyp[k]) for k in ("box", "obj", "cls", "obj_pw", "cls_pw")}
         self.lambda_theta = 0.5                     # lib/loss.py:160
         self.anchors_list = model.anchors
@@ -74,12 +73,13 @@ class _ComputeLossBase:
         p.box, p.obj, p.cls = self.hyp["box"], self.hyp["obj"], self.hyp["cls"]
         p.theta_gain, p.obj_pw, p.cls_pw = self.lambda_theta, self.hyp["obj_pw"], self.hyp["cls_pw"]
         p.compute_grad = 1 if compute_grad else 0
+        p.fl_gamma, p.fl_alpha = self.fl_gamma, 0.25             # FocalLoss(loss_fcn, gamma) keeps its default alpha (lib/loss.py:11)
         return p
 
     def _run(self, outputs, targets, compute_grad):
         S.check_layouts()
         dev = outputs[0].device
-        attrs = self.nc + (185 if self.MODE == 0 else 6)
+        attrs = self.nc + (185 if self.MODE == 0 else 6)              # (MODE 2 shares the kfiou head layout)
         outs = []
         for o in outputs:
             hip.require_device(o, "loss")
@@ -142,3 +142,13 @@ class ComputeCSLLoss(_ComputeLossBase):
 class ComputeKFIoULoss(_ComputeLossBase):
     MODE = 1
     KEYS = ("reg_loss", "conf_loss", "cls_loss", "total_loss")                    # lib/loss.py:361-366
+
+
+class ComputeSL1IoULoss(_ComputeLossBase):
+    """EXTRA mode, not in the reference's code: the smooth-L1-IoU box regression its Readme names (Readme.md:4,12-13: "combining
+    smooth-L1-IoU loss function proposed by R3Det", formula images only; BASELINE config C2).  Same constructor / call / loss_items
+    contract as ComputeKFIoULoss and the SAME network (Yolo(mode='kfiou'): 18 rotated anchors, attrs = nc + 6); only the regression
+    term differs: per match (L_sl1 / |L_sl1|) * |-log SkewIoU| with the exact rotated IoU of csrc/rotated_iou.h (definition:
+    DESIGN.md §4.3; oracle: oracle/ref_ops.sl1iou_loss, fp64, written for this build — no reference oracle exists)."""
+    MODE = 2
+    KEYS = ("reg_loss", "conf_loss", "cls_loss", "total_loss")

@@ -97,3 +97,34 @@ def test_g7_post_process(golden_dir):
             exp = g[f"c{case}_out{b}"]
             assert o.shape == exp.shape
             np.testing.assert_allclose(o.numpy(), exp, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode,nc", [("csl", 2), ("kfiou", 2), ("kfiou", 16), ("csl", 16)])
+def test_g10_focal_loss(golden_dir, mode, nc):
+    """Oracle with FocalLoss active + non-unit pos_weights against the fixture the imported reference produced (make_golden_focal.py)."""
+    g = _load(golden_dir, "g10_focal.npz")
+    hyp = {str(k): float(v) for k, v in zip(g["hyp_keys"], g["hyp_vals"])}
+    tag = f"{mode}_nc{nc}"
+    tg = torch.from_numpy(g[f"{tag}_targets"])
+    outs = [torch.from_numpy(g[f"{tag}_out{i}"].astype(np.float32)).requires_grad_() for i in range(3)]
+    loss, items = ref_ops.compute_loss(outs, tg, ref_ops.make_anchors(CFG, mode), nc, mode, hyp)
+    loss.backward()
+    for nm, ref in zip([str(s) for s in g[f"{tag}_item_names"]], g[f"{tag}_items"]):
+        assert abs(float(items[nm]) - ref) < 2e-5 * max(1.0, abs(ref)), (tag, nm)
+    for i in range(3):
+        np.testing.assert_allclose(outs[i].grad.numpy(), g[f"{tag}_grad{i}"], rtol=1e-4, atol=1e-7)
+
+
+def test_sl1iou_extra_mode_oracle_is_self_consistent():
+    """The extra mode's fp64 oracle (no reference code exists for it): value = mean |-log IoU|, identical boxes cost nothing, and the
+    autograd gradient has the direction of the smooth-L1 gradient scaled by |-log IoU| / S."""
+    p = torch.tensor([[3.0, 4.0, 6.0, 2.0, 0.3], [5.0, 5.0, 4.0, 4.0, -0.2]], dtype=torch.float64, requires_grad=True)
+    t = torch.tensor([[3.5, 4.2, 5.0, 2.5, 0.1], [5.0, 5.0, 4.0, 4.0, -0.2]], dtype=torch.float64)
+    loss, iou = ref_ops.sl1iou_loss(p, t)
+    assert abs(float(iou[1]) - 1.0) < 1e-6 and 0.3 < float(iou[0]) < 0.9
+    assert abs(float(loss) - 0.5 * (-np.log(float(iou[0])))) < 1e-9
+    loss.backward()
+    d = (p.detach() - t)[0]
+    S = float((0.5 * d * d).sum())
+    assert torch.allclose(p.grad[0], d * (-np.log(float(iou[0]))) / S / 2, rtol=1e-9)
+    assert float(p.grad[1].abs().sum()) == 0.0
