@@ -59,7 +59,43 @@ def test_full_size_training_steps_stay_finite():
     assert bool(torch.isfinite(rt.flat).all())
 
 
-@pytest.mark.parametrize("ver,mode,size,nc", [("yolov7", "kfiou", 800, 16), ("yolov7", "csl", 800, 16), ("yolov4", "csl", 608, 2), ("yolov5", "kfiou", 800, 16)])
+def test_full_size_c2_yolov4_608_smooth_l1_iou_steps():
+    """BASELINE config C2 at full size: UCAS-AOD yolov4 (nc = 2) 608x608, batch 64, with the smooth-L1-IoU regression of the EXTRA mode
+    (ComputeSL1IoULoss on the kfiou network; the reference names the loss but ships no code, so there is no oracle at any size — the
+    kernel itself is checked against this build's fp64 definition in test_gpu_model.py).  Five SGD steps on one fixed batch: finite
+    gradients, finite and falling loss, and the kfiou loss on the same network agrees on everything but the regression term."""
+    import bench
+    from ryolov4_amd.lib.loss import ComputeKFIoULoss, ComputeSL1IoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import synth_batch
+    torch.manual_seed(42)
+    m = Yolo(2, CFG, "kfiou", "yolov4")
+    m.apply(bench.weights_init_normal)
+    m.to(DEV).train()
+    rt = m.runtime()
+    crit, crit_kf = ComputeSL1IoULoss(m, HYP), ComputeKFIoULoss(m, HYP)
+    imgs, tg = synth_batch(64, 608, 2, False, seed=42)
+    imgs, tg = imgs.to(DEV), tg.to(DEV)
+    losses = []
+    for step in range(5):
+        outs = m(imgs, training=True)
+        if step == 0:
+            with torch.no_grad():
+                _, it_kf = crit_kf([o.detach() for o in outs], tg)
+                it_kf = dict(it_kf)
+        loss, items = crit(outs, tg)
+        if step == 0:
+            assert abs(items["cls_loss"] - it_kf["cls_loss"]) < 1e-6 * max(1.0, abs(it_kf["cls_loss"]))
+            assert items["reg_loss"] > 0 and items["reg_loss"] != it_kf["reg_loss"]
+        loss.backward()
+        assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+        rt.sgd_step(0.01)
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("ver,mode,size,nc", [("yolov7", "kfiou", 800, 16), ("yolov7", "csl", 800, 16), ("yolov4", "csl", 608, 2), ("yolov4", "kfiou", 608, 2),
+                                              ("yolov5", "kfiou", 800, 16)])
 def test_full_size_training_step_is_bitwise_deterministic(ver, mode, size, nc):
     """Two independent runs of the bench configuration's first training step (same seed, fresh model, run 2 on dirty memory) produce
     bit-identical head maps, loss and gradients.  Every kernel of the step is deterministic by construction (fixed-order partial
