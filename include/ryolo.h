@@ -201,6 +201,19 @@ int ryolo_unpack_wgrad(const float* scratch, int Cout, int Cin, int taps, int Ci
 /* torch.optim.SGD(momentum, nesterov=True) of train.py:156 over flat buffers: buf = mu*buf + g; p -= lr*(g + mu*buf) */
 int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, float mu, float gscale, int zero_grad,
                        ryolo_stream_t stream);   /* g is scaled by gscale on read; zero_grad=1 clears it (optimizer.zero_grad fused) */
+/* ---- image-side augmentations of the loader on uint8 HWC (BGR) images in HBM (csrc/augment.hip; datasets/base_dataset.py:224-330,
+ * lib/augmentations.py:8-74).  paste: `rects` = device array of nrect records {int64 src_off; int src_w, sx, sy, dx, dy, w, h, canvas}
+ * (ryolo_paste_rect_bytes = sizeof), canvases [ncanvas, CH, CW, 3] filled with `fill` first, rectangles applied in order (later wins).
+ * warp: dst[b] = cv2.warpPerspective(src[b], M[b], (DW, DH), borderValue = border) with Minv[b] = inverse(M[b]) as 9 doubles.
+ * hsv: BGR->HSV, lut [3][256] (hue, sat, val), HSV->BGR, in place.  mixup: out = uint8(a*r + b*(1-r)). */
+int ryolo_paste_rects(const uint8_t* pool, const void* rects_dev, int nrect, uint8_t* canvas, int ncanvas, int CH, int CW, int fill,
+                      ryolo_stream_t stream);
+int ryolo_paste_rect_bytes(int* bytes);
+int ryolo_warp_perspective_u8(const uint8_t* src, int batch, int SH, int SW, const double* Minv, uint8_t* dst, int DH, int DW, int border,
+                              ryolo_stream_t stream);
+int ryolo_hsv_gain_u8(uint8_t* img, int64_t npix, const uint8_t* lut, ryolo_stream_t stream);
+int ryolo_mixup_u8(const uint8_t* a, const uint8_t* b, double r, int64_t n, uint8_t* out, ryolo_stream_t stream);
+
 int ryolo_struct_sizes(int* sizes /* [11] */);
 
 /* ------------------------------------------------------------------------------------------------------------

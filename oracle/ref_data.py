@@ -146,3 +146,99 @@ def rescale_boxes(boxes, current_dim, original_shape):
     boxes[:, 2] = (x2 - x1)
     boxes[:, 3] = (y2 - y1)
     return boxes
+
+
+# ---------------------------------------------------------------------------------------------- augmentations
+def mosaic4_numpy(images, s, yc, xc):
+    """datasets/base_dataset.py:224-268, image part: 4 uint8 HWC images -> 2s x 2s canvas (114-filled) + per image (pad, boarder).
+    Pinned: tests/golden/make_golden_aug.py asserts equality with the reference's load_mosaic."""
+    img4 = np.full((s * 2, s * 2, 3), 114, dtype=np.uint8)
+    meta = []
+    for i, img in enumerate(images):
+        h, w = img.shape[:2]
+        if i == 0:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+            x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
+        elif i == 1:
+            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s * 2), yc
+            x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
+        elif i == 2:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s * 2, yc + h)
+            x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
+        else:
+            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
+            x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
+        img4[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
+        meta.append(((y1a - y1b, x1a - x1b), (x1b, x2b, y1b, y2b)))
+    return img4, meta
+
+
+def mixup_numpy(img, img2, r):
+    """lib/augmentations.py:24-28 (image part)."""
+    return (img * r + img2 * (1 - r)).astype(np.uint8)
+
+
+def warp_perspective_numpy(src, M, dsize, border=114):
+    """cv2.warpPerspective(src, M, dsize, borderValue = (114,)*3) restated from OpenCV's implementation (INTER_LINEAR: 5 fractional
+    coordinate bits, 15-bit weight table whose rounding error goes to the largest / smallest weight, round-to-nearest result).
+    PARITY UNPINNED: OpenCV is absent here and the reference does not pin its version."""
+    DW, DH = dsize
+    SH, SW = src.shape[:2]
+    m = np.linalg.inv(np.asarray(M, dtype=np.float64)).reshape(9)
+    xs, ys = np.meshgrid(np.arange(DW, dtype=np.float64), np.arange(DH, dtype=np.float64))
+    W = m[6] * xs + m[7] * ys + m[8]
+    W = np.where(W != 0, 32.0 / np.where(W != 0, W, 1.0), 0.0)
+    X = np.rint(np.clip((m[0] * xs + m[1] * ys + m[2]) * W, -2**31, 2**31 - 1)).astype(np.int64)
+    Y = np.rint(np.clip((m[3] * xs + m[4] * ys + m[5]) * W, -2**31, 2**31 - 1)).astype(np.int64)
+    sx, sy, ax, ay = X >> 5, Y >> 5, X & 31, Y & 31
+    fx1, fy1 = (ax.astype(np.float32) * np.float32(1 / 32)), (ay.astype(np.float32) * np.float32(1 / 32))
+    wf = np.stack(((1 - fy1) * (1 - fx1), (1 - fy1) * fx1, fy1 * (1 - fx1), fy1 * fx1), -1).astype(np.float32)
+    w = np.rint(wf * np.float32(32768)).astype(np.int64)
+    diff = w.sum(-1) - 32768
+    imax, imin = w.argmax(-1), w.argmin(-1)          # first maximum / first minimum, as the scan in initInterTab2D finds them
+    ii, jj = np.indices(diff.shape)
+    neg, pos = diff < 0, diff > 0
+    w[ii[neg], jj[neg], imax[neg]] -= diff[neg]
+    w[ii[pos], jj[pos], imin[pos]] -= diff[pos]
+    out = np.zeros((DH, DW, 3), dtype=np.int64)
+    for k in range(4):
+        px, py = sx + (k & 1), sy + (k >> 1)
+        ok = (px >= 0) & (px < SW) & (py >= 0) & (py < SH)
+        v = np.where(ok[..., None], src[np.clip(py, 0, SH - 1), np.clip(px, 0, SW - 1)].astype(np.int64), border)
+        out += v * w[..., k:k + 1]
+    return ((out + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def hsv_gain_numpy(img, r):
+    """lib/augmentations.py:8-21 with cv2.cvtColor restated from OpenCV (8-bit BGR2HSV integer path with 12-bit division tables, HSV2BGR
+    through the float converter).  PARITY UNPINNED (OpenCV absent, version un-pinned)."""
+    x = np.arange(0, 256, dtype=np.float64)
+    lut_h = ((x * r[0]) % 180).astype(np.uint8)
+    lut_s = np.clip(x * r[1], 0, 255).astype(np.uint8)
+    lut_v = np.clip(x * r[2], 0, 255).astype(np.uint8)
+    b, g, rr = [img[..., k].astype(np.int64) for k in range(3)]
+    v = np.maximum(b, np.maximum(g, rr))
+    vmin = np.minimum(b, np.minimum(g, rr))
+    diff = v - vmin
+    vr = np.where(v == rr, -1, 0)
+    vg = np.where(v == g, -1, 0)
+    sdiv = np.where(v > 0, np.rint((255 << 12) / np.maximum(v, 1).astype(np.float64)), 0).astype(np.int64)
+    hdiv = np.where(diff > 0, np.rint((180 << 12) / (6.0 * np.maximum(diff, 1))), 0).astype(np.int64)
+    s = (diff * sdiv + (1 << 11)) >> 12
+    h = (vr & (g - b)) + (~vr & ((vg & (b - rr + 2 * diff)) + ((~vg) & (rr - g + 4 * diff))))
+    h = (h * hdiv + (1 << 11)) >> 12
+    h = h + np.where(h < 0, 180, 0)
+    H, S, V = lut_h[h & 255].astype(np.float32), lut_s[s].astype(np.float32), lut_v[v].astype(np.float32)
+    hf, sf, vf = H * np.float32(6 / 180), S * np.float32(1 / 255), V * np.float32(1 / 255)
+    hf = np.where(hf >= 6, hf - 6, hf)
+    sec = np.floor(hf).astype(np.int64)
+    fr = (hf - sec.astype(np.float32)).astype(np.float32)
+    bad = (sec < 0) | (sec >= 6)
+    sec = np.where(bad, 0, sec)
+    fr = np.where(bad, np.float32(0), fr)
+    tab = np.stack((vf, vf * (1 - sf), vf * (1 - sf * fr), vf * (1 - sf * (1 - fr))), -1).astype(np.float32)
+    sector = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    idx = sector[sec]
+    out = np.take_along_axis(tab, idx, -1)
+    out = np.where((sf == 0)[..., None], vf[..., None], out)
+    return np.clip(np.rint(out * np.float32(255)), 0, 255).astype(np.uint8)

@@ -1,0 +1,189 @@
+// Image-side augmentations of the reference's loader as device kernels over uint8 HWC (BGR) images resident in HBM — SURVEY.md
+// §8(f) N2: mosaic-4 / mosaic-9 assembly (datasets/base_dataset.py:224-330), the perspective warp of random_warping
+// (lib/augmentations.py:45-74), hsv (:8-21) and mixup (:24-28).  At ~700 img/s per GPU the reference's 8 cv2 worker processes
+// (lib/load.py:19) cannot feed one MI355X; here a batch is byte movement at HBM speed:
+//   paste_rects   canvas filled with 114, then every source rectangle copied in the reference's paste order (later rectangles win,
+//                 as img9[y1:y2, x1:x2] = ... overwrites): one launch per batch of canvases, 4 pixels (12 bytes) per thread;
+//   warp          inverse perspective map per destination pixel + bilinear taps with OpenCV's fixed-point layout (5 fractional
+//                 coordinate bits, 15-bit weights, round-to-nearest), border value 114;
+//   hsv_gain      BGR -> HSV (OpenCV's 8-bit integer path: 12-bit division tables), three LUTs, HSV -> BGR (float path), in place;
+//   mixup         uint8(a * r + b * (1 - r)) in double, truncation like numpy's astype(uint8).
+// PARITY: paste and mixup are pure index / IEEE arithmetic and are pinned to the imported reference (fixture g11, the real
+// load_mosaic / load_mosaic9 / mixup ran); warp and hsv restate OpenCV (third-party, absent here, version un-pinned by the reference):
+// "parity unpinned" — checked only against this build's own numpy restatement (oracle/ref_data.py).
+#include "common.h"
+
+struct PasteRect {               // one `canvas[dy:dy+h, dx:dx+w] = src[sy:sy+h, sx:sx+w]`
+    int64_t src_off;             // byte offset of the source image in the pool
+    int src_w;                   // source row pitch in pixels
+    int sx, sy, dx, dy, w, h;
+    int canvas;                  // index of the destination canvas in the batch
+};
+
+__global__ __launch_bounds__(256) void paste_rects_kernel(const uint8_t* __restrict__ pool, const PasteRect* __restrict__ rects, int nrect,
+                                                          uint8_t* __restrict__ canvas, int CH, int CW, int fill)
+{
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= CW) return;
+    uint8_t px[3] = {(uint8_t)fill, (uint8_t)fill, (uint8_t)fill};
+    for (int r = nrect - 1; r >= 0; r--) {                          // the LAST paste that covers the pixel wins
+        const PasteRect q = rects[r];
+        if (q.canvas != b) continue;
+        const int rx = x - q.dx, ry = y - q.dy;
+        if ((unsigned)rx < (unsigned)q.w && (unsigned)ry < (unsigned)q.h) {
+            const uint8_t* s = pool + q.src_off + ((int64_t)(q.sy + ry) * q.src_w + q.sx + rx) * 3;
+            px[0] = s[0]; px[1] = s[1]; px[2] = s[2];
+            break;
+        }
+    }
+    uint8_t* d = canvas + (((int64_t)b * CH + y) * CW + x) * 3;
+    d[0] = px[0]; d[1] = px[1]; d[2] = px[2];
+}
+
+// dst[b] = warpPerspective(src[b], M[b]) with flags INTER_LINEAR, borderMode CONSTANT, borderValue (114, 114, 114).
+// Minv [B][9] double: the INVERSE of the matrix the caller passed to cv2.warpPerspective (OpenCV inverts it itself).
+__global__ __launch_bounds__(256) void warp_perspective_kernel(const uint8_t* __restrict__ src, int SH, int SW, const double* __restrict__ Minv,
+                                                               uint8_t* __restrict__ dst, int DH, int DW, int border)
+{
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= DW) return;
+    const double* m = Minv + (int64_t)b * 9;
+    // cv::warpPerspective: W = M20 x + M21 y + M22; fX = (M00 x + M01 y + M02) / W scaled by INTER_TAB_SIZE = 32 and rounded
+    // (saturate_cast<int> of a double = cvRound: round half to even)
+    double W = m[6] * x + m[7] * y + m[8];
+    W = W ? 32.0 / W : 0.0;
+    const double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, (m[0] * x + m[1] * y + m[2]) * W));
+    const double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, (m[3] * x + m[4] * y + m[5]) * W));
+    const int X = (int)rint(fX), Y = (int)rint(fY);
+    const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
+    // bilinear weights: OpenCV's table holds (1 - a/32, a/32) products scaled by 2^15 and rounded, corrected so the four sum to 2^15
+    const float fx1 = ax * (1.f / 32.f), fy1 = ay * (1.f / 32.f);
+    const float wf[4] = {(1.f - fy1) * (1.f - fx1), (1.f - fy1) * fx1, fy1 * (1.f - fx1), fy1 * fx1};
+    int w[4], sum = 0, imax = 0, imin = 0;
+    for (int k = 0; k < 4; k++) {
+        w[k] = (int)rintf(wf[k] * 32768.f);
+        sum += w[k];
+        if (w[k] > w[imax]) imax = k;
+        if (w[k] < w[imin]) imin = k;
+    }
+    // (initInterTab2D: the rounding error of the sum is pushed into the largest / smallest weight)
+    if (sum != 32768) {
+        const int diff = sum - 32768;
+        if (diff < 0) w[imax] -= diff; else w[imin] -= diff;
+    }
+    const uint8_t* sb = src + (int64_t)b * SH * SW * 3;
+    uint8_t* d = dst + (((int64_t)b * DH + y) * DW + x) * 3;
+    for (int c = 0; c < 3; c++) {
+        int acc = 0;
+        for (int k = 0; k < 4; k++) {
+            const int px = sx + (k & 1), py = sy + (k >> 1);
+            const int v = ((unsigned)px < (unsigned)SW && (unsigned)py < (unsigned)SH) ? sb[((int64_t)py * SW + px) * 3 + c] : border;
+            acc += v * w[k];
+        }
+        d[c] = (uint8_t)((acc + (1 << 14)) >> 15);
+    }
+}
+
+// cv2.cvtColor(BGR2HSV) on uint8 -> LUTs -> cv2.cvtColor(HSV2BGR), in place (lib/augmentations.py:8-21).  lut [3][256] uint8.
+__global__ __launch_bounds__(256) void hsv_gain_kernel(uint8_t* __restrict__ img, int64_t npix, const uint8_t* __restrict__ lut)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    uint8_t* p = img + i * 3;
+    const int b = p[0], g = p[1], r = p[2];
+    // RGB2HSV_b (OpenCV, hrange 180): 12-bit fixed-point division tables
+    int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int sdiv = v ? (int)rint((255 << 12) / (double)v) : 0;
+    const int hdiv = diff ? (int)rint((180 << 12) / (6.0 * diff)) : 0;
+    const int s = (diff * sdiv + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+    const int H = lut[h & 255], S = lut[256 + s], V = lut[512 + v];
+    // HSV2RGB_b: 8-bit values through the float converter (h in degrees / 2, s and v scaled by 1/255), result * 255 rounded
+    float hf = (float)H * (6.f / 180.f), sf = (float)S * (1.f / 255.f), vf = (float)V * (1.f / 255.f);
+    float bb, gg, rr;
+    if (sf == 0.f) {
+        bb = gg = rr = vf;
+    } else {
+        static const int sector[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+        if (hf < 0.f) { do hf += 6.f; while (hf < 0.f); }
+        else if (hf >= 6.f) { do hf -= 6.f; while (hf >= 6.f); }
+        const int sec = (int)floorf(hf);
+        hf -= (float)sec;
+        const int sc = (unsigned)sec >= 6u ? 0 : sec;
+        if ((unsigned)sec >= 6u) hf = 0.f;
+        float tab[4];
+        tab[0] = vf;
+        tab[1] = vf * (1.f - sf);
+        tab[2] = vf * (1.f - sf * hf);
+        tab[3] = vf * (1.f - sf * (1.f - hf));
+        bb = tab[sector[sc][0]];
+        gg = tab[sector[sc][1]];
+        rr = tab[sector[sc][2]];
+    }
+    p[0] = (uint8_t)min(255, max(0, (int)rintf(bb * 255.f)));
+    p[1] = (uint8_t)min(255, max(0, (int)rintf(gg * 255.f)));
+    p[2] = (uint8_t)min(255, max(0, (int)rintf(rr * 255.f)));
+}
+
+// out = (a * r + b * (1 - r)).astype(uint8): double arithmetic, truncation toward zero (lib/augmentations.py:24-28)
+__global__ __launch_bounds__(256) void mixup_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, double r, int64_t n,
+                                                    uint8_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = (double)a[i] * r + (double)b[i] * (1.0 - r);
+    out[i] = (uint8_t)(int)v;
+}
+
+extern "C" int ryolo_paste_rects(const uint8_t* pool, const void* rects_dev, int nrect, uint8_t* canvas, int ncanvas, int CH, int CW, int fill,
+                                 hipStream_t stream)
+{
+    if (ncanvas < 0 || CH < 0 || CW < 0 || nrect < 0) return RY_ERR_ARG;
+    if (ncanvas == 0 || CH == 0 || CW == 0) return RY_OK;
+    if (!canvas || (nrect && (!pool || !rects_dev))) return RY_ERR_ARG;
+    hipLaunchKernelGGL(paste_rects_kernel, dim3((unsigned)ry_cdiv(CW, 256), CH, ncanvas), dim3(256), 0, stream, pool,
+                       reinterpret_cast<const PasteRect*>(rects_dev), nrect, canvas, CH, CW, fill);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_paste_rect_bytes(int* bytes) { if (!bytes) return RY_ERR_ARG; *bytes = (int)sizeof(PasteRect); return RY_OK; }
+
+extern "C" int ryolo_warp_perspective_u8(const uint8_t* src, int batch, int SH, int SW, const double* Minv, uint8_t* dst, int DH, int DW,
+                                         int border, hipStream_t stream)
+{
+    if (batch < 0 || SH <= 0 || SW <= 0 || DH < 0 || DW < 0) return RY_ERR_ARG;
+    if (batch == 0 || DH == 0 || DW == 0) return RY_OK;
+    if (!src || !Minv || !dst) return RY_ERR_ARG;
+    hipLaunchKernelGGL(warp_perspective_kernel, dim3((unsigned)ry_cdiv(DW, 256), DH, batch), dim3(256), 0, stream, src, SH, SW, Minv, dst, DH, DW,
+                       border);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_hsv_gain_u8(uint8_t* img, int64_t npix, const uint8_t* lut, hipStream_t stream)
+{
+    if (npix < 0) return RY_ERR_ARG;
+    if (npix == 0) return RY_OK;
+    if (!img || !lut) return RY_ERR_ARG;
+    hipLaunchKernelGGL(hsv_gain_kernel, dim3((unsigned)ry_cdiv(npix, 256)), dim3(256), 0, stream, img, npix, lut);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_mixup_u8(const uint8_t* a, const uint8_t* b, double r, int64_t n, uint8_t* out, hipStream_t stream)
+{
+    if (n < 0) return RY_ERR_ARG;
+    if (n == 0) return RY_OK;
+    if (!a || !b || !out) return RY_ERR_ARG;
+    hipLaunchKernelGGL(mixup_kernel, dim3((unsigned)ry_cdiv(n, 256)), dim3(256), 0, stream, a, b, r, n, out);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
