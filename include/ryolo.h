@@ -213,6 +213,10 @@ int ryolo_warp_perspective_u8(const uint8_t* src, int batch, int SH, int SW, con
                               ryolo_stream_t stream);
 int ryolo_hsv_gain_u8(uint8_t* img, int64_t npix, const uint8_t* lut, ryolo_stream_t stream);
 int ryolo_mixup_u8(const uint8_t* a, const uint8_t* b, double r, int64_t n, uint8_t* out, ryolo_stream_t stream);
+/* pad_to_square (datasets/base_dataset.py:33-56): src [SH, SW, 3] resized (cv2.resize INTER_LINEAR semantics) to NH x NW and placed at
+ * (top, left) of the OH x OW canvas filled with `fill` */
+int ryolo_letterbox_u8(const uint8_t* src, int SH, int SW, int NH, int NW, int top, int left, uint8_t* dst, int OH, int OW, int fill,
+                       ryolo_stream_t stream);
 
 int ryolo_struct_sizes(int* sizes /* [11] */);
 

@@ -242,3 +242,43 @@ def hsv_gain_numpy(img, r):
     out = np.take_along_axis(tab, idx, -1)
     out = np.where((sf == 0)[..., None], vf[..., None], out)
     return np.clip(np.rint(out * np.float32(255)), 0, 255).astype(np.uint8)
+
+
+def resize_linear_numpy(src, dsize):
+    """cv2.resize(src, (w, h), interpolation = INTER_LINEAR) for uint8, restated from OpenCV (11-bit coefficients, two-pass integer
+    arithmetic).  PARITY UNPINNED (OpenCV absent, version un-pinned by the reference)."""
+    NW, NH = dsize
+    SH, SW = src.shape[:2]
+
+    def coef(dn, sn):
+        o = np.arange(dn, dtype=np.float64)
+        f = ((o + 0.5) * (sn / dn) - 0.5).astype(np.float32)
+        si = np.floor(f).astype(np.int64)
+        f = (f - si.astype(np.float32)).astype(np.float32)
+        lo, hi = si < 0, si >= sn - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        si = np.where(lo, 0, np.where(hi, sn - 1, si))
+        return si, np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64), np.rint(f * np.float32(2048)).astype(np.int64)
+    sx, ax0, ax1 = coef(NW, SW)
+    sy, by0, by1 = coef(NH, SH)
+    sx1, sy1 = np.minimum(sx + 1, SW - 1), np.minimum(sy + 1, SH - 1)
+    s = src.astype(np.int64)
+    r0 = s[sy][:, sx] * ax0[None, :, None] + s[sy][:, sx1] * ax1[None, :, None]
+    r1 = s[sy1][:, sx] * ax0[None, :, None] + s[sy1][:, sx1] * ax1[None, :, None]
+    out = (((by0[:, None, None] * (r0 >> 4)) >> 16) + ((by1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def pad_to_square_numpy(img, new_shape, pad_value=114):
+    """datasets/base_dataset.py:33-56 with cv2.resize -> resize_linear_numpy and cv2.copyMakeBorder(BORDER_CONSTANT) -> np.pad."""
+    shape = img.shape[:2]
+    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+    new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    dw /= 2
+    dh /= 2
+    if shape[::-1] != new_unpad:
+        img = resize_linear_numpy(img, new_unpad)
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return np.pad(img, ((top, bottom), (left, right), (0, 0)), constant_values=pad_value), (dh, dw)

@@ -142,6 +142,54 @@ __global__ __launch_bounds__(256) void mixup_kernel(const uint8_t* __restrict__ 
     out[i] = (uint8_t)(int)v;
 }
 
+// Letterbox of pad_to_square (datasets/base_dataset.py:33-56): cv2.resize(img, (NW, NH), INTER_LINEAR) placed at (top, left) of an
+// OH x OW canvas filled with `fill` (cv2.copyMakeBorder, BORDER_CONSTANT).  OpenCV's 8-bit linear resize: source coordinate
+// (x + 0.5) * scale - 0.5, 11-bit coefficients (cvRound), horizontal pass in int, vertical pass ((b0 * (S0 >> 4)) >> 16) + ... + 2 >> 2.
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int SH, int SW, int NH, int NW, int top, int left,
+                                                        uint8_t* __restrict__ dst, int OH, int OW, int fill)
+{
+    const int y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= OW) return;
+    uint8_t* d = dst + ((int64_t)y * OW + x) * 3;
+    const int rx = x - left, ry = y - top;
+    if ((unsigned)rx >= (unsigned)NW || (unsigned)ry >= (unsigned)NH) { d[0] = d[1] = d[2] = (uint8_t)fill; return; }
+    if (NH == SH && NW == SW) {                                     // `if shape[::-1] != new_unpad` — no resize
+        const uint8_t* sp = src + ((int64_t)ry * SW + rx) * 3;
+        d[0] = sp[0]; d[1] = sp[1]; d[2] = sp[2];
+        return;
+    }
+    auto coef = [](int o, int dn, int sn, int& s0, int& a0, int& a1) {
+        const double scale = (double)sn / (double)dn;
+        float f = (float)((o + 0.5) * scale - 0.5);
+        int si = (int)floorf(f);
+        f -= (float)si;
+        if (si < 0) { f = 0.f; si = 0; }
+        if (si >= sn - 1) { f = 0.f; si = sn - 1; }
+        s0 = si;
+        a0 = (int)rintf((1.f - f) * 2048.f);
+        a1 = (int)rintf(f * 2048.f);
+    };
+    int sx, ax0, ax1, sy, by0, by1;
+    coef(rx, NW, SW, sx, ax0, ax1);
+    coef(ry, NH, SH, sy, by0, by1);
+    const int sx1 = min(sx + 1, SW - 1), sy1 = min(sy + 1, SH - 1);
+    for (int c = 0; c < 3; c++) {
+        const int r0 = src[((int64_t)sy * SW + sx) * 3 + c] * ax0 + src[((int64_t)sy * SW + sx1) * 3 + c] * ax1;
+        const int r1 = src[((int64_t)sy1 * SW + sx) * 3 + c] * ax0 + src[((int64_t)sy1 * SW + sx1) * 3 + c] * ax1;
+        d[c] = (uint8_t)((((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+extern "C" int ryolo_letterbox_u8(const uint8_t* src, int SH, int SW, int NH, int NW, int top, int left, uint8_t* dst, int OH, int OW, int fill,
+                                  hipStream_t stream)
+{
+    if (SH <= 0 || SW <= 0 || NH <= 0 || NW <= 0 || OH <= 0 || OW <= 0) return RY_ERR_ARG;
+    if (!src || !dst) return RY_ERR_ARG;
+    hipLaunchKernelGGL(letterbox_kernel, dim3((unsigned)ry_cdiv(OW, 256), OH), dim3(256), 0, stream, src, SH, SW, NH, NW, top, left, dst, OH, OW, fill);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
 extern "C" int ryolo_paste_rects(const uint8_t* pool, const void* rects_dev, int nrect, uint8_t* canvas, int ncanvas, int CH, int CW, int fill,
                                  hipStream_t stream)
 {

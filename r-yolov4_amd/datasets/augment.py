@@ -229,3 +229,26 @@ def mixup(img, img2, r):
     out = torch.empty_like(img)
     hip.call("ryolo_mixup_u8", hip.ptr(img.contiguous()), hip.ptr(img2.contiguous()), float(r), img.numel(), hip.ptr(out), hip.stream())
     return out
+
+
+def pad_to_square_plan(shape, new_shape):
+    """datasets/base_dataset.py:33-56, the integer part: (new_unpad (w, h), (top, bottom, left, right), (dh, dw))."""
+    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+    new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    dw /= 2
+    dh /= 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return new_unpad, (top, bottom, left, right), (dh, dw)
+
+
+def pad_to_square(img, new_shape, pad_value=114):
+    """Device letterbox: img [H, W, 3] uint8 -> (canvas [top + NH + bottom, left + NW + right, 3], (dh, dw)) as the reference returns."""
+    hip.require_device(img, "pad_to_square")
+    H, W, _ = img.shape
+    (nw, nh), (top, bottom, left, right), pad = pad_to_square_plan((H, W), new_shape)
+    OH, OW = top + nh + bottom, left + nw + right
+    out = torch.empty((OH, OW, 3), dtype=torch.uint8, device=img.device)
+    hip.call("ryolo_letterbox_u8", hip.ptr(img.contiguous()), H, W, nh, nw, top, left, hip.ptr(out), OH, OW, pad_value, hip.stream())
+    return out, pad

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "ryolo_warp_perspective_u8": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     "ryolo_hsv_gain_u8": [_P, _L, _P, _P],
     "ryolo_mixup_u8": [_P, _P, ctypes.c_double, _L, _P, _P],
+    "ryolo_letterbox_u8": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "ryolo_pp_emit": [_P, _P, _P, _I, _L, _L, _P, _P],
     "ryolo_map_match_workspace_bytes": [_L, _L, ctypes.POINTER(_Z)],
     "ryolo_map_match": [_P, _P, _P, _P, _I, _L, _L, _P, _I, _I, _P, _P, _Z, _P],

@@ -127,3 +127,17 @@ def test_device_warp_and_hsv_against_numpy_restatement():
         got = A.hsv_gain(dev.clone(), r).cpu().numpy()
         ref = ref_data.hsv_gain_numpy(imgs, r)
         assert np.array_equal(got, ref), (r, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,new", [((48, 80), (64, 64)), ((64, 64), (64, 64)), ((30, 21), (96, 96)), ((100, 37), (64, 64))])
+def test_device_letterbox_against_numpy_restatement(shape, new):
+    """pad_to_square (datasets/base_dataset.py:33-56): integer plan shared with the reference's arithmetic; resize pixels restate
+    OpenCV's 8-bit INTER_LINEAR (parity unpinned) and equal the numpy restatement bit for bit; the border is 114."""
+    from oracle import ref_data
+    from ryolov4_amd.datasets import augment as A
+    img = np.random.RandomState(shape[0]).randint(0, 256, size=shape + (3,)).astype(np.uint8)
+    ref, pad_ref = ref_data.pad_to_square_numpy(img, new)
+    got, pad = A.pad_to_square(torch.from_numpy(img).cuda(), new)
+    assert pad == pad_ref and tuple(got.shape) == ref.shape
+    assert np.array_equal(got.cpu().numpy(), ref)
