@@ -272,35 +272,34 @@ __device__ __forceinline__ void stem_patch_pixel_frags(unsigned pa, unsigned pb,
     f1 = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(v8, v9), pack_bf2(v10, v11), pack_bf2(v12, v13), pack_bf2(v14, 0.f)));
 }
 
-// (image, row, first column) of a wave's current tile, advanced by a fixed number of tiles with carries: no division in the loop
+// Tile order: every wave owns a CONTIGUOUS range of tiles in column-major order (down one 32-pixel column block of an image, then the
+// next block), so a tile's three image rows are the previous tile's last two plus one new row: the patch is re-read from L1 / L2
+// instead of HBM (a raster walk with a grid-sized stride fetched every image row three times: 2.2 GB for the 0.5 GB image, PMC).
 struct StemWalk {
-    int n, oh, ow, an, ah, aw;
-    __device__ __forceinline__ void init(int64_t tile, int64_t stride_tiles, int H, int W)
+    int n, oh, ow;
+    __device__ __forceinline__ void init(int64_t u, int H, int W)
     {
-        const int HW = H * W;
-        const int64_t p0 = tile * 32;
-        n = (int)(p0 / HW);
-        const int rem = (int)(p0 - (int64_t)n * HW);
-        oh = rem / W;
-        ow = rem - oh * W;
-        const int64_t adv = stride_tiles * 32;
-        an = (int)(adv / HW);
-        const int ar = (int)(adv - (int64_t)an * HW);
-        ah = ar / W;
-        aw = ar - ah * W;
+        const int64_t per = (int64_t)H * (W >> 5);
+        n = (int)(u / per);
+        const int r = (int)(u - (int64_t)n * per);
+        const int cb = r / H;
+        oh = r - cb * H;
+        ow = cb << 5;
     }
     __device__ __forceinline__ void step(int H, int W)
     {
-        ow += aw; oh += ah; n += an;
-        if (ow >= W) { ow -= W; oh++; }
-        if (oh >= H) { oh -= H; n++; }
+        if (++oh == H) { oh = 0; ow += 32; if (ow == W) { ow = 0; n++; } }
     }
 };
 
 template <int EPI>
 __global__ __launch_bounds__(256) void stem3x3_fwd_lds_kernel(const StemParams p)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char patch[4][2][SP_BYTES];
+    // ring of NB tile buffers per wave, prefetch distance D.  Measured at 64 x 800^2: D = 1 -> 0.41 / 0.98 ms (statistics / fused pass),
+    // D = 3 -> 0.45 / 1.19 ms: the loop is not waiting for its DMA, it runs at its instruction rate (~100 VALU + ~100 SALU per tile:
+    // 16 waves per CU retire one tile per ~190 cycles), so one tile ahead is enough and the smaller footprint wins
+    constexpr int NB = 2, D = NB - 1;
+    __shared__ __attribute__((aligned(1024))) unsigned char patch[4][NB][SP_BYTES];
     __shared__ float red[4][2][32];
     __shared__ __attribute__((aligned(16))) bf16_t otile[4][32][40];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -324,19 +323,28 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_lds_kernel(const StemParams p
 #pragma unroll
     for (int e = 0; e < 16; e++) { ssum[e] = 0.f; ssq[e] = 0.f; }
 
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t tt = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
-    StemWalk nx;                                                   // the tile whose patch is issued next
-    nx.init(tt < ntiles ? tt : 0, stride, H, W);
+    const int64_t nwaves = (int64_t)gridDim.x * 4, per_wave = (ntiles + nwaves - 1) / nwaves;
+    const int64_t u0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave)) * per_wave;
+    const int64_t u1 = u0 + per_wave < ntiles ? u0 + per_wave : ntiles;
+    StemWalk nx, cur;                                              // nx: the tile whose patch is issued next; cur: the tile being computed
+    nx.init(u0 < ntiles ? u0 : 0, H, W);
+    cur = nx;
     auto issue = [&](int buf) { stem_patch_issue(L, p.img, (nx.n * 3 * H + nx.oh) * W + nx.ow, nx.oh, nx.ow, H, W, &patch[wave][buf][0]); };
-    if (tt < ntiles) issue(0);
+    // prologue: tiles u0 .. u0 + D - 1 (always 2 DMA instructions each: past the end of the range they re-read its last tile, so the
+    // counted wait below holds for every iteration)
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        issue(d);
+        if (u0 + d + 1 < u1) nx.step(H, W);
+    }
     const int offA = (px_l + 120 * h) * 4, offB = (px_l + 40 * h) * 4;
     int buf = 0;
-    for (; tt < ntiles; tt += stride, buf ^= 1) {
-        // prefetch the next tile (always 2 DMA instructions: past the end they re-read the last tile), then wait for everything older
-        if (tt + stride < ntiles) nx.step(H, W);
-        issue(buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    for (int64_t tt = u0; tt < u1; tt++) {
+        issue(buf == 0 ? D : buf - 1);                             // tile tt + D into the buffer tile tt - 1 just left
+        if (tt + D + 1 < u1) nx.step(H, W);
+        // everything but the D newest tiles' pieces has landed.  (The stores of earlier iterations sit between them in issue order;
+        // counting only the 2 D newer loads is exact without stores and conservative with them, whatever order stores retire in.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
         bf16x8 f0, f1;
         const unsigned pbase = lds_addr(&patch[wave][buf][0]);
         stem_patch_pixel_frags(pbase + (unsigned)offA, pbase + (unsigned)offB, f0, f1);
@@ -375,11 +383,13 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_lds_kernel(const StemParams p
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int pr = half * 16 + (lane >> 2), sl = lane & 3;
-                const int64_t opix = tt * 32 + pr;
+                const int64_t opix = ((int64_t)cur.n * H + cur.oh) * W + cur.ow + pr;
                 const uint4 o = *reinterpret_cast<const uint4*>(&otile[wave][pr][sl * 8]);
                 if (sl * 8 < p.Cout) *reinterpret_cast<uint4*>(p.out + opix * p.ldC + sl * 8) = o;
             }
         }
+        cur.step(H, W);
+        buf = buf == D ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (EPI == EPI_STATS) {
@@ -576,7 +586,8 @@ __global__ __launch_bounds__(1024) void stem_fold_kernel(const float* __restrict
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void stem3x3_bwd_kernel(const StemBwdParams p, float* __restrict__ slabs)
 {
     // wave-private double buffers: image patch (LDS-patch scheme above) + the dz tile [32 px][32 ch] bf16; reused for the final fold
-    constexpr int WAVE_BYTES = 2 * (SP_BYTES + 2048);
+    constexpr int NB = 2, D = NB - 1;                              // one tile ahead (D = 2 measured the same 1.19 ms: instruction-rate bound, see the forward kernel)
+    constexpr int WAVE_BYTES = NB * (SP_BYTES + 2048);
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * WAVE_BYTES > 4 * 32 * 33 * 4 ? 4 * WAVE_BYTES : 4 * 32 * 33 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -605,10 +616,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int e = 0; e < 16; e++) { accG[e] = 0.f; accX[e] = 0.f; }
     float s0 = 0.f, s1 = 0.f;
 
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t tt = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    const int64_t nwaves = (int64_t)gridDim.x * 4, per_wave = (ntiles + nwaves - 1) / nwaves;
+    const int64_t u0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave)) * per_wave;
+    const int64_t u1 = u0 + per_wave < ntiles ? u0 + per_wave : ntiles;
     StemWalk nx;                                                   // the tile whose operands are issued next
-    nx.init(tt < ntiles ? tt : 0, stride, H, W);
+    nx.init(u0 < ntiles ? u0 : 0, H, W);
     const bf16_t* dz_lane = p.dz + (int64_t)d_row * p.lddz + d_slot * 8;
     auto issue = [&](int b) {                                       // 4 DMA instructions: the patch (2) + the 2-KiB dz tile (2)
         stem_patch_issue(L, p.img, (nx.n * 3 * H + nx.oh) * W + nx.ow, nx.oh, nx.ow, H, W, patch_buf(b));
@@ -617,13 +629,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int u = 0; u < 2; u++)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(dz_lane + (t0 + 16 * u) * (int64_t)p.lddz), (lds_void_t*)(dz_buf(b) + u * 1024), 16, 0, 0);
     };
-    if (tt < ntiles) issue(0);
+#pragma unroll
+    for (int d = 0; d < D; d++) {                                   // prologue: tiles u0 .. u0 + D - 1 (past the end: re-reads of the last tile)
+        issue(d);
+        if (u0 + d + 1 < u1) nx.step(H, W);
+    }
     const int offA = (l31 + 120 * h) * 4, offB = (l31 + 40 * h) * 4;
     int buf = 0;
-    for (; tt < ntiles; tt += stride, buf ^= 1) {
-        if (tt + stride < ntiles) nx.step(H, W);
-        issue(buf ^ 1);                                            // next tile in flight (past the end: a harmless re-read of the last)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // this tile has landed (wave-private buffers: no barrier)
+    for (int64_t tt = u0; tt < u1; tt++, buf = buf == D ? 0 : buf + 1) {
+        issue(buf == 0 ? D : buf - 1);                             // tile tt + D into the buffer tile tt - 1 just left
+        if (tt + D + 1 < u1) nx.step(H, W);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * D) : "memory");   // this tile has landed (wave-private buffers: no barrier)
         const float* patch = reinterpret_cast<const float*>(patch_buf(buf));
         // dz for this lane's (channel, 16 pixels): four transposed reads, through inline asm (the builtin would make hipcc drain the
         // prefetch just issued, conv_internal.h); waited for below, after the recompute
