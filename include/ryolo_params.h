@@ -33,6 +33,12 @@ typedef struct ConvGemmParams {
     int pipe;                                       // bits 0-7 mainloop of the generic kernel: 0 register-staged double buffer, 1 LDS-DMA ring;
                                                     // 0x100 force 32-channel stages; 0x200 3x3 stride-1 layers with >= 512 tiles run the halo-patch kernel (conv3x3.hip), 0x400 also smaller ones
     unsigned a_bytes, w_bytes;                      // byte extents of A / W (informational; reserved for buffer-descriptor addressing)
+    const unsigned char* pool_idx; const bf16_t* pool_dz; int pool_ldi, pool_ld;
+                                                    // pool_idx != null (bf16 epilogues of the generic kernel, identity output grid): the gradient of a
+                                                    // MaxPool2d(2, 2) of the SAME tensor is added in the store — out[(h, w), n] += pool_dz[(h/2, w/2), n]
+                                                    // where pool_idx[(h/2, w/2), n] == (h & 1) * 2 + (w & 1) (argmax window offsets of ryolo_maxpool_fwd;
+                                                    // row strides pool_ldi / pool_ld elements).  Replaces a read-modify-write pass of ryolo_maxpool_bwd
+                                                    // over the full-resolution gradient (MaxConv, model/utils.py:146-160); bits equal the two-pass result
     int s2d_cin;                                    // > 0: depth-to-space store of a stride-2 data gradient computed as ONE stride-1 GEMM over the dY
                                                     // grid with Nout = 4 * s2d_cin columns (output parity ph, pw, then channel) and 2x2 taps (weights from
                                                     // ryolo_pack_s2d): column n of row (img, a, b) goes to pixel (2a + ph, 2b + pw), channel n % s2d_cin —

@@ -401,6 +401,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         constexpr int RPI = 64 / CH;                           // rows per iteration
         const int ch = lane % CH, r0 = lane / CH;
         const int n = n0 + wn * WTN + ch * 8;
+        // fused MaxPool2d(2, 2) gradient: (image, row, column) of the tile's first pixel, rows inside the tile by small exact divisions
+        int pl_img = 0, pl_oh = 0, pl_ow = 0;
+        float pl_rOW = 0.f, pl_rOH = 0.f;
+        if (p.pool_idx) {
+            const int64_t HWo = (int64_t)p.OH * p.OW;
+            pl_img = (int)(m0 / HWo);
+            const int rem = (int)(m0 - (int64_t)pl_img * HWo);
+            pl_oh = rem / p.OW;
+            pl_ow = rem - pl_oh * p.OW;
+            pl_rOW = 1.0f / (float)p.OW;
+            pl_rOH = 1.0f / (float)p.OH;
+        }
 #pragma unroll
         for (int it = 0; it < WTM / RPI; it++) {
             const int r = it * RPI + r0;
@@ -409,6 +421,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             const int64_t pix = out_pixel(m);
             uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
             bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
+            if (p.pool_idx) {
+                const int o_ = pl_ow + wm * WTM + r;
+                const int wr_ = small_div(o_, p.OW, pl_rOW);
+                const int ow_ = o_ - wr_ * p.OW, orow_ = pl_oh + wr_;
+                const int wi_ = small_div(orow_, p.OH, pl_rOH);
+                const int oh_ = orow_ - wi_ * p.OH;
+                const int64_t pp = ((int64_t)(pl_img + wi_) * (p.OH >> 1) + (oh_ >> 1)) * (p.OW >> 1) + (ow_ >> 1);
+                const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.pool_idx + pp * p.pool_ldi + n);
+                const uint4 gz = *reinterpret_cast<const uint4*>(p.pool_dz + pp * p.pool_ld + n);
+                const unsigned want = (unsigned)((oh_ & 1) * 2 + (ow_ & 1));
+                const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                const unsigned* b = reinterpret_cast<const unsigned*>(&gz);
+                unsigned w[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float g0 = ((packed >> (16 * q)) & 0xff) == want ? __uint_as_float(b[q] << 16) : 0.f;
+                    const float g1 = ((packed >> (16 * q + 8)) & 0xff) == want ? __uint_as_float(b[q] & 0xffff0000u) : 0.f;
+                    w[q] = pack_bf2(__uint_as_float(a[q] << 16) + g0, __uint_as_float(a[q] & 0xffff0000u) + g1);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
             if (p.s2d_cin) {                                       // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
                 const int q = n / p.s2d_cin, ci = n - q * p.s2d_cin;
                 o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
@@ -818,6 +851,10 @@ extern "C" int ryolo_pack_s2d(const float* w, int Cout, int Cin, bf16_t* out, hi
 
 static int gemm_check(const ConvGemmParams& p)
 {
+    if (p.pool_idx && (!p.pool_dz || p.pool_ld % 8 || p.pool_ldi % 8 || p.Nout % 8 || (p.OH & 1) || (p.OW & 1) || p.OW >= 32768 || p.nclasses != 1 ||
+                       p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || p.cls[0].oh_add || p.cls[0].ow_add ||
+                       (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.s2d_cin))
+        return RY_ERR_ARG;
     if (p.s2d_cin && (p.s2d_cin % 8 || p.Nout != 4 * p.s2d_cin || p.oh_mul != 2 || p.ow_mul != 2 || p.nclasses != 1 ||
                       (p.epi != EPI_RAW && p.epi != EPI_ACCUM)))
         return RY_ERR_ARG;

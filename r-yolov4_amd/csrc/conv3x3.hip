@@ -388,6 +388,7 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
     g = P3Geom{};
     const TapClass& tc = p.cls[0];
     if (p.nclasses != 1 || tc.ntaps != 9 || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
+    if (p.pool_idx || p.s2d_cin) return false;                    // epilogue variants of the generic kernel only
     if (p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || tc.oh_add || tc.ow_add) return false;
     if (p.Cin % 32 || p.Nout < 64 || p.Nout % 8 || p.ldA % 8 || p.ldC % 8 || !p.zeros) return false;
     if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT && p.epi != EPI_ACCUM) return false;

@@ -301,7 +301,7 @@ class Graph:
 
     # ------------------------------------------------------------------ convolution
     def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,
-              coeffs=None, act=0, bias=None, s2d=0):
+              coeffs=None, act=0, bias=None, s2d=0, pool=None):
         """Emit one ryolo_conv_gemm launch.  For epi == EPI_STATS the partial-statistics buffer is sized by the library's plan
         (one [2][Nout] row per M tile of the kernel it will run) and returned."""
         p = S.ConvGemmParams()
@@ -325,6 +325,8 @@ class Graph:
         p.a_bytes, p.w_bytes = A.span_bytes, W.numel() * 2
         p.pipe = self.rt.gemm_pipe
         p.s2d_cin = s2d
+        if pool is not None:
+            p.pool_idx, p.pool_dz, p.pool_ldi, p.pool_ld = pool
         stats = None
         if epi == S.EPI_STATS:
             rows = S.I()
@@ -341,15 +343,20 @@ class Graph:
         OW = (x.W + 2 * pad - k) // s + 1
         return k, s, pad, OH, OW
 
-    def _dgrad(self, conv, pk, dy, dy_ptr, dy_cin, x):
-        """x.grad (=|+=) conv_transpose(dy).  dy: TRef-like geometry (N, OH, OW, ld)."""
+    def _dgrad(self, conv, pk, dy, dy_ptr, dy_cin, x, pool=None):
+        """x.grad (=|+=) conv_transpose(dy).  dy: TRef-like geometry (N, OH, OW, ld).  pool = {"idx", "z"} of a MaxPool2d(2, 2) of the
+        same tensor x: its gradient is added in this launch's store (1x1 stride-1 layers on the generic kernel only)."""
         k, s, pad, OH, OW = self._conv_geom(conv, x)
         mode = x.grad_write_mode()
         epi = S.EPI_ACCUM if mode else S.EPI_RAW
         cin = conv.in_channels
         if s == 1:
             taps = [(pad - r, pad - c, r * k + c) for r in range(k) for c in range(k)]
-            self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld)
+            pl = None
+            if pool is not None:
+                assert k == 1 and pool["z"].C == x.C
+                pl = (pool["idx"].data_ptr(), pool["z"].gptr(), x.C, pool["z"].ld)
+            self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld, pool=pl)
         elif (self.rt.s2d_dgrad and k == 3 and pad == 1 and cin <= 32 and cin % 8 == 0 and x.H % 2 == 0 and x.W % 2 == 0
               and dy_cin % 32 == 0 and dy_cin == conv.out_channels):
             # narrow stride-2 layer: ONE stride-1 GEMM over the dY grid, N = 4 parities x cin, 2x2 taps, depth-to-space store
@@ -402,7 +409,7 @@ class Graph:
         if on_side:
             self.side_idx.add(len(self.bwd) - 1)
 
-    def conv_raw(self, conv, x, want_stats, fused=None):
+    def conv_raw(self, conv, x, want_stats, fused=None, pool_grad=None):
         """Emit the forward conv; returns (y TRef [M, Cout] raw bf16, stats tensor or None, backward-emitter).
         fused = (coeffs [4][Cout], act code, z TRef): eval-mode epilogue writes act(bn(conv)) straight into z (no raw y)."""
         rt = self.rt
@@ -417,7 +424,7 @@ class Graph:
         def backward(need_dx=True):
             self._wgrad(conv, y, y.gptr(), cout, x)
             if need_dx:
-                self._dgrad(conv, pk, y, y.gptr(), cout, x)
+                self._dgrad(conv, pk, y, y.gptr(), cout, x, pool=pool_grad if (pool_grad and pool_grad.get("idx") is not None) else None)
         return y, stats, backward
 
     def stem_raw(self, conv, want_stats, fused=None):
@@ -539,7 +546,7 @@ class Graph:
         return z
 
     # ------------------------------------------------------------------ Conv = conv -> BN -> act (+ residual)
-    def conv_bn_act(self, conv, bn, act, x, out=None, residual=None, stem=False):
+    def conv_bn_act(self, conv, bn, act, x, out=None, residual=None, stem=False, pool_grad=None):
         """model/utils.py:6-32.  x None => stem on the staged input image.  Returns the activation TRef."""
         rt = self.rt
         train = self.training
@@ -564,7 +571,7 @@ class Graph:
             z = self._stem_recompute(conv, bn, actc, out)
             if z is not None:
                 return z
-        y, stats, conv_bwd = (self.stem_raw(conv, bstat) if stem else self.conv_raw(conv, x, bstat))
+        y, stats, conv_bwd = (self.stem_raw(conv, bstat) if stem else self.conv_raw(conv, x, bstat, pool_grad=pool_grad))
         co = self.f32(4, cout)
         if bstat:
             self._call(self.fwd, "ryolo_bn_finalize", stats.data_ptr(), stats.shape[0], cout, float(y.M), float(bn.eps), float(bn.momentum),
@@ -759,7 +766,9 @@ class Graph:
         return z
 
     # ------------------------------------------------------------------ pooling / upsample
-    def maxpool(self, x, k, stride, out=None):
+    def maxpool(self, x, k, stride, out=None, grad_into=None):
+        """grad_into: a dict handed earlier to the sibling 1x1 conv of the same input (conv_bn_act(..., pool_grad=grad_into)): this pool's
+        backward is then NOT a launch of its own — the sibling's data-gradient store adds it (ConvGemmParams.pool_idx)."""
         pad = 0 if stride == 2 else k // 2
         OH = (x.H + 2 * pad - k) // stride + 1
         OW = (x.W + 2 * pad - k) // stride + 1
@@ -780,6 +789,9 @@ class Graph:
             p.rowidx = rowidx.data_ptr() if rowidx is not None else None
             p.growws = grow.data_ptr() if grow is not None else None
         self._call(self.fwd, "ryolo_maxpool_fwd", p)
+        if self.training and grad_into is not None:
+            grad_into["idx"], grad_into["z"] = idx, z
+            return z
         if self.training:
             def backward():
                 q = S.PoolParams()

@@ -36,6 +36,9 @@ class Runtime:
         self.stem_recompute = os.environ.get("RYOLO_STEM_RECOMPUTE", "1") != "0"
         # narrow stride-2 data gradients (<= 32 input channels: the second conv of yolov4 / yolov7) as one space-to-depth GEMM
         self.s2d_dgrad = os.environ.get("RYOLO_S2D_DGRAD", "1") != "0"
+        # MaxConv (model/utils.py:146-160): the MaxPool2d(2, 2) gradient is added inside the store of the sibling 1x1 conv's data
+        # gradient (same input tensor) instead of a read-modify-write pass over the full-resolution gradient
+        self.fuse_pool_grad = os.environ.get("RYOLO_FUSE_POOL_GRAD", "1") != "0"
         self._s2d = {}                    # id(conv) -> (conv, bf16 image [4 Cin][4][CoutP]) refreshed with the other packed weights
         self.side_event = None            # set by Graph.run around a gradient-bucket hook: event of the weight-gradient stream
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams

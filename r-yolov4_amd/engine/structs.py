@@ -19,7 +19,8 @@ class ConvGemmParams(C.Structure):
     _fields_ = [("A", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldA", I),
                 ("W", P), ("Nout", I), ("wtaps", I), ("OH", I), ("OW", I), ("sh", I), ("sw", I),
                 ("oh_mul", I), ("ow_mul", I), ("OHf", I), ("OWf", I), ("nclasses", I), ("cls", TapClass * 4),
-                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint), ("s2d_cin", I)]
+                ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint),
+                ("pool_idx", P), ("pool_dz", P), ("pool_ldi", I), ("pool_ld", I), ("s2d_cin", I)]
 
 
 class WgradParams(C.Structure):

@@ -26,9 +26,9 @@ class Conv(nn.Module):
         self.conv = nn.ModuleList(mods)
         self.act, self.has_bn = activation, bn
 
-    def emit(self, g, x, out=None, residual=None, stem=False):
+    def emit(self, g, x, out=None, residual=None, stem=False, pool_grad=None):
         assert self.has_bn, "head convs are emitted through Graph.head"
-        return g.conv_bn_act(self.conv[0], self.conv[1], self.act, x, out=out, residual=residual, stem=stem)
+        return g.conv_bn_act(self.conv[0], self.conv[1], self.act, x, out=out, residual=residual, stem=stem, pool_grad=pool_grad)
 
     def forward(self, x):
         raise RuntimeError("ryolov4_amd blocks have no eager forward: run them through Yolo.forward (static HIP plan)")
@@ -179,6 +179,16 @@ class MaxConv(nn.Module):               # model/utils.py:146-160
 
     def emit(self, g, x, out=None):
         cat = out if out is not None else g.new(x.N, x.H // 2, x.W // 2, 2 * self.h)
+        if g.training and g.rt.fuse_pool_grad and x.H % 2 == 0 and x.W % 2 == 0 and x.C % 8 == 0 and x.W < 32768:
+            # cv2 first: backward runs in reverse forward order, so cv2's data gradient comes AFTER cv1's (which produces the pooled
+            # tensor's gradient) and adds the MaxPool gradient in its own store — no pass of its own over the full-resolution gradient
+            holder = {}
+            t2 = self.cv2.emit(g, x, pool_grad=holder)
+            with g.side_branch():                           # pool -> 1x1 beside the 3x3 stride 2
+                self.cv1.emit(g, g.maxpool(x, 2, 2, grad_into=holder), out=cat.slice(0, self.h))
+            self.cv3.emit(g, t2, out=cat.slice(self.h, self.h))
+            g.join_side()
+            return cat
         with g.side_branch():                               # pool -> 1x1 beside 1x1 -> 3x3 stride 2
             self.cv1.emit(g, g.maxpool(x, 2, 2), out=cat.slice(0, self.h))
         self.cv3.emit(g, self.cv2.emit(g, x), out=cat.slice(self.h, self.h))
