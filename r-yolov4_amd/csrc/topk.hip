@@ -52,30 +52,43 @@ __device__ __forceinline__ void hist_add(unsigned* hist, unsigned bin, bool acti
 }
 
 // ---- select: composites of the K largest keys of row b -> comp[b][0 .. nsel) (unordered among > T, index order at == T), zero padded to P
+// Each of the 16 waves walks ONE contiguous segment of the row (64 consecutive keys per load, 4 loads in flight), so the index-ordered
+// compaction needs no workgroup barrier inside the walk: a counting sweep, one 16-entry scan, a writing sweep.
+#define TK_WAVES (TK_THREADS / 64)
+#define TK_UNROLL 4
 __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* __restrict__ key, int64_t M, int K, int P, u64* __restrict__ comp,
                                                                  int32_t* __restrict__ nsel)
 {
     __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_remaining, s_valid, s_run_eq, s_run_sel;
-    __shared__ unsigned wave_a[16], wave_b[16];
+    __shared__ unsigned s_prefix, s_remaining, s_valid;
+    __shared__ unsigned wave_gt[TK_WAVES], wave_eq[TK_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* krow = key + (int64_t)b * M;
     u64* crow = comp + (int64_t)b * P;
-    if (tid == 0) { s_prefix = 0; s_valid = 0; s_run_eq = 0; s_run_sel = 0; }
+    const int64_t per = (M + TK_WAVES - 1) / TK_WAVES, seg = (per + 64 * TK_UNROLL - 1) / (64 * TK_UNROLL) * (64 * TK_UNROLL);
+    const int64_t s0 = (int64_t)wave * seg, s1 = s0 + seg < M ? s0 + seg : M;
+    if (tid == 0) { s_prefix = 0; s_valid = 0; }
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned prefix = s_prefix;
         unsigned valid = 0;
-        for (int64_t i0 = 0; i0 < M; i0 += TK_THREADS) {
-            const int64_t i = i0 + tid;
-            const unsigned u = i < M ? key_image(krow[i]) : 0u;
-            const bool cand = i < M && u > TK_NEGINF_IMAGE;        // -inf (and anything below) is never a candidate
-            const bool act = cand && (pass == 0 || (u >> (shift + 8)) == prefix);
-            hist_add(hist, (u >> shift) & 255u, act);
-            if (pass == 0) valid += __popcll(__ballot(cand));      // identical in every lane of the wave
+        for (int64_t i0 = s0; i0 < s1; i0 += 64 * TK_UNROLL) {
+            unsigned u[TK_UNROLL];
+#pragma unroll
+            for (int j = 0; j < TK_UNROLL; j++) {
+                const int64_t i = i0 + j * 64 + lane;
+                u[j] = i < s1 ? key_image(krow[i]) : 0u;           // 0 < TK_NEGINF_IMAGE: never a candidate
+            }
+#pragma unroll
+            for (int j = 0; j < TK_UNROLL; j++) {
+                const bool cand = u[j] > TK_NEGINF_IMAGE;          // -inf (and anything below) is never a candidate
+                const bool act = cand && (pass == 0 || (u[j] >> (shift + 8)) == prefix);
+                hist_add(hist, (u[j] >> shift) & 255u, act);
+                if (pass == 0) valid += __popcll(__ballot(cand));  // identical in every lane of the wave
+            }
         }
         if (pass == 0 && lane == 0) atomicAdd(&s_valid, valid);
         __syncthreads();
@@ -94,32 +107,50 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* __
     const unsigned T = s_prefix, take_eq = s_remaining;             // T: image of the K-th largest key; take_eq of the keys == T (lowest indices)
     const unsigned total = min((unsigned)K, s_valid);
     if (total) {
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int64_t i0 = 0; i0 < M; i0 += TK_THREADS) {
-            const int64_t i = i0 + tid;
-            const unsigned u = i < M ? key_image(krow[i]) : 0u;
-            const bool cand = i < M && u > TK_NEGINF_IMAGE;
-            const bool gt = cand && u > T, eq = cand && u == T;
-            const unsigned long long beq = __ballot(eq);
-            if (lane == 0) wave_a[wave] = (unsigned)__popcll(beq);
-            __syncthreads();
-            unsigned eq_before = s_run_eq + (unsigned)__popcll(beq & lt);
-            for (int w = 0; w < wave; w++) eq_before += wave_a[w];
-            const bool take = gt || (eq && eq_before < take_eq);
-            const unsigned long long bt = __ballot(take);
-            if (lane == 0) wave_b[wave] = (unsigned)__popcll(bt);
-            __syncthreads();
-            unsigned pos = s_run_sel + (unsigned)__popcll(bt & lt);
-            for (int w = 0; w < wave; w++) pos += wave_b[w];
-            if (take) crow[pos] = ((u64)u << 32) | (u64)(~(unsigned)i);
-            __syncthreads();
-            if (tid == 0) {
-                unsigned a = 0, t = 0;
-                for (int w = 0; w < 16; w++) { a += wave_a[w]; t += wave_b[w]; }
-                s_run_eq += a;
-                s_run_sel += t;
+        unsigned ngt = 0, neq = 0;                                  // counting sweep (wave-uniform)
+        for (int64_t i0 = s0; i0 < s1; i0 += 64 * TK_UNROLL) {
+            unsigned u[TK_UNROLL];
+#pragma unroll
+            for (int j = 0; j < TK_UNROLL; j++) {
+                const int64_t i = i0 + j * 64 + lane;
+                u[j] = i < s1 ? key_image(krow[i]) : 0u;
             }
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TK_UNROLL; j++) {
+                const bool cand = u[j] > TK_NEGINF_IMAGE;
+                ngt += (unsigned)__popcll(__ballot(cand && u[j] > T));
+                neq += (unsigned)__popcll(__ballot(cand && u[j] == T));
+            }
+        }
+        if (lane == 0) { wave_gt[wave] = ngt; wave_eq[wave] = neq; }
+        __syncthreads();
+        unsigned eq_seen = 0, pos = 0;                              // keys == T before this wave's segment / output slots before it
+        for (int w = 0; w < wave; w++) {
+            const unsigned e = wave_eq[w];
+            const unsigned te = eq_seen < take_eq ? min(e, take_eq - eq_seen) : 0u;
+            pos += wave_gt[w] + te;
+            eq_seen += e;
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int64_t i0 = s0; i0 < s1; i0 += 64 * TK_UNROLL) {      // writing sweep
+            unsigned u[TK_UNROLL];
+#pragma unroll
+            for (int j = 0; j < TK_UNROLL; j++) {
+                const int64_t i = i0 + j * 64 + lane;
+                u[j] = i < s1 ? key_image(krow[i]) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < TK_UNROLL; j++) {
+                const int64_t i = i0 + j * 64 + lane;
+                const bool cand = u[j] > TK_NEGINF_IMAGE;
+                const bool gt = cand && u[j] > T, eq = cand && u[j] == T;
+                const unsigned long long beq = __ballot(eq);
+                const bool take = gt || (eq && eq_seen + (unsigned)__popcll(beq & lt) < take_eq);
+                const unsigned long long bt = __ballot(take);
+                if (take) crow[pos + (unsigned)__popcll(bt & lt)] = ((u64)u[j] << 32) | (u64)(~(unsigned)i);
+                pos += (unsigned)__popcll(bt);
+                eq_seen += (unsigned)__popcll(beq);
+            }
         }
     }
     for (int i = (int)total + tid; i < P; i += TK_THREADS) crow[i] = 0ull;

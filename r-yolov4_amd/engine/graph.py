@@ -231,7 +231,9 @@ class Graph:
         if side_idx or fork:
             if self._side is None:
                 n = max(len(self.fwd), len(self.bwd)) + 1
-                self._side = (torch.cuda.Stream(device=self.dev), [torch.cuda.Event() for _ in range(2 * n)], torch.cuda.Event())
+                # the side STREAMS belong to the runtime (every plan of a model shares them: a second plan with streams of its own pushed
+                # the process past its hardware queues and the 8-image plan ran 1.8x slower behind the 64-image one); events per plan
+                self._side = (self.rt.side_stream(1), [torch.cuda.Event() for _ in range(2 * n)], torch.cuda.Event())
             side, evs, join = self._side
             n_ev = len(evs) // 2
             main = torch.cuda.current_stream(self.dev)
@@ -257,7 +259,7 @@ class Graph:
                     first, lane = ent
                     if lane == 2:                    # long independent tails (detection heads): their own stream, joined at the end
                         if self._side2 is None:
-                            self._side2 = (torch.cuda.Stream(device=self.dev), torch.cuda.Event())
+                            self._side2 = (self.rt.side_stream(2), torch.cuda.Event())
                         lane_stream = self._side2[0]
                         dirty2 = True
                     else:

@@ -25,6 +25,7 @@ class Runtime:
         self._packed = {}
         self._pack_table = None
         self._graphs = {}
+        self._side_streams = {}
         self.momentum_buf = None
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)       # source of padded rows for the LDS-DMA GEMM loop
         # bits 0-7: generic mainloop (1 LDS-DMA ring [default], 0 register staged);
@@ -48,6 +49,14 @@ class Runtime:
         # concatenated output channels: the input is read once instead of twice (forward and weight gradient) and its gradient is
         # written once instead of store + read-modify-write (Graph.conv_bn_act_group)
         self.merge_siblings = os.environ.get("RYOLO_MERGE_SIBLINGS", "1") != "0"
+
+    def side_stream(self, lane):
+        """The engine's extra HIP streams (lane 1: weight gradients / forked forward branches, lane 2: detection-head tails), created
+        once per model and shared by all of its plans."""
+        st = self._side_streams.get(lane)
+        if st is None:
+            st = self._side_streams[lane] = torch.cuda.Stream(device=self.device)
+        return st
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):

@@ -137,10 +137,57 @@ def diag_iou_rotated(boxes1, boxes2):
 
 
 # ------------------------------------------------------------------------------------------ post_process
+class PostProcessPlan:
+    """post_process (lib/general.py:136-183) for a FIXED shape [B, M, nc + 6] on static, worst-case sized buffers: six C-ABI launches
+    (score + filter, radix-select top-K, gather, NMS mask + on-device greedy reduce, emit), no allocation, no host read — the whole
+    sequence can be captured in a hipGraph behind the forward (Yolo.capture_inference(..., post=...), BASELINE config C5).
+    run(predictions) -> (out [B, max_det, 7] zero padded, num [B] int32 on the device)."""
+
+    def __init__(self, B, M, nc, device, conf_thres=0.5, iou_thres=0.4, gt_only=True):
+        self.B, self.M, self.nc, self.dev = B, M, nc, device
+        self.conf_thres, self.iou_thres, self.gt_only = float(conf_thres), float(iou_thres), bool(gt_only)
+        f32, i32 = torch.float32, torch.int32
+        self.K = K = min(M, MAX_NMS)
+        self.key = torch.empty((B, M), dtype=f32, device=device)
+        self.cls = torch.empty((B, M), dtype=f32, device=device)
+        self.count = torch.empty(B, dtype=i32, device=device)
+        need = hip._Z()
+        hip.call("ryolo_sort_workspace_bytes", B, K, need)
+        self.sort_ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=device)
+        self.skey = torch.empty((B, K), dtype=f32, device=device)
+        self.order = torch.empty((B, K), dtype=torch.int64, device=device)
+        self.dets = torch.empty((B, K, 7), dtype=f32, device=device)
+        self.rboxes = torch.empty((B, K, 5), dtype=f32, device=device)
+        hip.call("ryolo_nms_workspace_bytes", B, K, need)
+        self.nms_ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=device)
+        self.mk = max(min(MAX_DET, K), 1)
+        self.keep = torch.empty((B, self.mk), dtype=torch.int64, device=device)
+        self.num = torch.empty(B, dtype=i32, device=device)
+        self.out = torch.empty((B, self.mk, 7), dtype=f32, device=device)
+
+    def run(self, predictions):
+        B, M, nc, K, st = self.B, self.M, self.nc, self.K, hip.stream()
+        hip.call("ryolo_pp_score", hip.ptr(predictions), B, M, nc, self.conf_thres, hip.ptr(self.key), hip.ptr(self.cls), hip.ptr(self.count), st)
+        # the max_nms best candidates in (score desc, candidate index asc) order — the reference's argsort(descending=True)[:max_nms] at
+        # lib/general.py:166-168 leaves tie order undefined; SURVEY §7 fixes it.  Radix select + LDS sort on the device (csrc/topk.hip)
+        hip.call("ryolo_topk_desc", hip.ptr(self.key), B, M, K, hip.ptr(self.skey), hip.ptr(self.order), None, hip.ptr(self.sort_ws),
+                 self.sort_ws.numel(), st)
+        hip.call("ryolo_pp_gather", hip.ptr(predictions), hip.ptr(self.skey), hip.ptr(self.order), hip.ptr(self.cls), B, M, nc, K, K, MAX_WH,
+                 hip.ptr(self.dets), hip.ptr(self.rboxes), hip.ptr(self.count), st)
+        hip.call("ryolo_nms_rotated_batched", hip.ptr(self.rboxes), hip.ptr(self.count), B, K, self.iou_thres, 1 if self.gt_only else 0, self.mk,
+                 hip.ptr(self.nms_ws), self.nms_ws.numel(), hip.ptr(self.keep), self.mk, hip.ptr(self.num), st)
+        hip.call("ryolo_pp_emit", hip.ptr(self.dets), hip.ptr(self.keep), hip.ptr(self.num), B, K, self.mk, hip.ptr(self.out), st)
+        return self.out, self.num
+
+
+_pp_plans = {}
+
+
 def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
     """lib/general.py:136-183.  predictions [B, M, nc+6] (x,y,w,h,theta_rad,obj,cls...) on the HIP device;
     predictions[:, :, 6:] is multiplied by the objectness IN PLACE exactly like the reference (:155).
-    Returns a list of B tensors [n_i, 7] = (x, y, w, h, theta_rad, score, class)."""
+    Returns a list of B tensors [n_i, 7] = (x, y, w, h, theta_rad, score, class).  One device->host read (the per-image counts: the
+    list of variable-length tensors is the reference's return type); PostProcessPlan.run is the read-free form."""
     hip.require_device(predictions, "post_process")
     if predictions.dim() != 3 or predictions.shape[2] < 6:
         raise RuntimeError("post_process: predictions must be [B, M, nc+6]")
@@ -154,25 +201,16 @@ def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
         return []
     if M == 0 or nc == 0:
         return [empty] * B
-    st = hip.stream()
-    key = torch.empty((B, M), dtype=torch.float32, device=dev)
-    cls = torch.empty((B, M), dtype=torch.float32, device=dev)
-    count = torch.empty(B, dtype=torch.int32, device=dev)
-    hip.call("ryolo_pp_score", hip.ptr(predictions), B, M, nc, float(conf_thres), hip.ptr(key), hip.ptr(cls), hip.ptr(count), st)
-    # The max_nms best candidates in (score desc, candidate index asc) order — the reference's argsort(descending=True)[:max_nms] at
-    # lib/general.py:166-168 leaves tie order undefined; SURVEY §7 fixes it.  Radix select + LDS sort on the device (csrc/topk.hip).
-    K = min(M, MAX_NMS)
-    skey, order = topk_desc(key, K)
-    dets = torch.empty((B, K, 7), dtype=torch.float32, device=dev)
-    rboxes = torch.empty((B, K, 5), dtype=torch.float32, device=dev)
-    hip.call("ryolo_pp_gather", hip.ptr(predictions), hip.ptr(skey), hip.ptr(order), hip.ptr(cls), B, M, nc, K, K, MAX_WH,
-             hip.ptr(dets), hip.ptr(rboxes), hip.ptr(count), st)
-    keep, num = _nms_sorted_batched(rboxes, count, iou_thres, gt_only, MAX_DET)
-    ks = keep.shape[1]
-    out = torch.empty((B, ks, 7), dtype=torch.float32, device=dev)
-    hip.call("ryolo_pp_emit", hip.ptr(dets), hip.ptr(keep), hip.ptr(num), B, K, ks, hip.ptr(out), st)
+    key = (B, M, nc, dev.index)
+    plan = _pp_plans.get(key)
+    if plan is None:
+        if len(_pp_plans) > 8:
+            _pp_plans.clear()
+        plan = _pp_plans[key] = PostProcessPlan(B, M, nc, dev)
+    plan.conf_thres, plan.iou_thres, plan.gt_only = float(conf_thres), float(iou_thres), bool(gt_only)
+    out, num = plan.run(predictions)
     n_host = num.cpu().tolist()          # the single device->host read of the whole batch
-    return [out[b, :n] if n > 0 else empty for b, n in enumerate(n_host)]
+    return [out[b, :n].clone() if n > 0 else empty for b, n in enumerate(n_host)]
 
 
 # ------------------------------------------------------------------------------------------ polygon <-> rotated box

@@ -299,12 +299,15 @@ class Yolo(nn.Module):
         return self.yolo(list(outs), training)
 
 
-    def capture_inference(self, batch, size, device=None, static_weights=True):
+    def capture_inference(self, batch, size, device=None, static_weights=True, post=None):
         """hipGraph-captured inference (BASELINE config C5): the eval forward tape (≈330 C-ABI launches: folded BN + activation
         GEMMs, pooling, heads) and the YoloLayer decode are captured ONCE into a hipGraph on static buffers; the returned callable
         copies a batch into the static input and replays the graph — one host call instead of hundreds, which is what batch-1
         latency is made of.  Returns fn(imgs[B,3,S,S]) -> (head maps list, detections [B, rows, nc+6]); the outputs are the
-        graph's static buffers (valid until the next call).  post_process stays outside (its row counts are data dependent).
+        graph's static buffers (valid until the next call).
+        post = (conf_thres, iou_thres): post_process (score filter, radix-select top-K, rotated NMS with its on-device greedy reduce) is
+        captured in the SAME graph on worst-case sized buffers (lib.general.PostProcessPlan: no allocation, no host read); fn then
+        returns (head maps, detections, dets [B, max_det, 7] zero padded, num [B] int32 on the device).
         static_weights: the fp32 -> bf16 weight repack and the folded-BN coefficient kernels (weights-only work, ≈100 launches) are
         left out of the graph; re-capture after changing the weights."""
         if self.training:
@@ -321,16 +324,27 @@ class Yolo(nn.Module):
         graph = torch.cuda.CUDAGraph()
         g = self.runtime(dev).graph(batch, size, size, False)
         g.static_weights = static_weights                        # bf16 weight images and folded BN coefficients are already in place
+        plan = None
+        if post is not None:
+            from ..lib.general import PostProcessPlan
+            with torch.no_grad():
+                _, probe = self(static_in, False)
+            plan = PostProcessPlan(batch, probe.shape[1], probe.shape[2] - 6, dev, post[0], post[1])
+            plan.run(probe)                                      # warm-up outside the capture (lazy kernel attributes)
+            torch.cuda.synchronize(dev)
+        dets = num = None
         try:
             with torch.cuda.graph(graph), torch.no_grad():
                 heads, infer = self(static_in, False)
+                if plan is not None:
+                    dets, num = plan.run(infer)
         finally:
             g.static_weights = False
 
         def run(imgs):
             static_in.copy_(imgs)
             graph.replay()
-            return heads, infer
+            return (heads, infer) if plan is None else (heads, infer, dets, num)
         run.graph, run.static_input = graph, static_in
         return run
 

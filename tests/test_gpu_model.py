@@ -297,6 +297,32 @@ def test_captured_inference_replay_matches_eager():
 
 
 @pytest.mark.gpu
+def test_captured_inference_with_post_process_in_the_graph():
+    """BASELINE config C5: forward + decode + post_process (score filter, radix-select top-K, rotated NMS with the on-device greedy
+    reduce) captured in ONE hipGraph on worst-case buffers, counts left on the device: replays on new inputs give the eager
+    post_process result bit for bit (the eager path is checked against the oracle in test_gpu_postprocess.py)."""
+    import torch
+    from ryolov4_amd.lib.general import post_process
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, fill_state
+    m = Yolo(16, CFG, "kfiou", "yolov7")
+    m.load_state_dict(fill_state(m.state_dict()))
+    m.cuda().eval()
+    run = m.capture_inference(2, 128, post=(0.05, 0.4))
+    for seed in (3, 4):
+        x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(seed)).cuda()
+        with torch.no_grad():
+            _, inf = m(x, False)
+            want = post_process(inf.clone(), 0.05, 0.4)
+        _, _, dets, num = run(x)
+        n = num.cpu().tolist()
+        assert sum(n) > 0
+        for b in range(2):
+            assert n[b] == want[b].shape[0] and torch.equal(dets[b, :n[b]], want[b])
+            assert float(dets[b, n[b]:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
 def test_load_state_dict_after_first_forward_keeps_the_engine_in_sync():
     """Checkpoint loading AFTER the runtime exists (parameters are views of one flat buffer by then): load_state_dict copies in
     place, the next forward must see the new weights (bf16 images are repacked every forward) — same output as a fresh model."""

@@ -59,7 +59,22 @@ for B in [int(b) for b in os.environ.get("B", "1,8,64").split(",")]:
         _, got_inf = cap(imgs)
         assert torch.equal(ref_inf, got_inf), "graph replay differs from the eager forward"
     t_gf, t_ga = timed(gfwd, n), timed(gfull, n)
-    out[f"b{B}"] = {"fwd_ms": round(t_f, 3), "fwd_img_s": round(B / t_f * 1e3, 1), "fwd_pp_ms": round(t_a, 3),
+    # one live captured graph at a time: a second hipGraphExec of the same tape replays measurably slower while the first is alive
+    # (tools/diag_pp.py: 3.6 -> 5.5 ms at batch 1 — the graph's internal streams compete for the hardware queues)
+    del cap, got_inf
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    # forward + decode + post_process in ONE captured graph (worst-case buffers, counts stay on the device)
+    capp = model.capture_inference(B, SZ, post=(0.25, 0.45))
+    with torch.no_grad():
+        _, inf2 = model(imgs, training=False)
+        want = post_process(inf2.clone(), 0.25, 0.45)
+        _, _, dets, num = capp(imgs)
+        nh = num.cpu().tolist()
+        assert all(torch.equal(dets[b, :nh[b]], want[b]) for b in range(B)), "captured post_process differs from the eager one"
+    t_gp = timed(lambda: capp(imgs), n)
+    out[f"b{B}"] = {"graph_fwd_pp_captured_ms": round(t_gp, 3), "graph_fwd_pp_captured_img_s": round(B / t_gp * 1e3, 1),"fwd_ms": round(t_f, 3), "fwd_img_s": round(B / t_f * 1e3, 1), "fwd_pp_ms": round(t_a, 3),
                     "fwd_pp_img_s": round(B / t_a * 1e3, 1),
                     "graph_fwd_ms": round(t_gf, 3), "graph_fwd_img_s": round(B / t_gf * 1e3, 1), "graph_fwd_pp_ms": round(t_ga, 3),
                     "graph_fwd_pp_img_s": round(B / t_ga * 1e3, 1)}
