@@ -15,6 +15,7 @@ import ctypes as C
 import torch
 
 from .. import hip
+from . import arena
 from . import structs as S
 
 BF16 = torch.bfloat16
@@ -23,15 +24,33 @@ BF16 = torch.bfloat16
 class Buf:
     """[N*H*W, C] bf16 activation buffer (NHWC, channel stride = C) and, lazily, its gradient twin."""
 
-    def __init__(self, N, H, W, Cc, device):
+    def __init__(self, N, H, W, Cc, device, graph=None):
         self.N, self.H, self.W, self.C = N, H, W, Cc
-        self.t = torch.empty((N * H * W, Cc), dtype=BF16, device=device)
+        self.graph = graph
+        self.k = None
+        if graph is not None:        # member of a plan: dedicated memory, a virtual address (dry pass) or a slot of the plan's arena
+            self.k = graph._nbuf
+            graph._nbuf += 1
+        self.t = self._storage(0, device)
         self.g = None
         self.g_written = []          # channel ranges already written during the planned backward
 
+    def _storage(self, which, device):
+        g, shape = self.graph, (self.N * self.H * self.W, self.C)
+        nbytes = shape[0] * shape[1] * 2
+        if g is not None and g.dry:
+            v = g._virt[2 * self.k + which] = arena.Virt(2 * self.k + which, nbytes)
+            return v
+        if g is not None and g.layout is not None:
+            off = g.layout.off.get(2 * self.k + which)
+            if off is None or g.layout.sizes[2 * self.k + which] != nbytes:
+                raise RuntimeError("engine: the second planning pass asked for a buffer the liveness pass did not see")
+            return g.arena[off:off + nbytes].view(BF16).view(shape)
+        return torch.empty(shape, dtype=BF16, device=device)
+
     def grad_tensor(self):
         if self.g is None:
-            self.g = torch.empty_like(self.t)
+            self.g = self._storage(1, self.t.device if isinstance(self.t, torch.Tensor) else None)
         return self.g
 
 
@@ -89,11 +108,17 @@ def _fill_class(tc, taps, oh_add=0, ow_add=0):
 
 
 class Graph:
-    def __init__(self, rt, B, Hin, Win, training, frozen=False):
+    def __init__(self, rt, B, Hin, Win, training, frozen=False, dry=False, layout=None):
         self.rt, self.B, self.Hin, self.Win, self.training = rt, B, Hin, Win, training
+        # buffer placement (engine/arena.py): dry = liveness pass on virtual addresses; layout = its result, the buffers are slots of ONE arena
+        self.dry, self.layout = dry, layout
+        self._nbuf, self._virt, self._raw = 0, {}, {}
+        self.arena = torch.empty(layout.total, dtype=torch.uint8, device=rt.device) if layout is not None else None
+        self._done = None                      # completion events of the weight-gradient launches (bounded lag, see run())
         self.frozen = frozen                   # backward tape with eval-mode (running-statistics) BatchNorm
         self.batch_stats = training and not frozen
         self.dev = rt.device
+        self.adev = torch.device("meta") if dry else rt.device      # the dry pass allocates nothing: sizes and (null) addresses only
         self.fwd, self.bwd = [], []            # tapes: lists of (fn_name, args...) closures
         self.keep = []                         # tensors/structs kept alive
         self.side_idx = set()                  # backward-tape entries launched on the weight-gradient stream
@@ -103,7 +128,7 @@ class Graph:
         self._side = None                      # (stream, event pool)
         self._side2 = None                     # (stream, join event) of forward lane 2
         self.stream = None
-        self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.dev)   # staging of the input batch
+        self.img = torch.empty((B, 3, Hin, Win), dtype=torch.float32, device=self.adev)   # staging of the input batch
         self._img_slot, self._img_structs = None, []
         self.heads = []                        # per scale: dict(out=fp32 tensor, dout=fp32 tensor)
         self.debug = {}
@@ -117,12 +142,12 @@ class Graph:
 
     # ------------------------------------------------------------------ helpers
     def new(self, N, H, W, Cc):
-        b = Buf(N, H, W, Cc, self.dev)
+        b = Buf(N, H, W, Cc, self.dev, self)
         self.keep.append(b)
         return TRef(b)
 
     def f32(self, *shape, zero=False):
-        t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.dev)
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.adev)
         self.keep.append(t)
         return t
 
@@ -157,6 +182,8 @@ class Graph:
         self.keep.extend(a for a in args if isinstance(a, C.Structure))
         fn = getattr(hip.lib(), name)
         tape.append((fn, conv, name))
+        if self.dry:
+            self._raw[(id(tape), len(tape) - 1)] = args
         self.meta[(id(tape), len(tape) - 1)] = self._describe(name, args)
         if tape is self.bwd:
             # which bytes of the flat gradient buffer this launch writes (data-parallel overlap: a bucket is reduced as soon as
@@ -238,6 +265,12 @@ class Graph:
             n_ev = len(evs) // 2
             main = torch.cuda.current_stream(self.dev)
             sst = side.cuda_stream
+        lag = self.layout.lag if (side_idx is not None and self.layout is not None) else 0
+        if lag:
+            if self._done is None:
+                order = sorted(self.side_idx)
+                self._done = ({t: n for n, t in enumerate(order)}, [torch.cuda.Event() for _ in order])
+            wpos, done = self._done
         tid = id(tape)
         dirty, dirty2, pending, lane_stream = False, False, None, None
         for i, (fn, args, name) in enumerate(tape):
@@ -245,6 +278,10 @@ class Graph:
             if side_idx is not None:
                 on_side = i in side_idx
                 if on_side:                          # a weight gradient: its operands are final once everything before it ran
+                    if lag and wpos[i] >= lag:
+                        # bounded lag: weight gradient n - lag has finished before anything enqueued from here on starts — the arena
+                        # hands the memory of ITS operands to later launches on that promise (engine/arena.py)
+                        main.wait_event(done[wpos[i] - lag])
                     evs[i].record(main)
                     side.wait_event(evs[i])
                     dirty = True
@@ -283,6 +320,8 @@ class Graph:
                 rc = fn(*args, sst if on_side else st)
             if rc != 0:
                 raise RuntimeError(f"{name} failed with code {rc}")
+            if lag and on_side:
+                done[wpos[i]].record(side)
             if after:
                 cb = after.get(i)
                 if cb is not None:
@@ -404,7 +443,7 @@ class Graph:
         else:
             # a weight gradient that stays on the main stream (the im2col stem of yolov5) would race with the side-stream launches
             # on a shared workspace: it gets its own slabs
-            own = torch.empty(max(need.value, 16), dtype=torch.uint8, device=self.dev)
+            own = torch.empty(max(need.value, 16), dtype=torch.uint8, device=self.adev)
             self.keep.append(own)
             p.partial = own.data_ptr()
         self._call(self.bwd, "ryolo_conv_wgrad", p)
@@ -724,7 +763,7 @@ class Graph:
             for bn, c4 in ((bn_a, coa), (bn_b, cob)):
                 self._call(self.wprep, "ryolo_bn_eval_coeffs", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                            bn.running_var.data_ptr(), float(bn.eps), cout, c4.data_ptr())
-            wfold = torch.empty((cout, 9, cin), dtype=BF16, device=self.dev)
+            wfold = torch.empty((cout, 9, cin), dtype=BF16, device=self.adev)
             self.keep.append(wfold)
             self._call(self.wprep, "ryolo_repconv_fold", conv_a.weight.data_ptr(), conv_b.weight.data_ptr(), coa.data_ptr(), cob.data_ptr(),
                        cout, cin, wfold.data_ptr(), co.data_ptr())
@@ -775,7 +814,7 @@ class Graph:
         OH = (x.H + 2 * pad - k) // stride + 1
         OW = (x.W + 2 * pad - k) // stride + 1
         z = out if out is not None else self.new(x.N, OH, OW, x.C)
-        idx = torch.empty((x.N * OH * OW, x.C), dtype=torch.uint8, device=self.dev) if self.training else None
+        idx = torch.empty((x.N * OH * OW, x.C), dtype=torch.uint8, device=self.adev) if self.training else None
         self.keep.append(idx)
         p = S.PoolParams()
         p.x, p.ldx, p.z, p.ldz = x.ptr(), x.ld, z.ptr(), z.ld
@@ -783,9 +822,9 @@ class Graph:
         p.idx = idx.data_ptr() if idx is not None else None
         if stride == 1 and k >= 5:
             # SPP-style windows: separable row / column passes (scratch: row maxima; their argmax offsets are kept for backward)
-            rowmax = torch.empty((x.M, x.C), dtype=BF16, device=self.dev)
-            rowidx = torch.empty((x.M, x.C), dtype=torch.uint8, device=self.dev) if self.training else None
-            grow = torch.empty((x.M, x.C), dtype=torch.float32, device=self.dev) if self.training else None
+            rowmax = torch.empty((x.M, x.C), dtype=BF16, device=self.adev)
+            rowidx = torch.empty((x.M, x.C), dtype=torch.uint8, device=self.adev) if self.training else None
+            grow = torch.empty((x.M, x.C), dtype=torch.float32, device=self.adev) if self.training else None
             self.keep.extend([rowmax, rowidx, grow])
             p.rowmax = rowmax.data_ptr()
             p.rowidx = rowidx.data_ptr() if rowidx is not None else None
@@ -819,6 +858,16 @@ class Graph:
     def copy_slice(self, x, out):
         """Materialise an already-produced tensor into a concat slice (only needed when the producer could not be planned to
         write there directly).  Plumbing-level strided copy; gradient flows back by accumulation."""
+        if self.dry:                                 # liveness pass: the two uses, no torch views of virtual buffers
+            self.fwd.append((None, (), "copy_slice"))
+            self._raw[(id(self.fwd), len(self.fwd) - 1)] = (x.ptr(), out.ptr())
+            if self.training:
+                def backward():
+                    x.grad_write_mode()
+                    self.bwd.append((None, (), "copy_slice_bwd"))
+                    self._raw[(id(self.bwd), len(self.bwd) - 1)] = (x.gptr(), out.gptr())
+                self._pending_bwd.append(backward)
+            return out
         xs = x.buf.t[:, x.c0:x.c0 + x.C]
         os_ = out.buf.t[:, out.c0:out.c0 + out.C]
         self.fwd.append((lambda *_a: (os_.copy_(xs), 0)[1], (), "copy_slice"))
@@ -855,7 +904,7 @@ class Graph:
         if self.training:
             dout = self.f32(x.N, na, x.H, x.W, attrs)
             rec["dout"] = dout
-            dpre = torch.zeros((M, coutp), dtype=BF16, device=self.dev)       # pad columns stay zero
+            dpre = torch.zeros((M, coutp), dtype=BF16, device=self.adev)       # pad columns stay zero
             self.keep.append(dpre)
             nblk = x.N * ((x.H * x.W + 127) // 128)
             scratch = self.f32(max((nblk + 64) * 2 * cout, ((M + 1023) // 1024) * max(coutp, x.C)))
@@ -904,7 +953,7 @@ class Graph:
             emit()
         self._pending_bwd = None
         if self._wgrads:
-            ws = torch.empty(self._wgrad_ws_bytes, dtype=torch.uint8, device=self.dev)
+            ws = torch.empty(self._wgrad_ws_bytes, dtype=torch.uint8, device=self.adev)
             self.keep.append(ws)
             for p in self._wgrads:
                 p.partial = ws.data_ptr()

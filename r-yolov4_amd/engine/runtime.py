@@ -44,6 +44,9 @@ class Runtime:
         self.side_event = None            # set by Graph.run around a gradient-bucket hook: event of the weight-gradient stream
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
+        # activations and their gradients of a plan as liveness-placed slots of one arena (engine/arena.py); 0 = one tensor per buffer
+        self.buffer_reuse = os.environ.get("RYOLO_BUFFER_REUSE", "1") != "0"
+        self.wgrad_lag = int(os.environ.get("RYOLO_WGRAD_LAG", "8"))             # weight gradients the side stream may fall behind by
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
         # sibling convolutions of a block that read the same input (ELAN / CSP / C3 / SPPCSPC cv1 + cv2) as ONE GEMM with
         # concatenated output channels: the input is read once instead of twice (forward and weight gradient) and its gradient is
@@ -196,10 +199,22 @@ class Runtime:
         if g is None:
             if not self.check_resident():
                 raise RuntimeError("ryolov4_amd: parameters were moved after the first forward; build a new Yolo/runtime")
-            g = Graph(self, B, H, W, training, frozen)
+            layout = None
+            if self.buffer_reuse:
+                # liveness pass on virtual addresses, then the real plan on one arena (engine/arena.py)
+                from . import arena
+                dry = Graph(self, B, H, W, training, frozen, dry=True)
+                dry.begin()
+                self.model._emit(dry)
+                dry.finish()
+                layout = arena.plan(dry, self.wgrad_lag if self.wgrad_stream else 0)
+                del dry
+            g = Graph(self, B, H, W, training, frozen, layout=layout)
             g.begin()
             self.model._emit(g)
             g.finish()
+            if layout is not None and layout.names != ([e[2] for e in g.fwd], [e[2] for e in g.bwd]):
+                raise RuntimeError("engine: the two planning passes emitted different tapes")
             self._graphs[key] = g
         return g
 

@@ -135,3 +135,27 @@ def test_main_stream_wgrad_never_shares_the_split_k_workspace_with_the_side_stre
     assert side_ws and not (side_ws & main_ws)
     if ver == "yolov5":
         assert main_ws                                   # the 6x6 stride-2 stem goes through im2col + the generic wgrad on the main stream
+
+
+@pytest.mark.parametrize("ver", ["yolov7", "yolov4", "yolov5"])
+@pytest.mark.parametrize("training", [True, False])
+def test_arena_layout_is_conflict_free_and_small(ver, training):
+    """engine/arena.py: no two buffers whose lifetimes intersect share bytes; training plans need about half of the one-tensor-per-buffer
+    sum (the gradient twins ride in dead activations), inference plans a fifth; both planning passes emit the same tapes."""
+    from ryolov4_amd.engine import arena
+    m = Yolo(16, CFG, "kfiou", ver)
+    rt = Runtime(m, torch.device("cpu"))
+    g = rt.graph(2, 128, 128, training)
+    lay = g.layout
+    assert lay is not None and arena.check(lay)
+    assert lay.total <= (0.62 if training else 0.35) * lay.sum_bytes
+    assert g.arena.numel() == lay.total
+    rt2 = Runtime(m, torch.device("cpu"))
+    rt2.buffer_reuse = False
+    g2 = rt2.graph(2, 128, 128, training)
+    assert g2.layout is None and [e[2] for e in g2.fwd] == [e[2] for e in g.fwd] and [e[2] for e in g2.bwd] == [e[2] for e in g.bwd]
+    # a weight gradient's operands stay put until the main stream has waited for it: lifetimes of side-stream reads end at a later
+    # weight gradient's position, never before their own
+    F = len(g.fwd)
+    for k, (lo, hi) in lay.life.items():
+        assert 0 <= lo <= hi < F + len(g.bwd)
