@@ -401,6 +401,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         constexpr int RPI = 64 / CH;                           // rows per iteration
         const int ch = lane % CH, r0 = lane / CH;
         const int n = n0 + wn * WTN + ch * 8;
+        BsLane bsl;
+        if (p.nbstat) bs_lane_init(p, n, bsl);
         // fused MaxPool2d(2, 2) gradient: (image, row, column) of the tile's first pixel, rows inside the tile by small exact divisions
         int pl_img = 0, pl_oh = 0, pl_ow = 0;
         float pl_rOW = 0.f, pl_rOH = 0.f;
@@ -458,7 +460,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
             *reinterpret_cast<uint4*>(o) = v;
+            if (p.nbstat && bsl.y) bs_lane_row(bsl, pix, v);
         }
+        if (p.nbstat) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(smem), wave, r0, ch, tid, n0, mb);
 #ifdef GEMM_TIMING
         T3 = __builtin_readcyclecounter();
 #endif
@@ -860,6 +864,17 @@ static int gemm_check(const ConvGemmParams& p)
         return RY_ERR_ARG;
     if (!p.A || !p.W || !p.out || p.Cin <= 0 || p.Cin % BK || p.ldA % 8 || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4)
         return RY_ERR_ARG;
+    if (p.nbstat) {
+        if (p.nbstat < 0 || p.nbstat > RY_MAX_BSTAT || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.s2d_cin || p.nclasses != 1 || p.oh_mul != 1 ||
+            p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || p.cls[0].oh_add || p.cls[0].ow_add)
+            return RY_ERR_ARG;
+        for (int q = 0; q < p.nbstat; q++) {
+            const BwdStat& b = p.bstat[q];
+            if (!b.y || !b.co || !b.part || b.C <= 0 || (b.C & 7) || (b.n0 & 7) || (b.ldy & 7) || b.n0 < 0 || b.n0 + b.C > p.Nout ||
+                (reinterpret_cast<uintptr_t>(b.y) & 15))
+                return RY_ERR_ARG;
+        }
+    }
     return RY_OK;
 }
 

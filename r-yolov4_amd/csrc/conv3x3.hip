@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     const int ncol = n0 + wn * WTN + ch * 8;
     const int cq = lane & 15, rg = lane >> 4;                  // statistics: 4 channels x every 4th row per lane
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    BsLane bsl;
+    if (p.nbstat) bs_lane_init(p, ncol, bsl);
 #pragma unroll
     for (int half = 0; half < TM / 2; half++) {
 #pragma unroll
@@ -345,8 +347,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
             *reinterpret_cast<uint4*>(o) = v;
+            if (p.nbstat && bsl.y) bs_lane_row(bsl, pix, v);
         }
     }
+    if (p.nbstat) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(p3_lds), wave, r0, ch, tid, n0, mb);
     if (p.epi == EPI_STATS) {
         // every lane parks its 8 partial sums in LDS, one thread per column folds the 4 row groups x WM waves
         // (a shuffle tree here is 16 dependent ds_bpermute round trips, ~2 k cycles)

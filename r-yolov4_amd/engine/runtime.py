@@ -45,6 +45,10 @@ class Runtime:
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
         # activations and their gradients of a plan as liveness-placed slots of one arena (engine/arena.py); 0 = one tensor per buffer
+        # BatchNorm-backward reduce pass folded into the epilogue of the data-gradient launch that completes the activation gradient
+        self.fuse_bn_reduce = os.environ.get("RYOLO_FUSE_BN_REDUCE", "1") != "0"
+        self.fuse_bn_kernels = int(os.environ.get("RYOLO_FUSE_BN_KERNELS", "3"))      # bit 0: generic GEMM launches, bit 1: 3x3 halo-patch launches
+        self.fuse_bn_max_elems = int(float(os.environ.get("RYOLO_FUSE_BN_MAX_ELEMS", "32e6")))   # only launches with M * N up to this: the fold pays where the stand-alone reduce is latency-bound (A/B in DESIGN.md)
         self.buffer_reuse = os.environ.get("RYOLO_BUFFER_REUSE", "1") != "0"
         self.wgrad_lag = int(os.environ.get("RYOLO_WGRAD_LAG", "8"))             # weight gradients the side stream may fall behind by
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
@@ -199,17 +203,27 @@ class Runtime:
         if g is None:
             if not self.check_resident():
                 raise RuntimeError("ryolov4_amd: parameters were moved after the first forward; build a new Yolo/runtime")
+            last_writer = None
+            if training and self.fuse_bn_reduce:
+                # discovery pass: which launch completes the gradient of every Conv block's activation (it takes over the BatchNorm-
+                # backward reduce pass in its epilogue, ConvGemmParams.bstat)
+                disc = Graph(self, B, H, W, training, frozen, dry=True)
+                disc.begin()
+                self.model._emit(disc)
+                disc.finish()
+                last_writer = disc.last_writers()
+                del disc
             layout = None
             if self.buffer_reuse:
                 # liveness pass on virtual addresses, then the real plan on one arena (engine/arena.py)
                 from . import arena
-                dry = Graph(self, B, H, W, training, frozen, dry=True)
+                dry = Graph(self, B, H, W, training, frozen, dry=True, last_writer=last_writer)
                 dry.begin()
                 self.model._emit(dry)
                 dry.finish()
                 layout = arena.plan(dry, self.wgrad_lag if self.wgrad_stream else 0)
                 del dry
-            g = Graph(self, B, H, W, training, frozen, layout=layout)
+            g = Graph(self, B, H, W, training, frozen, layout=layout, last_writer=last_writer)
             g.begin()
             self.model._emit(g)
             g.finish()
