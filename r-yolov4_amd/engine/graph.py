@@ -142,7 +142,7 @@ class Graph:
         self.debug = {}
         self.meta = {}                         # (tape id, index) -> (kernel class, algorithmic flops)
         self.timer = None                      # set by bench.py: per-launch HIP-event timing of the conv kernels
-        self._wgrads, self._wgrad_ws_bytes = [], 0   # split-K workspace shared by the weight-gradient launches of ONE stream (see _emit_wgrad)
+        self._wgrads, self._wgrad_ws_bytes = {}, {}  # per lane: split-K workspace shared by the weight-gradient launches of ONE stream (see _emit_wgrad)
         self.grad_writes = []                  # (backward tape index, [element offsets into Runtime.gflat it writes])
         self.wprep = []                        # launches that depend on the weights only (eval-mode BN folding); run before fwd
         self._fork_open = False                # a side_branch() was emitted since the last join_side()
@@ -269,16 +269,21 @@ class Graph:
                 # the side STREAMS belong to the runtime (every plan of a model shares them: a second plan with streams of its own pushed
                 # the process past its hardware queues and the 8-image plan ran 1.8x slower behind the 64-image one); events per plan
                 self._side = (self.rt.side_stream(1), [torch.cuda.Event() for _ in range(2 * n)], torch.cuda.Event())
-            side, evs, join = self._side
+            side, evs, join = self._side[:3]
             n_ev = len(evs) // 2
             main = torch.cuda.current_stream(self.dev)
             sst = side.cuda_stream
         lag = self.layout.lag if (side_idx is not None and self.layout is not None) else 0
-        if lag:
+        if side_idx is not None:
             if self._done is None:
                 order = sorted(self.side_idx)
                 self._done = ({t: n for n, t in enumerate(order)}, [torch.cuda.Event() for _ in order])
             wpos, done = self._done
+            # weight gradient n runs on lane n % lanes: with small batches one weight-gradient kernel does not fill the GPU either
+            lanes = [side] + [self.rt.side_stream(2 + k) for k in range(1, max(1, self.rt.wgrad_lanes))]
+            if len(lanes) > 1 and len(self._side) == 3:
+                self._side = self._side + ([torch.cuda.Event() for _ in lanes],)
+            used = set()
         tid = id(tape)
         dirty, dirty2, pending, lane_stream = False, False, None, None
         for i, (fn, args, name) in enumerate(tape):
@@ -291,9 +296,11 @@ class Graph:
                         # hands the memory of ITS operands to later launches on that promise (engine/arena.py)
                         main.wait_event(done[wpos[i] - lag])
                     evs[i].record(main)
-                    side.wait_event(evs[i])
+                    lane_stream = lanes[wpos[i] % len(lanes)]
+                    lane_stream.wait_event(evs[i])
                     dirty = True
-                    lane_stream, sst = side, side.cuda_stream
+                    used.add(wpos[i] % len(lanes))
+                    sst = lane_stream.cuda_stream
             elif fork is not None:
                 if dirty and i in self.fwd_join:     # snapshot of the side stream at the join point (later forks are not waited for)
                     pending = evs[n_ev + i]
@@ -329,18 +336,26 @@ class Graph:
             if rc != 0:
                 raise RuntimeError(f"{name} failed with code {rc}")
             if lag and on_side:
-                done[wpos[i]].record(side)
+                done[wpos[i]].record(lane_stream)
             if after:
                 cb = after.get(i)
                 if cb is not None:
                     if dirty:
                         # the bucket may hold gradients written on the side stream: the hook's collective stream waits for this
                         # event as well (parallel._Reducer._launch); the main stream is NOT stalled
+                        if side_idx is not None and len(lanes) > 1:      # all weight-gradient lanes funnel into lane 0 first
+                            for k in sorted(used - {0}):
+                                self._side[3][k].record(lanes[k])
+                                side.wait_event(self._side[3][k])
                         join.record(side)
                         self.rt.side_event = join
                     cb()
                     self.rt.side_event = None
         if dirty:
+            if side_idx is not None and len(lanes) > 1:
+                for k in sorted(used - {0}):
+                    self._side[3][k].record(lanes[k])
+                    main.wait_event(self._side[3][k])
             join.record(side)
             main.wait_event(join)
         if dirty2:
@@ -492,9 +507,10 @@ class Graph:
         hip.call("ryolo_conv_wgrad_plan", p, sk, need)
         on_side = bool(side and self.rt.wgrad_stream)
         if on_side or not self.rt.wgrad_stream:
-            # launches of ONE stream are ordered, so they can share one split-K workspace
-            self._wgrad_ws_bytes = max(self._wgrad_ws_bytes, need.value)
-            self._wgrads.append(p)
+            # launches of ONE stream are ordered, so they can share one split-K workspace; side launch n runs on lane n % lanes (run())
+            lane = len(self.side_idx) % max(1, self.rt.wgrad_lanes) if on_side else 0
+            self._wgrad_ws_bytes[lane] = max(self._wgrad_ws_bytes.get(lane, 0), need.value)
+            self._wgrads.setdefault(lane, []).append(p)
         else:
             # a weight gradient that stays on the main stream (the im2col stem of yolov5) would race with the side-stream launches
             # on a shared workspace: it gets its own slabs
@@ -1014,8 +1030,8 @@ class Graph:
         for emit in reversed(self._pending_bwd):
             emit()
         self._pending_bwd = None
-        if self._wgrads:
-            ws = torch.empty(self._wgrad_ws_bytes, dtype=torch.uint8, device=self.adev)
+        for lane, plist in self._wgrads.items():
+            ws = torch.empty(self._wgrad_ws_bytes[lane], dtype=torch.uint8, device=self.adev)
             self.keep.append(ws)
-            for p in self._wgrads:
+            for p in plist:
                 p.partial = ws.data_ptr()

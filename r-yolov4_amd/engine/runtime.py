@@ -50,6 +50,7 @@ class Runtime:
         self.fuse_bn_kernels = int(os.environ.get("RYOLO_FUSE_BN_KERNELS", "3"))      # bit 0: generic GEMM launches, bit 1: 3x3 halo-patch launches
         self.fuse_bn_max_elems = int(float(os.environ.get("RYOLO_FUSE_BN_MAX_ELEMS", "32e6")))   # only launches with M * N up to this: the fold pays where the stand-alone reduce is latency-bound (A/B in DESIGN.md)
         self.buffer_reuse = os.environ.get("RYOLO_BUFFER_REUSE", "1") != "0"
+        self.wgrad_lanes = int(os.environ.get("RYOLO_WGRAD_LANES", "1"))          # weight gradients round-robin over this many side streams
         self.wgrad_lag = int(os.environ.get("RYOLO_WGRAD_LAG", "8"))             # weight gradients the side stream may fall behind by
         self.fold_repconv = os.environ.get("RYOLO_FOLD_REPCONV", "1") != "0"      # eval plans: RepConv as one re-parameterised 3x3 GEMM
         # sibling convolutions of a block that read the same input (ELAN / CSP / C3 / SPPCSPC cv1 + cv2) as ONE GEMM with
