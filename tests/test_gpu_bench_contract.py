@@ -37,7 +37,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["train_loss"]["finite"] is True
     # batch 2, all host threads — tried first; a host where that oversubscribes torch-CPU falls back and says so
     assert "batch 2" in cb["sample"] and cb["host_cpu_count"] == os.cpu_count()
-    assert cb["cores"] == os.cpu_count() or f"torch.set_num_threads({os.cpu_count()}) did not finish" in cb["sample"]
+    assert f"torch.set_num_threads({os.cpu_count()})" in cb["sample"]                    # the all-threads attempt is always made and reported
     # second regime in the same line: 8 images per GPU, with its own roofline
     b8 = d["b8"]
     assert b8["unit"] == "img/s" and b8["value"] > 0 and abs(b8["value"] - 8 / (b8["ms_per_step"] / 1e3)) < 1e-2 * b8["value"]

@@ -94,7 +94,6 @@ def test_end_to_end_loss_and_boxes_vs_fp32_oracle(cfg, ver, mode, nc, S, B):
     orc = ref_model.Yolo(nc, CFG, mode, ver)
     orc.load_state_dict(sd)
     orc.eval()
-    torch.set_num_threads(os.cpu_count() or 1)
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(8))
     tg = synth_targets(B, 16, nc, mode == "csl", seed=12, img_size=S)
     with torch.no_grad():

@@ -59,4 +59,3 @@ with torch.cuda.graph(g2):
 def two():
     cap(imgs); g2.replay()
 print("two graphs fwd, pp ms", timed(two))
-os.environ["RYOLO_NO_FORK"] = "1"
