@@ -1,0 +1,32 @@
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02m
+mkdir -p $O
+cd $R
+# 1. PMC traffic of the step (then the bench line reads it)
+timeout 1500 bash tools/pmc_step.sh r02 > $O/pmc_step.txt 2>&1
+cp gpurun_out/r02_pmc_step_traffic.json profiles/r02_pmc_step_traffic.json
+# 2. default bench line
+( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
+# 3. rocprofv3 kernel stats, serialized streams, b64 and b8
+cd /tmp; export TMPDIR=/tmp
+RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64 -o run -- python $R/bench.py --no-cpu-baseline --no-b8 --steps 8 > $O/prof_b64.json 2> $O/prof_b64.err
+RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b8 -o run -- python $R/bench.py --no-cpu-baseline --no-b8 --batch 8 --steps 20 > $O/prof_b8.json 2> $O/prof_b8.err
+cd $R
+# 4. per-launch tables
+B=64 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b64.txt 2>&1
+B=8 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b8.txt 2>&1
+# 5. NMS, inference
+timeout 600 python tools/time_nms.py > $O/nms.txt 2>&1; cp gpurun_out/nms_times.json $O/nms_times.json
+timeout 600 python tools/bench_infer.py > $O/infer.txt 2>&1; cp gpurun_out/infer.json $O/infer.json
+# 6. other configs + batch sweep
+for cfg in "yolov4 kfiou 608 2" "yolov7 csl 800 16" "yolov5 kfiou 800 16"; do set -- $cfg; timeout 300 python bench.py --ver $1 --mode $2 --size $3 --nc $4 --no-cpu-baseline --no-b8 --steps 8 > $O/cfg_$1_$2.json 2> $O/cfg_$1_$2.err; done
+for b in 96 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-b8 --no-kernel-timing --steps 8 > $O/batch$b.json 2> $O/batch$b.err; done
+# 7. overfit curves
+timeout 600 python tools/overfit_curve.py kfiou 300 > $O/overfit_kfiou.json 2> $O/overfit_kfiou.err
+timeout 600 python tools/overfit_curve.py csl 300 > $O/overfit_csl.json 2> $O/overfit_csl.err
+# 8. DP check: 2 ranks gloo on the one GPU, and 1 rank through RCCL
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py > $O/dp_check_gloo2.txt 2>&1
+BACKEND=nccl timeout 600 python tools/dp_check.py > $O/dp_check_rccl1.txt 2>&1
+ls -la $O
+tail -3 $O/pmc_step.txt; cat $O/bench_time.txt; tail -2 $O/dp_check_gloo2.txt $O/dp_check_rccl1.txt
