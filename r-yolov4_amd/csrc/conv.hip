@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 #define RY_STAGES 3
 #endif
 
-template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32>
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, bool BS = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -401,8 +401,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         constexpr int RPI = 64 / CH;                           // rows per iteration
         const int ch = lane % CH, r0 = lane / CH;
         const int n = n0 + wn * WTN + ch * 8;
+        // BS: the launch completes activation gradients (ConvGemmParams.bstat) — its own instantiation, so that the two-phase store loop's
+        // registers do not cost the plain kernels their third resident workgroup (164 -> 204 VGPRs when it was one kernel)
         BsLane bsl;
-        if (p.nbstat) bs_lane_init(p, n, bsl);
+        if constexpr (BS) bs_lane_init(p, n, bsl);
         // fused MaxPool2d(2, 2) gradient: (image, row, column) of the tile's first pixel, rows inside the tile by small exact divisions
         int pl_img = 0, pl_oh = 0, pl_ow = 0;
         float pl_rOW = 0.f, pl_rOH = 0.f;
@@ -415,54 +417,130 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             pl_rOW = 1.0f / (float)p.OW;
             pl_rOH = 1.0f / (float)p.OH;
         }
+        if constexpr (BS) {
+            // Two phases: every global load of the store loop (old value of an accumulate epilogue, BatchNorm input of a bstat lane) is
+            // issued before the first one is used — inside one loop with `continue` branches each iteration paid its own round trip.
+            constexpr int NIT = WTM / RPI, GRP = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);
+            const bool accum = p.epi == EPI_ACCUM, bs_on = p.nbstat && bsl.y;
+            const int n_s = n < p.Nout ? n : 0;
 #pragma unroll
-        for (int it = 0; it < WTM / RPI; it++) {
-            const int r = it * RPI + r0;
-            const int64_t m = m0 + wm * WTM + r;
-            if (m >= M || n >= p.Nout) continue;
-            const int64_t pix = out_pixel(m);
-            uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
-            bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
-            if (p.pool_idx) {
-                const int o_ = pl_ow + wm * WTM + r;
-                const int wr_ = small_div(o_, p.OW, pl_rOW);
-                const int ow_ = o_ - wr_ * p.OW, orow_ = pl_oh + wr_;
-                const int wi_ = small_div(orow_, p.OH, pl_rOH);
-                const int oh_ = orow_ - wi_ * p.OH;
-                const int64_t pp = ((int64_t)(pl_img + wi_) * (p.OH >> 1) + (oh_ >> 1)) * (p.OW >> 1) + (ow_ >> 1);
-                const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.pool_idx + pp * p.pool_ldi + n);
-                const uint4 gz = *reinterpret_cast<const uint4*>(p.pool_dz + pp * p.pool_ld + n);
-                const unsigned want = (unsigned)((oh_ & 1) * 2 + (ow_ & 1));
-                const unsigned* a = reinterpret_cast<const unsigned*>(&v);
-                const unsigned* b = reinterpret_cast<const unsigned*>(&gz);
-                unsigned w[4];
+            for (int g0 = 0; g0 < NIT; g0 += GRP) {
+                int64_t pixv[GRP];
+                bf16_t* ov[GRP];
+                bool lv[GRP];
+                uint4 oldv[GRP], yv[GRP];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float g0 = ((packed >> (16 * q)) & 0xff) == want ? __uint_as_float(b[q] << 16) : 0.f;
-                    const float g1 = ((packed >> (16 * q + 8)) & 0xff) == want ? __uint_as_float(b[q] & 0xffff0000u) : 0.f;
-                    w[q] = pack_bf2(__uint_as_float(a[q] << 16) + g0, __uint_as_float(a[q] & 0xffff0000u) + g1);
+                for (int k = 0; k < GRP; k++) {
+                    const int r = (g0 + k) * RPI + r0;
+                    const int64_t m = m0 + wm * WTM + r;
+                    lv[k] = m < M && n < p.Nout;
+                    const int64_t pix = out_pixel(lv[k] ? m : 0);
+                    pixv[k] = pix;
+                    bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n_s;
+                    if (p.s2d_cin) {                                   // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
+                        const int q = n_s / p.s2d_cin, ci = n_s - q * p.s2d_cin;
+                        o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
+                    }
+                    ov[k] = o;
                 }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            if (p.s2d_cin) {                                       // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
-                const int q = n / p.s2d_cin, ci = n - q * p.s2d_cin;
-                o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
-            }
-            if (p.epi == EPI_ACCUM) {
-                const uint4 old = *reinterpret_cast<const uint4*>(o);
-                const unsigned* a = reinterpret_cast<const unsigned*>(&v);
-                const unsigned* b = reinterpret_cast<const unsigned*>(&old);
-                unsigned w[4];
+                if (accum) {
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
-                                    __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                    for (int k = 0; k < GRP; k++) oldv[k] = *reinterpret_cast<const uint4*>(ov[k]);
+                }
+                if (bs_on) {
+#pragma unroll
+                    for (int k = 0; k < GRP; k++) yv[k] = bs_lane_load(bsl, pixv[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < GRP; k++) {
+                    if (!lv[k]) continue;
+                    const int r = (g0 + k) * RPI + r0;
+                    uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
+                    if (p.pool_idx) {
+                        const int o_ = pl_ow + wm * WTM + r;
+                        const int wr_ = small_div(o_, p.OW, pl_rOW);
+                        const int ow_ = o_ - wr_ * p.OW, orow_ = pl_oh + wr_;
+                        const int wi_ = small_div(orow_, p.OH, pl_rOH);
+                        const int oh_ = orow_ - wi_ * p.OH;
+                        const int64_t pp = ((int64_t)(pl_img + wi_) * (p.OH >> 1) + (oh_ >> 1)) * (p.OW >> 1) + (ow_ >> 1);
+                        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.pool_idx + pp * p.pool_ldi + n);
+                        const uint4 gz = *reinterpret_cast<const uint4*>(p.pool_dz + pp * p.pool_ld + n);
+                        const unsigned want = (unsigned)((oh_ & 1) * 2 + (ow_ & 1));
+                        const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                        const unsigned* b = reinterpret_cast<const unsigned*>(&gz);
+                        unsigned w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float g0_ = ((packed >> (16 * q)) & 0xff) == want ? __uint_as_float(b[q] << 16) : 0.f;
+                            const float g1_ = ((packed >> (16 * q + 8)) & 0xff) == want ? __uint_as_float(b[q] & 0xffff0000u) : 0.f;
+                            w[q] = pack_bf2(__uint_as_float(a[q] << 16) + g0_, __uint_as_float(a[q] & 0xffff0000u) + g1_);
+                        }
+                        v = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    if (accum) {
+                        const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                        const unsigned* b = reinterpret_cast<const unsigned*>(&oldv[k]);
+                        unsigned w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
+                                            __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
+                        v = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    *reinterpret_cast<uint4*>(ov[k]) = v;
+                    if (bs_on) bs_lane_row(bsl, yv[k], v);
+                }
+                __builtin_amdgcn_sched_barrier(0);                     // keep the next group's loads behind this group's stores (registers)
             }
-            *reinterpret_cast<uint4*>(o) = v;
-            if (p.nbstat && bsl.y) bs_lane_row(bsl, pix, v);
+        } else {
+#pragma unroll
+            for (int it = 0; it < WTM / RPI; it++) {
+                const int r = it * RPI + r0;
+                const int64_t m = m0 + wm * WTM + r;
+                if (m >= M || n >= p.Nout) continue;
+                const int64_t pix = out_pixel(m);
+                uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
+                bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
+                if (p.pool_idx) {
+                    const int o_ = pl_ow + wm * WTM + r;
+                    const int wr_ = small_div(o_, p.OW, pl_rOW);
+                    const int ow_ = o_ - wr_ * p.OW, orow_ = pl_oh + wr_;
+                    const int wi_ = small_div(orow_, p.OH, pl_rOH);
+                    const int oh_ = orow_ - wi_ * p.OH;
+                    const int64_t pp = ((int64_t)(pl_img + wi_) * (p.OH >> 1) + (oh_ >> 1)) * (p.OW >> 1) + (ow_ >> 1);
+                    const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(p.pool_idx + pp * p.pool_ldi + n);
+                    const uint4 gz = *reinterpret_cast<const uint4*>(p.pool_dz + pp * p.pool_ld + n);
+                    const unsigned want = (unsigned)((oh_ & 1) * 2 + (ow_ & 1));
+                    const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                    const unsigned* b = reinterpret_cast<const unsigned*>(&gz);
+                    unsigned w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float g0 = ((packed >> (16 * q)) & 0xff) == want ? __uint_as_float(b[q] << 16) : 0.f;
+                        const float g1 = ((packed >> (16 * q + 8)) & 0xff) == want ? __uint_as_float(b[q] & 0xffff0000u) : 0.f;
+                        w[q] = pack_bf2(__uint_as_float(a[q] << 16) + g0, __uint_as_float(a[q] & 0xffff0000u) + g1);
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                if (p.s2d_cin) {                                       // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
+                    const int q = n / p.s2d_cin, ci = n - q * p.s2d_cin;
+                    o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
+                }
+                if (p.epi == EPI_ACCUM) {
+                    const uint4 old = *reinterpret_cast<const uint4*>(o);
+                    const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                    const unsigned* b = reinterpret_cast<const unsigned*>(&old);
+                    unsigned w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
+                                        __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *reinterpret_cast<uint4*>(o) = v;
+            }
         }
-        if (p.nbstat) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(smem), wave, r0, ch, tid, n0, mb);
+        if constexpr (BS) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(smem), wave, r0, ch, tid, n0, mb);
 #ifdef GEMM_TIMING
         T3 = __builtin_readcyclecounter();
 #endif
@@ -811,7 +889,11 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    if (p.nbstat) {
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, true>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 

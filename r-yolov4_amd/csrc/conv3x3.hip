@@ -318,36 +318,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                 ssum[3] += f3; ssq[3] += f3 * f3;
             }
         }
+        // Store loop in two phases: every global load of the half (the old value of an accumulate epilogue, the BatchNorm input of a
+        // bstat lane) is issued before the first one is used.  With the loads inside one loop next to `continue` branches each of the
+        // 8 iterations paid its own memory round trip: +24 us on a 77 us launch for EPI_ACCUM, +40 us more with bstat (128->128 @50^2).
+        constexpr int NIT = 64 / RPI, GRP = 4;                          // 4 iterations in flight: more would cost a resident workgroup (VGPRs)
+        static_assert(NIT % GRP == 0, "store loop grouping");
+        const bool accum = p.epi == EPI_ACCUM, bs_on = p.nbstat && bsl.y;
+        const int ncol_s = ncol < p.Nout ? ncol : 0;
 #pragma unroll
-        for (int it = 0; it < 64 / RPI; it++) {
-            const int r = it * RPI + r0;
-            const int mrow = wm * WTM + half * 64 + r;
-            int64_t pix;
-            bool live;
-            if (g.mode == 1) {
-                const int rr = small_div(mrow, g.TW, g.rTW), c = mrow - rr * g.TW;
-                live = mrow < g.TH * g.TW;
-                pix = ((int64_t)img0 * H + oh0 + rr) * W + ow0 + c;
-            } else {
-                pix = p0 + mrow;
-                live = pix < M;
-            }
-            if (!live || ncol >= p.Nout) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
-            bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + ncol;
-            if (p.epi == EPI_ACCUM) {
-                const uint4 old = *reinterpret_cast<const uint4*>(o);
-                const unsigned* a = reinterpret_cast<const unsigned*>(&v);
-                const unsigned* b = reinterpret_cast<const unsigned*>(&old);
-                unsigned w[4];
+        for (int g0 = 0; g0 < NIT; g0 += GRP) {
+            int64_t pixv[GRP];
+            bool lv[GRP];
+            uint4 oldv[GRP], yv[GRP];
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
-                                    __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int k = 0; k < GRP; k++) {
+                const int r = (g0 + k) * RPI + r0;
+                const int mrow = wm * WTM + half * 64 + r;
+                int64_t pix;
+                bool live;
+                if (g.mode == 1) {
+                    const int rr = small_div(mrow, g.TW, g.rTW), c = mrow - rr * g.TW;
+                    live = mrow < g.TH * g.TW;
+                    pix = ((int64_t)img0 * H + oh0 + rr) * W + ow0 + c;
+                } else {
+                    pix = p0 + mrow;
+                    live = pix < M;
+                }
+                live = live && ncol < p.Nout;
+                lv[k] = live;
+                pixv[k] = live ? pix : 0;                               // dead rows read (and discard) pixel 0 of their own columns
             }
-            *reinterpret_cast<uint4*>(o) = v;
-            if (p.nbstat && bsl.y) bs_lane_row(bsl, pix, v);
+            if (accum) {
+#pragma unroll
+                for (int k = 0; k < GRP; k++)
+                    oldv[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.out) + pixv[k] * p.ldC + ncol_s);
+            }
+            if (bs_on) {
+#pragma unroll
+                for (int k = 0; k < GRP; k++) yv[k] = bs_lane_load(bsl, pixv[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < GRP; k++) {
+                if (!lv[k]) continue;
+                const int r = (g0 + k) * RPI + r0;
+                uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
+                bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pixv[k] * p.ldC + ncol;
+                if (accum) {
+                    const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+                    const unsigned* b = reinterpret_cast<const unsigned*>(&oldv[k]);
+                    unsigned w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        w[q] = pack_bf2(__uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16),
+                                        __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *reinterpret_cast<uint4*>(o) = v;
+                if (bs_on) bs_lane_row(bsl, yv[k], v);
+            }
         }
     }
     if (p.nbstat) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(p3_lds), wave, r0, ch, tid, n0, mb);

@@ -94,9 +94,9 @@ __device__ __forceinline__ void bs_lane_init(const ConvGemmParams& p, int n, BsL
         }
     }
 }
-__device__ __forceinline__ void bs_lane_row(BsLane& L, int64_t pix, const uint4& dz)
+__device__ __forceinline__ uint4 bs_lane_load(const BsLane& L, int64_t pix) { return *reinterpret_cast<const uint4*>(L.y + pix * L.ldy); }
+__device__ __forceinline__ void bs_lane_row(BsLane& L, const uint4& yv, const uint4& dz)
 {
-    const uint4 yv = *reinterpret_cast<const uint4*>(L.y + pix * L.ldy);
     const unsigned* a = reinterpret_cast<const unsigned*>(&dz);
     const unsigned* b = reinterpret_cast<const unsigned*>(&yv);
 #pragma unroll
