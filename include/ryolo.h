@@ -63,6 +63,19 @@ int ryolo_map_match(float* preds, const int64_t* pred_off, const float* targets,
                     int64_t ntgt, const float* iouv, int niou, int num_classes, unsigned char* tp, void* workspace, size_t workspace_bytes,
                     ryolo_stream_t stream);
 
+/* AP from the concatenated statistics (test.py:16-99 `ap_per_class` + `compute_ap`), on the device: confidence sort (score desc, index
+ * asc), per-class cumulative hits, recall = hits / (n_labels + 1e-16), precision = hits / rank, precision envelope, trapezoid over the
+ * 101-point recall grid for every IoU threshold, and precision / recall at the first threshold interpolated over `conf_grid` (the
+ * reference's 1000-point px) — numpy's float64 expressions restated (np.interp, pairwise-summed np.trapz).
+ * tp [n][niou] bytes, conf / pred_cls [n] fp32, target_cls [nl] fp32 (class ids: integers in [0, nc), nc <= 256), recall_grid [101] and
+ * conf_grid [nconf] float64 on the device (np.linspace values from the host).  Out, all classes 0 .. nc-1 (the caller keeps those with
+ * n_labels > 0, like np.unique(target_cls)): ap [nc][niou], prec_at / rec_at [nc][nconf] (zero rows for classes without labels or
+ * predictions), n_labels [nc], n_pred [nc].  No host synchronisation. */
+int ryolo_ap_workspace_bytes(int64_t n, int niou, int nc, size_t* bytes);
+int ryolo_ap_per_class(const unsigned char* tp, const float* conf, const float* pred_cls, int64_t n, const float* target_cls, int64_t nl,
+                       int nc, int niou, const double* recall_grid, const double* conf_grid, int nconf, void* workspace, size_t workspace_bytes,
+                       double* ap, double* prec_at, double* rec_at, int64_t* n_labels, int64_t* n_pred, ryolo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * YoloLayer — replaces model/yololayer.py:15-56 (YoloCSLLayer.forward) and :66-105 (YoloKFIoULayer.forward).
  * ------------------------------------------------------------------------------------------------------------ */

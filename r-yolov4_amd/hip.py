@@ -36,6 +36,8 @@ _SIGNATURES = {
     "ryolo_pp_emit": [_P, _P, _P, _I, _L, _L, _P, _P],
     "ryolo_map_match_workspace_bytes": [_L, _L, ctypes.POINTER(_Z)],
     "ryolo_map_match": [_P, _P, _P, _P, _I, _L, _L, _P, _I, _I, _P, _P, _Z, _P],
+    "ryolo_ap_workspace_bytes": [_L, _I, _I, ctypes.POINTER(_Z)],
+    "ryolo_ap_per_class": [_P, _P, _P, _L, _P, _L, _I, _I, _P, _P, _I, _P, _Z, _P, _P, _P, _P, _P, _P],
     "ryolo_to_tensor": [_P, _I, _I, _I, _P, _P, _P],
     "ryolo_encode_labels": [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P],
     "ryolo_polys_to_xywha": [_P, _L, _P, _P],

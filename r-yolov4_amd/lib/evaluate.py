@@ -2,9 +2,11 @@
 
 `get_batch_statistics` (test.py:102-149) — the per-image / per-class Python loops with a detectron2 `pairwise_iou_rotated`
 call and `.item()` syncs each — is ONE kernel launch for the batch (csrc/evaluate.hip) and one device->host read.
-`ap_per_class` / `compute_ap` / `calculate_eval_stats` (test.py:16-99,152-164) run once per evaluation on a few thousand rows:
-host-side numpy here as in the reference, same signatures and return values, written independently (class-grouped, all IoU
-thresholds at once) and bit-identical to the reference's numbers (fixture G8).
+`ap_per_class` / `compute_ap` / `calculate_eval_stats` (test.py:16-99,152-164): `calculate_eval_stats` runs the AP computation on the
+device (`ap_per_class_device` -> ryolo_ap_per_class: confidence sort, cumulative curves, envelope, 101-point integral, 1000-point
+precision / recall curves; numpy's float64 expressions restated, bit-identical on fixture G8); `ap_per_class` / `compute_ap` are the
+host-side numpy restatement with the reference's signatures and return values, written independently (class-grouped, all IoU
+thresholds at once) — what the CPU tests pin to the fixture and the device path is compared with.
 """
 import ctypes
 
@@ -124,12 +126,51 @@ def ap_per_class(tp, conf, pred_cls, target_cls):
     return prec_at[:, best], rec_at[:, best], ap, f1[:, best], classes.astype("int32")
 
 
-def calculate_eval_stats(stats, num_classes):
+def ap_per_class_device(tp, conf, pred_cls, target_cls, num_classes=None, device=None):
+    """ap_per_class with the sort, the cumulative curves, the envelope, the 101-point integral and the 1000-point precision / recall
+    curves computed on the HIP device (csrc/evaluate.hip: ryolo_ap_per_class); inputs numpy arrays or tensors as ap_per_class takes
+    them.  Only the O(classes x 1000) tail (F1, its mean over classes, the argmax) runs on the host.  Same return tuple.  Equal
+    confidences are ordered by index (np.argsort(-conf) leaves their order to the sort implementation)."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    tp_t = torch.as_tensor(np.ascontiguousarray(np.asarray(tp)).astype(np.uint8)).to(dev)
+    conf_t = torch.as_tensor(np.asarray(conf, dtype=np.float32)).to(dev).contiguous()
+    pcls_t = torch.as_tensor(np.asarray(pred_cls, dtype=np.float32)).to(dev).contiguous()
+    tcls_np = np.asarray(target_cls, dtype=np.float32)
+    tcls_t = torch.as_tensor(tcls_np).to(dev).contiguous()
+    n, niou = int(tp_t.shape[0]), int(tp_t.shape[1])
+    nc = int(num_classes) if num_classes else int(max(tcls_np.max(initial=0), np.asarray(pred_cls, dtype=np.float32).max(initial=0))) + 1
+    grid = torch.as_tensor(_RECALL_GRID).to(dev)
+    cgrid = torch.as_tensor(_CONF_GRID).to(dev)
+    need = hip._Z()
+    hip.call("ryolo_ap_workspace_bytes", n, niou, nc, need)
+    ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev)
+    ap = torch.empty((nc, niou), dtype=torch.float64, device=dev)
+    prec_at = torch.empty((nc, _CONF_GRID.size), dtype=torch.float64, device=dev)
+    rec_at = torch.empty_like(prec_at)
+    nlab = torch.empty(nc, dtype=torch.int64, device=dev)
+    npred = torch.empty(nc, dtype=torch.int64, device=dev)
+    hip.call("ryolo_ap_per_class", hip.ptr(tp_t) if n else None, hip.ptr(conf_t) if n else None, hip.ptr(pcls_t) if n else None, n,
+             hip.ptr(tcls_t) if tcls_t.numel() else None, int(tcls_t.numel()), nc, niou, hip.ptr(grid), hip.ptr(cgrid), int(_CONF_GRID.size),
+             hip.ptr(ws), ws.numel(), hip.ptr(ap), hip.ptr(prec_at), hip.ptr(rec_at), hip.ptr(nlab), hip.ptr(npred), hip.stream())
+    present = np.nonzero(nlab.cpu().numpy() > 0)[0]               # np.unique(target_cls): the classes that have labels
+    ap_h, p_h, r_h = ap.cpu().numpy()[present], prec_at.cpu().numpy()[present], rec_at.cpu().numpy()[present]
+    f1 = 2 * p_h * r_h / (p_h + r_h + 1e-16)
+    best = f1.mean(0).argmax()
+    return p_h[:, best], r_h[:, best], ap_h, f1[:, best], present.astype("int32")
+
+
+def calculate_eval_stats(stats, num_classes, host=False):
     """test.py:152-164: (nt, p, r, ap50, ap, f1, ap_class, mp, mr, map50, map) from the concatenated statistics; the all-zero
-    tuple (with nt = zeros(1)) when there is not a single true positive at the first threshold."""
+    tuple (with nt = zeros(1)) when there is not a single true positive at the first threshold.  The AP computation runs on the HIP
+    device (ap_per_class_device); host=True selects the numpy restatement above (what the CPU tests pin to the reference fixture)."""
     if not (len(stats) and stats[0].any()):
         return torch.zeros(1), 0.0, 0.0, [], [], 0.0, [], 0.0, 0.0, 0.0, 0.0
-    p, r, ap_all, f1, ap_class = ap_per_class(*stats)
+    if host:
+        p, r, ap_all, f1, ap_class = ap_per_class(*stats)
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("ryolov4_amd.lib.evaluate.calculate_eval_stats: no HIP device (pass host=True for the numpy restatement)")
+        p, r, ap_all, f1, ap_class = ap_per_class_device(*stats, num_classes=num_classes)
     ap50, ap = ap_all[:, 0], ap_all.mean(1)
     nt = np.bincount(stats[3].astype(np.int64), minlength=num_classes)
     return nt, p, r, ap50, ap, f1, ap_class, p.mean(), r.mean(), ap50.mean(), ap.mean()

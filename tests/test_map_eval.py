@@ -48,7 +48,7 @@ def test_ap_per_class_host_code(ci):
     p, r, ap, f1, cls = evaluate.ap_per_class(*cat)
     for got, name in ((p, "p"), (r, "r"), (ap, "ap"), (f1, "f1"), (cls, "cls")):
         assert np.array_equal(got, G8[f"c{ci}_{name}"]), name
-    res = evaluate.calculate_eval_stats(cat, 17)
+    res = evaluate.calculate_eval_stats(cat, 17, host=True)
     assert abs(res[-2] - G8[f"c{ci}_ap"][:, 0].mean()) < 1e-12 and abs(res[-1] - G8[f"c{ci}_ap"].mean(1).mean()) < 1e-12
 
 
@@ -97,3 +97,41 @@ def test_no_predictions_and_no_labels_anywhere():
     tg = torch.tensor([[1.0, 3.0, 10.0, 10.0, 4.0, 8.0, 0.1]])
     st = evaluate.get_batch_statistics(outs, tg, torch.linspace(0.5, 0.95, 10), 10)
     assert len(st) == 1 and st[0][0].shape == (0, 10) and st[0][3] == [3.0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(NCASES))
+def test_device_ap_equals_host_ap_on_the_fixture(ci):
+    """ryolo_ap_per_class (sort, curves, envelope, 101-point integral, 1000-point p / r curves on the device) against the fixture values
+    the imported reference produced: bit for bit."""
+    if f"c{ci}_ap" not in G8:
+        pytest.skip("no true positives in this case")
+    from ryolov4_amd.lib import evaluate
+    n = int(G8[f"c{ci}_nstats"])
+    cat = [np.concatenate([G8[f"c{ci}_{name}{k}"] for k in range(n)], 0) for name in ("tp", "conf", "pcls", "tcls")]
+    cat[0] = cat[0].astype(bool)
+    p, r, ap, f1, cls = evaluate.ap_per_class_device(*cat, num_classes=17)
+    for got, name in ((p, "p"), (r, "r"), (ap, "ap"), (f1, "f1"), (cls, "cls")):
+        assert np.array_equal(got, G8[f"c{ci}_{name}"]), (name, np.abs(np.asarray(got, dtype=np.float64) - G8[f"c{ci}_{name}"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nc,seed", [(20000, 16, 0), (3000, 3, 1), (1, 2, 2), (1025, 5, 3)])
+def test_device_ap_random_vs_host(n, nc, seed):
+    """Larger random statistics (several 1024-element scan chunks per class, classes without predictions or labels, distinct confidences
+    so that the sort order is defined): device == host numpy path, exactly."""
+    from ryolov4_amd.lib import evaluate
+    rng = np.random.RandomState(seed)
+    conf = rng.permutation(n).astype(np.float32) / np.float32(n) * np.float32(0.98) + np.float32(0.01)      # distinct
+    pcls = rng.randint(0, nc, n).astype(np.float32)
+    tp = rng.rand(n, 10) < (conf[:, None] * np.linspace(0.9, 0.2, 10)[None])
+    tp = np.logical_and.accumulate(tp, axis=1)                         # a TP at a higher threshold is a TP at the lower ones
+    tcls = rng.randint(0, nc, max(n // 2, 1)).astype(np.float32)
+    if nc > 2:
+        pcls[pcls == 1] = 0                                           # class 1: labels but no predictions
+        tcls = tcls[tcls != 2]                                        # class 2: predictions but no labels
+    hp, hr, hap, hf1, hcls = evaluate.ap_per_class(tp, conf, pcls, tcls)
+    dp, dr, dap, df1, dcls = evaluate.ap_per_class_device(tp, conf, pcls, tcls, num_classes=nc)
+    assert np.array_equal(hcls, dcls)
+    for a, b, name in ((hp, dp, "p"), (hr, dr, "r"), (hap, dap, "ap"), (hf1, df1, "f1")):
+        assert np.array_equal(a, b), (name, np.abs(a - b).max())
