@@ -55,9 +55,10 @@ def test_frozen_bn_only_the_bn_parameter_gradients_move_and_only_by_summation_or
 
 
 def test_batch_statistics_mode_fused_vs_unfused_on_the_first_layers():
-    """Train-mode BatchNorm: the sums enter dY of every layer.  Same inputs, fusion on / off: identical forward and loss; the gradients of
-    the LAST layers (nothing upstream of them has seen a fused sum yet... they see it first) agree to fp32 summation order amplified by
-    one bf16 rounding; the whole gradient vector stays within the run-to-run distance two different bf16 roundings would produce."""
+    """Train-mode BatchNorm: the sums steer dY of every layer.  Same inputs, fusion on / off: identical forward and loss; the gradients of
+    the layers next to the loss (at most a couple of folded BatchNorms between them and the head maps) agree to 2e-2 — fp32 summation
+    order seen through one bf16 rounding of dY — and the whole gradient vector stays finite and positively correlated (at random
+    initialisation ~100 batch-statistics BatchNorms amplify any rounding difference, see test_gpu_parity_e2e.py)."""
     ha, la, ga, _ = _grads("yolov7", "kfiou", True, False)
     hb, lb, gb, _ = _grads("yolov7", "kfiou", False, False)
     assert la == lb and all(torch.equal(x, y) for x, y in zip(ha, hb))

@@ -1,3 +1,5 @@
+# End-of-round evidence on ONE GPU box (run from the repo root through gpurun): PMC step traffic, default bench line, rocprofv3 kernel
+# stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/r02m/
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02m
@@ -29,4 +31,4 @@ timeout 600 python tools/overfit_curve.py csl 300 > $O/overfit_csl.json 2> $O/ov
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py > $O/dp_check_gloo2.txt 2>&1
 BACKEND=nccl timeout 600 python tools/dp_check.py > $O/dp_check_rccl1.txt 2>&1
 ls -la $O
-tail -3 $O/pmc_step.txt; cat $O/bench_time.txt; tail -2 $O/dp_check_gloo2.txt $O/dp_check_rccl1.txt
+tail -n 3 $O/pmc_step.txt; cat $O/bench_time.txt; tail -n 2 $O/dp_check_gloo2.txt; tail -n 2 $O/dp_check_rccl1.txt
