@@ -213,9 +213,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         int* taptab = reinterpret_cast<int*>(smem + (MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS));
         // constant tap index -> the bytes come from scalar dword loads of the kernarg segment; `tc.dh[tid]` made every thread fetch
         // its byte with a VMEM load and the workgroup wait a full memory round trip before its first DMA could be issued
+        // ... and ALL of them are requested before the first LDS write: scalar loads and LDS writes share one counter (lgkmcnt), so
+        // "load tap t, write tap t" in a loop made every tap wait for its own kernarg round trip — 5 000 of the 5 400 prologue cycles
+        // of a workgroup (cycle counters, tools/gemm_phases.py).  The 40-byte TapClass is fetched as ten dwords, bytes are cut out below.
+        static_assert(sizeof(TapClass) == 40 && offsetof(TapClass, dh) == 12 && offsetof(TapClass, dw) == 12 + RY_MAX_TAPS &&
+                      offsetof(TapClass, widx) == 12 + 2 * RY_MAX_TAPS, "TapClass layout");
+        const unsigned* tcw = reinterpret_cast<const unsigned*>(&tc);
+        unsigned tw[10];
 #pragma unroll
-        for (int t = 0; t < RY_MAX_TAPS; t++)
-            if (tid == t && t < tc.ntaps) taptab[t] = (tc.dh[t] & 0xff) | ((tc.dw[t] & 0xff) << 8) | ((tc.widx[t] & 0xff) << 16);
+        for (int i = 0; i < 10; i++) tw[i] = tcw[i];
+#pragma unroll
+        for (int t = 0; t < RY_MAX_TAPS; t++) {
+            const unsigned bdh = (tw[(12 + t) >> 2] >> (((12 + t) & 3) * 8)) & 0xffu;
+            const unsigned bdw = (tw[(21 + t) >> 2] >> (((21 + t) & 3) * 8)) & 0xffu;
+            const unsigned bwi = (tw[(30 + t) >> 2] >> (((30 + t) & 3) * 8)) & 0xffu;
+            if (tid == t && t < (int)tw[0]) taptab[t] = (int)(bdh | (bdw << 8) | (bwi << 16));
+        }
         __syncthreads();
         int is_t = 0, is_c0 = 0;                                  // (tap, channel chunk) of the next stage to issue
         int cur_dh = 0, cur_dw = 0;

@@ -98,9 +98,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
         b_ofs[u] = (n0 + r) < p.Nout ? (unsigned)((int64_t)(n0 + r) * p.wtaps * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8) : 0xffffffffu;
     }
     // ---- per-tap scalars through LDS (a VMEM kernarg byte load inside the loop would drain vmcnt) + the zero row ----------
+    // (all 27 kernarg dwords are requested before the first LDS write: scalar loads and LDS writes share the lgkmcnt counter, and
+    // "load tap t, write tap t" in one loop made every tap wait for its own kernarg round trip — see conv.hip)
+    int tapv[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) tapv[t] = ((g.tdh[t] + 1) * g.PW + (g.tdw[t] + 1)) | (g.twi[t] << 16);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 9; t++)
-        if (tid == t) tab[t] = ((g.tdh[t] + 1) * g.PW + (g.tdw[t] + 1)) | (g.twi[t] << 16);
+        if (tid == t) tab[t] = tapv[t];
     if (tid >= 64 && tid < 80) reinterpret_cast<unsigned*>(p3_lds + zrow_off)[tid - 64] = 0u;
     // ---- A fragment rows: patch row of output pixel m (tap (−1,−1)) and the 9-bit validity mask -----------------------------
     int run_oh = 0, run_ow = 0;
