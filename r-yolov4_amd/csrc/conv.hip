@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 #define RY_STAGES 3
 #endif
 
-template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, bool BS = false>
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -167,6 +167,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         // fragment reads is applied on the SOURCE side.  KB = 64 fetches whole 128-byte lines per pixel row (the KB = 32 gather
         // issues two 64-byte half-line requests per line and was L2/TA request-rate bound: ablation in profiles/ + DESIGN.md).
         //   KB = 32: 4 slots/row, phys = slot ^ ((row >> 2) & 3);   KB = 64: 8 slots/row, phys = slot ^ ((row >> 1) & 7)
+        // the tap class of this launch: 40 kernarg bytes as ten dwords, requested first so that their round trip overlaps the index math
+        const unsigned* tcw = reinterpret_cast<const unsigned*>(&tc);
+        unsigned tw[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) tw[i] = tcw[i];
         constexpr int SPR = KB / 8;                             // 16-byte slots per row
         constexpr int RPP = 64 / SPR;                           // rows per 1-KiB piece
         constexpr int STG = (BM + BN) * KB;                     // elements per stage
@@ -218,10 +223,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         // of a workgroup (cycle counters, tools/gemm_phases.py).  The 40-byte TapClass is fetched as ten dwords, bytes are cut out below.
         static_assert(sizeof(TapClass) == 40 && offsetof(TapClass, dh) == 12 && offsetof(TapClass, dw) == 12 + RY_MAX_TAPS &&
                       offsetof(TapClass, widx) == 12 + 2 * RY_MAX_TAPS, "TapClass layout");
-        const unsigned* tcw = reinterpret_cast<const unsigned*>(&tc);
-        unsigned tw[10];
-#pragma unroll
-        for (int i = 0; i < 10; i++) tw[i] = tcw[i];
 #pragma unroll
         for (int t = 0; t < RY_MAX_TAPS; t++) {
             const unsigned bdh = (tw[(12 + t) >> 2] >> (((12 + t) & 3) * 8)) & 0xffu;
@@ -414,8 +415,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         constexpr int RPI = 64 / CH;                           // rows per iteration
         const int ch = lane % CH, r0 = lane / CH;
         const int n = n0 + wn * WTN + ch * 8;
-        // BS: the launch completes activation gradients (ConvGemmParams.bstat) — its own instantiation, so that the two-phase store loop's
-        // registers do not cost the plain kernels their third resident workgroup (164 -> 204 VGPRs when it was one kernel)
+        // EP: 0 plain store loop; 1 accumulate epilogue (EPI_ACCUM); 2 the launch also completes activation gradients (ConvGemmParams.bstat).
+        // 1 and 2 use the two-phase loop below and are their own instantiations, so that its registers do not cost the plain kernels their
+        // third resident workgroup (164 -> 204 VGPRs when everything was one kernel)
+        constexpr bool BS = EP == 2;
         BsLane bsl;
         if constexpr (BS) bs_lane_init(p, n, bsl);
         // fused MaxPool2d(2, 2) gradient: (image, row, column) of the tile's first pixel, rows inside the tile by small exact divisions
@@ -430,11 +433,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             pl_rOW = 1.0f / (float)p.OW;
             pl_rOH = 1.0f / (float)p.OH;
         }
-        if constexpr (BS) {
+        if constexpr (EP != 0) {
             // Two phases: every global load of the store loop (old value of an accumulate epilogue, BatchNorm input of a bstat lane) is
             // issued before the first one is used — inside one loop with `continue` branches each iteration paid its own round trip.
             constexpr int NIT = WTM / RPI, GRP = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);
-            const bool accum = p.epi == EPI_ACCUM, bs_on = p.nbstat && bsl.y;
+            const bool accum = p.epi == EPI_ACCUM, bs_on = BS && p.nbstat && bsl.y;
             const int n_s = n < p.Nout ? n : 0;
 #pragma unroll
             for (int g0 = 0; g0 < NIT; g0 += GRP) {
@@ -903,7 +906,9 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
     if (p.nbstat) {
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, true>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    } else if (p.epi == EPI_ACCUM) {
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
     }
