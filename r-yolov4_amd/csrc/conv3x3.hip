@@ -73,6 +73,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     // ---- patch DMA sources -> LDS table ptab[u][tid]: piece (wave + 4u) = patch rows 16*piece ... +15, lane -> (row, slot) ---------
     // (element offset / 8 into A; ~0u -> zero page).  Kept in LDS, not in 9 VGPRs: the main loop stays rolled and lean.
     unsigned* const ptab = reinterpret_cast<unsigned*>(p3_lds + zrow_off + 128);
+    // output pixel of tile row m (-1: dead row), one entry per thread: the store loop of the epilogue reads it back instead of redoing the
+    // tile -> image index arithmetic for each of its 16 rows per lane (35 VALU instructions per row, a quarter of the store loop)
+    int* const rowpix = reinterpret_cast<int*>(p3_lds + zrow_off + 128 + (unsigned)g.TP * 1024u);
+    {
+        const int mrow = tid;
+        int64_t pix;
+        bool live;
+        if (g.mode == 1) {
+            const int rr = small_div(mrow, g.TW, g.rTW), c = mrow - rr * g.TW;
+            live = mrow < g.TH * g.TW;
+            pix = ((int64_t)img0 * H + oh0 + rr) * W + ow0 + c;
+        } else {
+            pix = p0 + mrow;
+            live = pix < M;
+        }
+        rowpix[mrow] = live ? (int)pix : -1;
+    }
     for (int u = 0; u < g.TP; u++) {
         const int pc = min(wave + 4 * u, g.P - 1);
         const int j = pc * 16 + (lane >> 2);
@@ -339,20 +356,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
             for (int k = 0; k < GRP; k++) {
                 const int r = (g0 + k) * RPI + r0;
-                const int mrow = wm * WTM + half * 64 + r;
-                int64_t pix;
-                bool live;
-                if (g.mode == 1) {
-                    const int rr = small_div(mrow, g.TW, g.rTW), c = mrow - rr * g.TW;
-                    live = mrow < g.TH * g.TW;
-                    pix = ((int64_t)img0 * H + oh0 + rr) * W + ow0 + c;
-                } else {
-                    pix = p0 + mrow;
-                    live = pix < M;
-                }
-                live = live && ncol < p.Nout;
+                const int pi = rowpix[wm * WTM + half * 64 + r];
+                const bool live = pi >= 0 && ncol < p.Nout;
                 lv[k] = live;
-                pixv[k] = live ? pix : 0;                               // dead rows read (and discard) pixel 0 of their own columns
+                pixv[k] = live ? (int64_t)pi : 0;                        // dead rows read (and discard) pixel 0 of their own columns
             }
             if (accum) {
 #pragma unroll
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
-static unsigned p3_lds_bytes(int P, int BN) { return 2u * P * 1024u + 3u * BN * 64u + 128u + (unsigned)ry_cdiv(P, 4) * 1024u; }
+static unsigned p3_lds_bytes(int P, int BN) { return 2u * P * 1024u + 3u * BN * 64u + 128u + (unsigned)ry_cdiv(P, 4) * 1024u + P3_BM * 4u; }
 
 bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
 {
