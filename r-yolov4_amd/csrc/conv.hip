@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 #define RY_STAGES 3
 #endif
 
-template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0>
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0, bool ID = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -349,9 +349,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     // The MFMAs ran with A = weights, B = pixels, so acc[i][j] is the TRANSPOSED 32x32 tile: column = lane & 31 = pixel
     // i*32 + (lane & 31), row = channel j*32 + (e & 3) + 8*(e >> 2) + 4*(lane >> 5).  A lane therefore owns 4 consecutive
     // channels of ONE pixel per register quad: one 8-byte LDS store (or one 16-byte fp32 store) instead of four 2-byte ones.
-    const bool identity = (p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && tc.oh_add == 0 && tc.ow_add == 0);
+    // ID: the launcher has checked that the output grid is the iteration grid and that neither the fused pool gradient nor the
+    // depth-to-space store is asked for — the common case (every forward launch, every stride-1 data gradient).  Its store loops carry no
+    // index arithmetic and none of the rare branches: in the one-size-fits-all loop every row iteration walked ~400 instructions of
+    // uniform branches, 64-bit divisions and waits (3 300 cycles per workgroup for eight 16-byte stores per lane).
+    const bool identity = ID || (p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && tc.oh_add == 0 && tc.ow_add == 0);
     const int h = lane >> 5;
     auto out_pixel = [&](int64_t m) -> int64_t {
+        if constexpr (ID) return m;
         if (identity) return m;
         const int img = (int)(m / ((int64_t)p.OH * p.OW));
         const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         // fused MaxPool2d(2, 2) gradient: (image, row, column) of the tile's first pixel, rows inside the tile by small exact divisions
         int pl_img = 0, pl_oh = 0, pl_ow = 0;
         float pl_rOW = 0.f, pl_rOH = 0.f;
-        if (p.pool_idx) {
+        if (!ID && p.pool_idx) {
             const int64_t HWo = (int64_t)p.OH * p.OW;
             pl_img = (int)(m0 / HWo);
             const int rem = (int)(m0 - (int64_t)pl_img * HWo);
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                     const int64_t pix = out_pixel(lv[k] ? m : 0);
                     pixv[k] = pix;
                     bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n_s;
-                    if (p.s2d_cin) {                                   // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
+                    if (!ID && p.s2d_cin) {                            // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
                         const int q = n_s / p.s2d_cin, ci = n_s - q * p.s2d_cin;
                         o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
                     }
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                     if (!lv[k]) continue;
                     const int r = (g0 + k) * RPI + r0;
                     uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
-                    if (p.pool_idx) {
+                    if (!ID && p.pool_idx) {
                         const int o_ = pl_ow + wm * WTM + r;
                         const int wr_ = small_div(o_, p.OW, pl_rOW);
                         const int ow_ = o_ - wr_ * p.OW, orow_ = pl_oh + wr_;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 const int64_t pix = out_pixel(m);
                 uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
-                if (p.pool_idx) {
+                if (!ID && p.pool_idx) {
                     const int o_ = pl_ow + wm * WTM + r;
                     const int wr_ = small_div(o_, p.OW, pl_rOW);
                     const int ow_ = o_ - wr_ * p.OW, orow_ = pl_oh + wr_;
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                     }
                     v = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                if (p.s2d_cin) {                                       // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
+                if (!ID && p.s2d_cin) {                                // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
                     const int q = n / p.s2d_cin, ci = n - q * p.s2d_cin;
                     o = reinterpret_cast<bf16_t*>(p.out) + (pix + (int64_t)(q >> 1) * p.OWf + (q & 1)) * p.ldC + ci;
                 }
@@ -905,12 +910,18 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
-    if (p.nbstat) {
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+    const dim3 grid((unsigned)(gm * gn), 1, p.nclasses);
+    const bool ident = p.nclasses == 1 && p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && p.cls[0].oh_add == 0 &&
+                       p.cls[0].ow_add == 0 && !p.pool_idx && !p.s2d_cin;
+    if (p.nbstat) {                                             // (identity grid by gemm_check; the pool gradient may ride along)
+        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, false>), grid, dim3(256), 0, stream, p);
     } else if (p.epi == EPI_ACCUM) {
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, false>), grid, dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB>), dim3((unsigned)(gm * gn), 1, p.nclasses), dim3(256), 0, stream, p);
+        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, false>), grid, dim3(256), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
