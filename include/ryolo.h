@@ -235,8 +235,9 @@ int ryolo_struct_sizes(int* sizes /* [11] */);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Loss — replaces ComputeCSLLoss.__call__/build_targets (lib/loss.py:191-331) and ComputeKFIoULoss (:368-492),
- * bbox_ciou (:36-78), KFLoss (:100-150).  Forward + gradient w.r.t. the head maps in one call; items[5] =
- * reg, conf, cls, theta, total (already scaled by the hyp gains).
+ * bbox_ciou (:36-78), KFLoss (:100-150).  Forward + gradient w.r.t. the head maps in one call; items[6] =
+ * reg, conf, cls, theta, total (already scaled by the hyp gains), and the number of target rows whose image index lies outside
+ * [0, batch) — the reference raises IndexError on those (lib/loss.py:209,385), this library skips them and reports the count.
  * ------------------------------------------------------------------------------------------------------------ */
 int ryolo_loss_workspace_bytes(const LossParams* p, size_t* bytes);
 int ryolo_loss(const LossParams* p, ryolo_stream_t stream);

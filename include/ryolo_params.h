@@ -156,7 +156,7 @@ typedef struct LossParams {
     float anchors[3][LOSS_MAX_NA][3];
     float box, obj, cls, theta_gain, obj_pw, cls_pw;
     void* ws; size_t ws_bytes;
-    float* items;             // [5] device: reg, conf, cls, theta, total
+    float* items;             // [6] device: reg, conf, cls, theta, total, number of target rows dropped because their image index is outside [0, batch)
     int compute_grad;
     float fl_gamma, fl_alpha; // FocalLoss (lib/loss.py:10-33) around every BCE term when fl_gamma > 0 (hyp['fl_gamma']); alpha = 0.25 in the reference
 } LossParams;

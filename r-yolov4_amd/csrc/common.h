@@ -17,6 +17,21 @@
 
 static inline int64_t ry_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: one flag word per (kernel, device), set with a relaxed
+// atomic so that two host threads racing through the first launch both end up with the attribute in place (the call is idempotent).
+#include <atomic>
+struct RyLdsAttr { std::atomic<unsigned long long> done{0}; };     // bit d = device d configured (devices >= 64: always re-set)
+static inline int ry_max_dynamic_lds(RyLdsAttr& st, const void* fn, int bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RY_ERR_LAUNCH;
+    const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (st.done.load(std::memory_order_acquire) & bit)) return RY_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return RY_ERR_LAUNCH;
+    if (bit) st.done.fetch_or(bit, std::memory_order_release);
+    return RY_OK;
+}
+
 // ---- bf16 <-> f32 (round-to-nearest-even), device side -------------------------------------------------
 #include "ryolo_params.h"   // bf16_t + POD parameter blocks
 

@@ -494,13 +494,8 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
 
 template <int BN, int WM, int WN> static int p3_launch_t(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return RY_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static RyLdsAttr attr;
+    if (ry_max_dynamic_lds(attr, reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN>), 160 * 1024)) return RY_ERR_LAUNCH;
     static const unsigned ldspad = getenv("RYOLO_P3_LDSPAD") ? (unsigned)atoi(getenv("RYOLO_P3_LDSPAD")) : 0u;   // occupancy experiments
     hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes + ldspad, stream, p, g);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
@@ -819,15 +814,10 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
 
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                hipSuccess)
-            return RY_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static RyLdsAttr attr_f, attr_t;
+    if (ry_max_dynamic_lds(attr_f, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<false>), 160 * 1024) ||
+        ry_max_dynamic_lds(attr_t, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<true>), 160 * 1024))
+        return RY_ERR_LAUNCH;
     const dim3 grid((unsigned)((int64_t)g.gx * g.gc * g.splitk));
     if (g.co64)
         hipLaunchKernelGGL((conv3x3_wgrad_kernel<true>), grid, dim3(256), g.lds_bytes, stream, p, g);

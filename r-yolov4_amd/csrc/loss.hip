@@ -569,11 +569,25 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossParams p, 
         }
         tot[1] += part[4] / (double)s.cells;
     }
+    // target rows whose image index is outside [0, batch): the reference raises IndexError at pi[b, ...] (lib/loss.py:209,385); the
+    // assignment kernels drop such rows instead of indexing out of bounds, and the count is reported so the host can raise
+    int bad = 0;
+    for (int t = threadIdx.x; t < p.nt; t += 256) {
+        const int tb = (int)p.targets[(int64_t)t * p.tcols];
+        bad += (tb < 0 || tb >= p.batch) ? 1 : 0;
+    }
+    red[threadIdx.x] = (double)bad;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const float reg = p.box * (float)tot[0], conf = p.obj * (float)tot[1], cls = p.cls * (float)tot[2],
                     th = p.theta_gain * (float)tot[3];
         p.items[0] = reg; p.items[1] = conf; p.items[2] = cls; p.items[3] = th;
         p.items[4] = reg + conf + cls + th;
+        p.items[5] = (float)red[0];
     }
 }
 

@@ -216,12 +216,8 @@ static int64_t tk_pow2(int64_t n) { int64_t p = 64; while (p < n) p <<= 1; retur
 
 static int tk_sort_rows(u64* comp, int rows, int64_t P, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bitonic_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_CHUNK * 8) != hipSuccess)
-            return RY_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static RyLdsAttr attr;
+    if (ry_max_dynamic_lds(attr, reinterpret_cast<const void*>(bitonic_local_kernel), TK_CHUNK * 8)) return RY_ERR_LAUNCH;
     const int chunk = (int)(P < TK_CHUNK ? P : TK_CHUNK);
     const unsigned nchunks = (unsigned)(P / chunk);
     hipLaunchKernelGGL(bitonic_local_kernel, dim3(nchunks, rows), dim3(TK_THREADS), (size_t)chunk * 8, stream, comp, P, chunk, (int64_t)2, (int64_t)chunk);

@@ -15,6 +15,8 @@ import torch
 
 from .. import hip
 
+MAP_MAX_CLASSES = 256      # csrc/evaluate.hip
+
 
 def get_batch_statistics(outputs, targets, iouv, niou):
     """Same contract as test.py:102: `outputs` = post_process result (list of [n_i, 7] score-descending tensors on the HIP
@@ -139,6 +141,11 @@ def ap_per_class_device(tp, conf, pred_cls, target_cls, num_classes=None, device
     tcls_t = torch.as_tensor(tcls_np).to(dev).contiguous()
     n, niou = int(tp_t.shape[0]), int(tp_t.shape[1])
     nc = int(num_classes) if num_classes else int(max(tcls_np.max(initial=0), np.asarray(pred_cls, dtype=np.float32).max(initial=0))) + 1
+    if nc > MAP_MAX_CLASSES:
+        raise RuntimeError(f"ap_per_class_device: {nc} classes > {MAP_MAX_CLASSES} (one workgroup per class, class table in LDS); use ap_per_class / host=True")
+    if tcls_np.size and (tcls_np.max() >= nc or tcls_np.min() < 0):
+        # the numpy path counts every label class it meets (np.unique); dropping out-of-range labels here would silently change nt / recall
+        raise ValueError(f"ap_per_class_device: target class outside [0, {nc})")
     grid = torch.as_tensor(_RECALL_GRID).to(dev)
     cgrid = torch.as_tensor(_CONF_GRID).to(dev)
     need = hip._Z()
@@ -162,7 +169,11 @@ def ap_per_class_device(tp, conf, pred_cls, target_cls, num_classes=None, device
 def calculate_eval_stats(stats, num_classes, host=False):
     """test.py:152-164: (nt, p, r, ap50, ap, f1, ap_class, mp, mr, map50, map) from the concatenated statistics; the all-zero
     tuple (with nt = zeros(1)) when there is not a single true positive at the first threshold.  The AP computation runs on the HIP
-    device (ap_per_class_device); host=True selects the numpy restatement above (what the CPU tests pin to the reference fixture)."""
+    device (ap_per_class_device); host=True selects the numpy restatement above (what the CPU tests pin to the reference fixture; also
+    the form for more than MAP_MAX_CLASSES classes).  There is no silent switch between the two: without a HIP device the default raises.
+    Tie rule of the device path: confidences are compared as fp32 and equal confidences keep ascending detection index, i.e. a STABLE
+    descending sort; the reference's np.argsort(-conf) (quicksort) leaves tie order unspecified, so with duplicated confidences the
+    numpy path may differ in the last digits while both are valid readings of test.py:38."""
     if not (len(stats) and stats[0].any()):
         return torch.zeros(1), 0.0, 0.0, [], [], 0.0, [], 0.0, 0.0, 0.0, 0.0
     if host:

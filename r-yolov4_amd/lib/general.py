@@ -165,22 +165,28 @@ class PostProcessPlan:
         self.num = torch.empty(B, dtype=i32, device=device)
         self.out = torch.empty((B, self.mk, 7), dtype=f32, device=device)
 
-    def run(self, predictions):
+    def run(self, predictions, conf_thres=None, iou_thres=None, gt_only=None):
+        """Thresholds default to the constructor's; per-call values do not touch the plan (a captured graph keeps what it was captured
+        with).  `predictions[:, :, 6:]` is multiplied by the objectness IN PLACE, as lib/general.py:155 does."""
         B, M, nc, K, st = self.B, self.M, self.nc, self.K, hip.stream()
-        hip.call("ryolo_pp_score", hip.ptr(predictions), B, M, nc, self.conf_thres, hip.ptr(self.key), hip.ptr(self.cls), hip.ptr(self.count), st)
+        conf = self.conf_thres if conf_thres is None else float(conf_thres)
+        iou = self.iou_thres if iou_thres is None else float(iou_thres)
+        gt = self.gt_only if gt_only is None else bool(gt_only)
+        hip.call("ryolo_pp_score", hip.ptr(predictions), B, M, nc, conf, hip.ptr(self.key), hip.ptr(self.cls), hip.ptr(self.count), st)
         # the max_nms best candidates in (score desc, candidate index asc) order — the reference's argsort(descending=True)[:max_nms] at
         # lib/general.py:166-168 leaves tie order undefined; SURVEY §7 fixes it.  Radix select + LDS sort on the device (csrc/topk.hip)
         hip.call("ryolo_topk_desc", hip.ptr(self.key), B, M, K, hip.ptr(self.skey), hip.ptr(self.order), None, hip.ptr(self.sort_ws),
                  self.sort_ws.numel(), st)
         hip.call("ryolo_pp_gather", hip.ptr(predictions), hip.ptr(self.skey), hip.ptr(self.order), hip.ptr(self.cls), B, M, nc, K, K, MAX_WH,
                  hip.ptr(self.dets), hip.ptr(self.rboxes), hip.ptr(self.count), st)
-        hip.call("ryolo_nms_rotated_batched", hip.ptr(self.rboxes), hip.ptr(self.count), B, K, self.iou_thres, 1 if self.gt_only else 0, self.mk,
+        hip.call("ryolo_nms_rotated_batched", hip.ptr(self.rboxes), hip.ptr(self.count), B, K, iou, 1 if gt else 0, self.mk,
                  hip.ptr(self.nms_ws), self.nms_ws.numel(), hip.ptr(self.keep), self.mk, hip.ptr(self.num), st)
         hip.call("ryolo_pp_emit", hip.ptr(self.dets), hip.ptr(self.keep), hip.ptr(self.num), B, K, self.mk, hip.ptr(self.out), st)
         return self.out, self.num
 
 
-_pp_plans = {}
+_pp_plans = {}      # (B, M, nc, device, stream, thread) -> PostProcessPlan, insertion order = least recently used first
+_PP_PLANS_MAX = 8
 
 
 def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
@@ -201,14 +207,19 @@ def post_process(predictions, conf_thres=0.5, iou_thres=0.4, gt_only=True):
         return []
     if M == 0 or nc == 0:
         return [empty] * B
-    key = (B, M, nc, dev.index)
-    plan = _pp_plans.get(key)
+    # the static buffers of a plan belong to ONE stream of ONE host thread: launches of the same shape from another stream or thread get
+    # their own plan instead of racing on key / dets / keep / out
+    import threading
+    key = (B, M, nc, dev.index, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
+    plan = _pp_plans.pop(key, None)
     if plan is None:
-        if len(_pp_plans) > 8:
-            _pp_plans.clear()
-        plan = _pp_plans[key] = PostProcessPlan(B, M, nc, dev)
-    plan.conf_thres, plan.iou_thres, plan.gt_only = float(conf_thres), float(iou_thres), bool(gt_only)
-    out, num = plan.run(predictions)
+        while len(_pp_plans) >= _PP_PLANS_MAX:
+            old_key = next(iter(_pp_plans))
+            torch.cuda.synchronize(torch.device("cuda", old_key[3]))    # launches still reading the evicted buffers finish first
+            del _pp_plans[old_key]
+        plan = PostProcessPlan(B, M, nc, dev)
+    _pp_plans[key] = plan                                                # most recently used last
+    out, num = plan.run(predictions, conf_thres, iou_thres, gt_only)
     n_host = num.cpu().tolist()          # the single device->host read of the whole batch
     return [out[b, :n].clone() if n > 0 else empty for b, n in enumerate(n_host)]
 

@@ -88,7 +88,7 @@ class _ComputeLossBase:
             outs.append(o.detach().float().contiguous())
         targets = targets.to(dev).float().contiguous()
         grads = [torch.empty_like(o) for o in outs] if compute_grad else [None] * 3
-        items = torch.empty(5, dtype=torch.float32, device=dev)
+        items = torch.empty(6, dtype=torch.float32, device=dev)     # reg, conf, cls, theta, total, dropped target rows
         p = self._params(outs, targets, compute_grad, grads)
         self._last_shape, self._last_gs = (p.nt, self.na, p.batch), [o.shape[2] for o in outs]
         need = S.Z()
@@ -126,8 +126,13 @@ class _ComputeLossBase:
             _, items = self._run(list(outputs), target, False)
             loss = items[4:5].clone()
         names = ("reg_loss", "conf_loss", "cls_loss", "theta_loss", "total_loss")
+        self.dropped_targets = items[5]                # device scalar: rows whose image index is outside [0, batch)
         if sync_items:
             vals = items.tolist()                      # the single device->host read of the step
+            if vals[5] > 0:
+                # the reference indexes pi[b, a, gj, gi] (lib/loss.py:209,385) and raises here; a collate / shard re-indexing bug must
+                # not train quietly on fewer labels
+                raise IndexError("loss: {} target row(s) carry an image index outside [0, {}) (targets[:, 0])".format(int(vals[5]), outputs[0].shape[0]))
             self.loss_items.update({k: vals[names.index(k)] for k in self.KEYS})
         else:
             self.loss_items.update({k: items[names.index(k)] for k in self.KEYS})

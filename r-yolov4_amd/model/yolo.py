@@ -307,7 +307,9 @@ class Yolo(nn.Module):
         graph's static buffers (valid until the next call).
         post = (conf_thres, iou_thres): post_process (score filter, radix-select top-K, rotated NMS with its on-device greedy reduce) is
         captured in the SAME graph on worst-case sized buffers (lib.general.PostProcessPlan: no allocation, no host read); fn then
-        returns (head maps, detections, dets [B, max_det, 7] zero padded, num [B] int32 on the device).
+        returns (head maps, detections, dets [B, max_det, 7] zero padded, num [B] int32 on the device).  As in the reference, whose
+        post_process multiplies predictions[:, :, 6:] by the objectness in place (lib/general.py:155), the `detections` buffer returned
+        WITH post holds class scores already multiplied by objectness — with post=None it holds the raw decode.
         static_weights: the fp32 -> bf16 weight repack and the folded-BN coefficient kernels (weights-only work, ≈100 launches) are
         left out of the graph; re-capture after changing the weights."""
         if self.training:

@@ -24,7 +24,8 @@ def main():
     from model.yolo import Yolo as RefYolo
     from lib import loss as rloss
     g10 = {"hyp_keys": np.array(sorted(HYP_FL)), "hyp_vals": np.array([HYP_FL[k] for k in sorted(HYP_FL)], np.float64)}
-    for mode, nc, (B, S, nt) in (("csl", 2, (2, 32, 12)), ("kfiou", 2, (2, 64, 12)), ("kfiou", 16, (2, 64, 24)), ("csl", 16, (1, 32, 0))):
+    for tag, mode, nc, (B, S, nt) in (("csl_nc2", "csl", 2, (2, 32, 12)), ("kfiou_nc2", "kfiou", 2, (2, 64, 12)), ("kfiou_nc16", "kfiou", 16, (2, 64, 24)),
+                                      ("csl_nc16", "csl", 16, (2, 64, 24)), ("csl_nc16_empty", "csl", 16, (1, 32, 0))):
         ref = RefYolo(nc, CFG, mode, "yolov4")
         L = (rloss.ComputeCSLLoss if mode == "csl" else rloss.ComputeKFIoULoss)(ref, HYP_FL)
         assert isinstance(L.BCEobj, rloss.FocalLoss) and isinstance(L.BCEcls, rloss.FocalLoss)
@@ -43,7 +44,8 @@ def main():
             assert abs(items[k] - float(items2[k])) < 2e-5 * max(1, abs(items[k])), (mode, k)
         for o, o2 in zip(outs, outs2):
             assert torch.allclose(o.grad, o2.grad, rtol=1e-4, atol=1e-7), (mode, (o.grad - o2.grad).abs().max())
-        tag = f"{mode}_nc{nc}"
+        if nt:      # every matched-target term must be live: a fixture whose targets match nothing pins only the objectness term
+            assert all(items[k] > 1e-3 for k in items), (tag, items)
         g10[f"{tag}_targets"] = tg.numpy()
         for i, o in enumerate(outs):
             g10[f"{tag}_out{i}"] = o.detach().numpy().astype(np.float16)

@@ -47,3 +47,37 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     for part in ("mask_reduce_ms", "end_to_end_ms"):
         assert set(nms[part]) == {"U_0.65", "U_0.2", "C_0.65", "C_0.2"} and all(v > 0 for v in nms[part].values())
     assert d["nms_ms_10k_boxes"] == nms["mask_reduce_ms"]["C_0.65"]
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` WITHOUT a launcher must re-exec under torch.distributed.run (never report a single rank as n_gpus 2):
+    two ranks over gloo on the one GPU of the test box, overlapped bucketed all-reduce of the flat gradient buffer, replicas compared
+    bit for bit after the steps (train.py:150-152,198-202)."""
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device", "--batch", "2", "--size", "256",
+                        "--steps", "2", "--warmup", "1", "--no-b8", "--no-kernel-timing"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert abs(d["value"] - 4 / (d["ms_per_step"] / 1e3)) < 1e-2 * d["value"]
+    di = d["distributed"]
+    assert di["world_size"] == 2 and di["ranks_in_allreduce"] == 2 and di["backend"] == "gloo" and di["replicas_bit_identical"] is True
+    tl = d["train_loss"]
+    assert tl["finite"] is True and tl["after_timed_steps"] < tl["first_step"]
+    assert "cpu_baseline" not in d                                     # rank 0 at N = 1 only
+
+
+def test_bench_gpus_n_without_enough_devices_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU node can run it")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 8" in (r.stderr + r.stdout) and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

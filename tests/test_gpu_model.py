@@ -167,13 +167,14 @@ def test_loss_golden(golden_dir, mode, nc):
         assert abs(it2["total_loss"] - items["total_loss"]) < 1e-6 * max(1.0, abs(items["total_loss"]))
 
 
-@pytest.mark.parametrize("mode,nc", [("csl", 2), ("kfiou", 2), ("kfiou", 16), ("csl", 16)])
-def test_focal_loss_golden(golden_dir, mode, nc):
+@pytest.mark.parametrize("tag", ["csl_nc2", "kfiou_nc2", "kfiou_nc16", "csl_nc16", "csl_nc16_empty"])
+def test_focal_loss_golden(golden_dir, tag):
     """hyp['fl_gamma'] > 0: FocalLoss (lib/loss.py:10-33) around the objectness / class / CSL-angle BCE terms, with non-unit pos_weights —
     loss items 1e-4 and logit gradients rtol 2e-3 against fixture G10 (the reference itself ran with fl_gamma = 1.5, obj_pw = 1.3,
     cls_pw = 0.8: tests/golden/make_golden_focal.py); the last case has no targets."""
     from ryolov4_amd.lib import loss as L
     g = np.load(os.path.join(golden_dir, "g10_focal.npz"))
+    mode, nc = tag.split("_")[0], int(tag.split("_")[1][2:])
     hyp = {str(k): float(v) for k, v in zip(g["hyp_keys"], g["hyp_vals"])}
     assert hyp["fl_gamma"] == 1.5
 
@@ -182,7 +183,6 @@ def test_focal_loss_golden(golden_dir, mode, nc):
     m = M()
     m.anchors, m.nc = ref_ops.make_anchors(CFG, mode), nc
     crit = (L.ComputeCSLLoss if mode == "csl" else L.ComputeKFIoULoss)(m, hyp)
-    tag = f"{mode}_nc{nc}"
     tg = torch.from_numpy(g[f"{tag}_targets"]).to(DEV)
     outs = [torch.from_numpy(g[f"{tag}_out{i}"].astype(np.float32)).to(DEV).requires_grad_() for i in range(3)]
     loss, items = crit(outs, tg)

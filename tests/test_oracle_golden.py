@@ -99,12 +99,12 @@ def test_g7_post_process(golden_dir):
             np.testing.assert_allclose(o.numpy(), exp, atol=1e-6)
 
 
-@pytest.mark.parametrize("mode,nc", [("csl", 2), ("kfiou", 2), ("kfiou", 16), ("csl", 16)])
-def test_g10_focal_loss(golden_dir, mode, nc):
+@pytest.mark.parametrize("tag", ["csl_nc2", "kfiou_nc2", "kfiou_nc16", "csl_nc16", "csl_nc16_empty"])
+def test_g10_focal_loss(golden_dir, tag):
     """Oracle with FocalLoss active + non-unit pos_weights against the fixture the imported reference produced (make_golden_focal.py)."""
     g = _load(golden_dir, "g10_focal.npz")
+    mode, nc = tag.split("_")[0], int(tag.split("_")[1][2:])
     hyp = {str(k): float(v) for k, v in zip(g["hyp_keys"], g["hyp_vals"])}
-    tag = f"{mode}_nc{nc}"
     tg = torch.from_numpy(g[f"{tag}_targets"])
     outs = [torch.from_numpy(g[f"{tag}_out{i}"].astype(np.float32)).requires_grad_() for i in range(3)]
     loss, items = ref_ops.compute_loss(outs, tg, ref_ops.make_anchors(CFG, mode), nc, mode, hyp)
