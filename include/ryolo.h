@@ -230,6 +230,19 @@ int ryolo_mixup_u8(const uint8_t* a, const uint8_t* b, double r, int64_t n, uint
  * (top, left) of the OH x OW canvas filled with `fill` */
 int ryolo_letterbox_u8(const uint8_t* src, int SH, int SW, int NH, int NW, int top, int left, uint8_t* dst, int OH, int OW, int fill,
                        ryolo_stream_t stream);
+/* load_image for a whole batch (datasets/base_dataset.py:170-186): `items` = device array of nitems records {int64 src_off, dst_off; int SH,
+ * SW, NH, NW, interp, lut} (ryolo_resize_item_bytes = sizeof): image at pool + src_off resized to NH x NW into stage + dst_off; interp
+ * 0 = cv2.INTER_LINEAR, 1 = cv2.INTER_AREA (downscaling, generic float form), 2 = copy; lut >= 0: hsv tables luts[lut][3][256] applied
+ * to the resized pixel (lib/augmentations.py:8-21).  max_pixels = largest NH * NW of the batch (grid size). */
+int ryolo_resize_item_bytes(int* bytes);
+int ryolo_resize_hsv_batch(const uint8_t* pool, const void* items_dev, int nitems, int64_t max_pixels, const uint8_t* luts, uint8_t* stage,
+                           ryolo_stream_t stream);
+/* label side of the sample composition for every label row of a batch, element-wise (load_target datasets/base_dataset.py:188-222, the
+ * mosaic-9 crop :318-330, the vertex warp lib/augmentations.py:67-74): `rows` = device array of LabelRow records (csrc/augment.hip;
+ * ryolo_label_row_bytes = sizeof), mats = 3x3 double matrices (row-major) indexed by LabelRow.mat; out [nrows][10] = (slot, class, 8
+ * vertex coordinates), NaN vertices for rows a filter dropped (ryolo_encode_labels then removes them, keeping the order). */
+int ryolo_label_row_bytes(int* bytes);
+int ryolo_label_stage(const void* rows_dev, int64_t nrows, const double* mats, float* out, ryolo_stream_t stream);
 
 int ryolo_struct_sizes(int* sizes /* [11] */);
 

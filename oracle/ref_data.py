@@ -209,13 +209,9 @@ def warp_perspective_numpy(src, M, dsize, border=114):
     return ((out + (1 << 14)) >> 15).astype(np.uint8)
 
 
-def hsv_gain_numpy(img, r):
-    """lib/augmentations.py:8-21 with cv2.cvtColor restated from OpenCV (8-bit BGR2HSV integer path with 12-bit division tables, HSV2BGR
-    through the float converter).  PARITY UNPINNED (OpenCV absent, version un-pinned)."""
-    x = np.arange(0, 256, dtype=np.float64)
-    lut_h = ((x * r[0]) % 180).astype(np.uint8)
-    lut_s = np.clip(x * r[1], 0, 255).astype(np.uint8)
-    lut_v = np.clip(x * r[2], 0, 255).astype(np.uint8)
+def bgr2hsv_numpy(img):
+    """cv2.cvtColor(img, COLOR_BGR2HSV) for uint8, restated from OpenCV (integer path, 12-bit division tables, hue range 180).
+    PARITY UNPINNED (OpenCV absent, version un-pinned)."""
     b, g, rr = [img[..., k].astype(np.int64) for k in range(3)]
     v = np.maximum(b, np.maximum(g, rr))
     vmin = np.minimum(b, np.minimum(g, rr))
@@ -228,7 +224,12 @@ def hsv_gain_numpy(img, r):
     h = (vr & (g - b)) + (~vr & ((vg & (b - rr + 2 * diff)) + ((~vg) & (rr - g + 4 * diff))))
     h = (h * hdiv + (1 << 11)) >> 12
     h = h + np.where(h < 0, 180, 0)
-    H, S, V = lut_h[h & 255].astype(np.float32), lut_s[s].astype(np.float32), lut_v[v].astype(np.float32)
+    return np.stack((h & 255, s, v), -1).astype(np.uint8)
+
+
+def hsv2bgr_numpy(hsv):
+    """cv2.cvtColor(hsv, COLOR_HSV2BGR) for uint8: OpenCV's float converter on h * 2 degrees / s, v scaled by 1 / 255.  PARITY UNPINNED."""
+    H, S, V = [hsv[..., k].astype(np.float32) for k in range(3)]
     hf, sf, vf = H * np.float32(6 / 180), S * np.float32(1 / 255), V * np.float32(1 / 255)
     hf = np.where(hf >= 6, hf - 6, hf)
     sec = np.floor(hf).astype(np.int64)
@@ -238,10 +239,63 @@ def hsv_gain_numpy(img, r):
     fr = np.where(bad, np.float32(0), fr)
     tab = np.stack((vf, vf * (1 - sf), vf * (1 - sf * fr), vf * (1 - sf * (1 - fr))), -1).astype(np.float32)
     sector = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
-    idx = sector[sec]
-    out = np.take_along_axis(tab, idx, -1)
+    out = np.take_along_axis(tab, sector[sec], -1)
     out = np.where((sf == 0)[..., None], vf[..., None], out)
     return np.clip(np.rint(out * np.float32(255)), 0, 255).astype(np.uint8)
+
+
+def hsv_gain_numpy(img, r):
+    """lib/augmentations.py:8-21 with cv2.cvtColor / cv2.LUT restated (bgr2hsv_numpy, hsv2bgr_numpy).  PARITY UNPINNED."""
+    x = np.arange(0, 256, dtype=np.float64)
+    lut_h = ((x * r[0]) % 180).astype(np.uint8)
+    lut_s = np.clip(x * r[1], 0, 255).astype(np.uint8)
+    lut_v = np.clip(x * r[2], 0, 255).astype(np.uint8)
+    hsv = bgr2hsv_numpy(img)
+    return hsv2bgr_numpy(np.stack((lut_h[hsv[..., 0]], lut_s[hsv[..., 1]], lut_v[hsv[..., 2]]), -1))
+
+
+def resize_area_numpy(src, dsize):
+    """cv2.resize(src, (w, h), interpolation = INTER_AREA) for uint8 DOWNSCALING, restated from OpenCV's generic cv::ResizeArea_: per
+    axis every destination cell covers [d * scale, (d + 1) * scale) of the source — a leading partial source cell, whole cells of
+    weight 1 / cellWidth, a trailing partial cell (weights in float); rows are accumulated horizontally, then vertically, in float;
+    cvRound at the end.  (OpenCV takes an integer fast path when both scale factors are whole numbers; its rounding can differ in
+    ties.)  PARITY UNPINNED (OpenCV absent, version un-pinned by the reference)."""
+    NW, NH = dsize
+    SH, SW = src.shape[:2]
+
+    def axis(dn, sn):
+        scale = sn / dn
+        tabs = []
+        for d in range(dn):
+            f1 = d * scale
+            f2 = f1 + scale
+            cell = min(scale, sn - f1)
+            s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+            s2 = min(s2, sn - 1)
+            s1 = min(s1, s2)
+            t = []
+            if s1 - f1 > 1e-3:
+                t.append((s1 - 1, np.float32((s1 - f1) / cell)))
+            t += [(sx, np.float32(1.0 / cell)) for sx in range(s1, s2)]
+            if f2 - s2 > 1e-3:
+                t.append((s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+            tabs.append(t)
+        return tabs
+    tx, ty = axis(NW, SW), axis(NH, SH)
+    s = src.astype(np.float32)
+    rows = np.zeros((SH, NW, 3), dtype=np.float32)
+    for dx, t in enumerate(tx):
+        acc = np.zeros((SH, 3), dtype=np.float32)
+        for sx, w in t:
+            acc = acc + s[:, sx] * w
+        rows[:, dx] = acc
+    out = np.zeros((NH, NW, 3), dtype=np.float32)
+    for dy, t in enumerate(ty):
+        acc = np.zeros((NW, 3), dtype=np.float32)
+        for sy, w in t:
+            acc = acc + w * rows[sy]
+        out[dy] = acc
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
 def resize_linear_numpy(src, dsize):

@@ -68,7 +68,7 @@ def install_dropin(detectron2=True):
     import importlib
     for alias, real in (("model", "ryolov4_amd.model"), ("model.yolo", "ryolov4_amd.model.yolo"),
                         ("lib", "ryolov4_amd.lib"), ("lib.loss", "ryolov4_amd.lib.loss"),
-                        ("lib.general", "ryolov4_amd.lib.general")):
+                        ("lib.general", "ryolov4_amd.lib.general"), ("lib.load", "ryolov4_amd.lib.load")):
         _sys.modules[alias] = importlib.import_module(real)
     if detectron2:
         _sys.modules.update(_detectron2_modules())

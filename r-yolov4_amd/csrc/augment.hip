@@ -180,6 +180,222 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     }
 }
 
+// ---- batched source-image stage of load_image (datasets/base_dataset.py:170-186): cv2.resize to (NW, NH) [+ hsv gain in place] for EVERY
+// source image a batch uses, one launch.  An item reads one image of the resident pool and writes its resized copy into a staging pool;
+// interp 0 = INTER_LINEAR (the 8-bit two-pass integer form of letterbox_kernel above), 1 = INTER_AREA (the float accumulation form of
+// cv::ResizeArea_: per axis a leading partial cell, whole cells of weight 1 / cellWidth, a trailing partial cell; weights and sums in
+// float, cvRound at the end), 2 = copy (r == 1: the reference skips cv2.resize).  lut >= 0: the three 256-entry tables of hsv() for this
+// image (lib/augmentations.py:8-21) are applied to the resized pixel before it is stored (resize, then hsv in place: same result).
+struct ResizeItem {
+    int64_t src_off, dst_off;    // byte offsets into the source pool / the staging pool
+    int SH, SW, NH, NW;
+    int interp, lut;
+};
+
+__device__ __forceinline__ void hsv_lut_pixel(int& b, int& g, int& r, const uint8_t* __restrict__ lut)
+{
+    int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int sdiv = v ? (int)rint((255 << 12) / (double)v) : 0;
+    const int hdiv = diff ? (int)rint((180 << 12) / (6.0 * diff)) : 0;
+    const int s = (diff * sdiv + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+    const int H = lut[h & 255], S = lut[256 + s], V = lut[512 + v];
+    float hf = (float)H * (6.f / 180.f), sf = (float)S * (1.f / 255.f), vf = (float)V * (1.f / 255.f);
+    float bb, gg, rr;
+    if (sf == 0.f) {
+        bb = gg = rr = vf;
+    } else {
+        static const int sector[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+        if (hf < 0.f) { do hf += 6.f; while (hf < 0.f); }
+        else if (hf >= 6.f) { do hf -= 6.f; while (hf >= 6.f); }
+        const int sec = (int)floorf(hf);
+        hf -= (float)sec;
+        const int sc = (unsigned)sec >= 6u ? 0 : sec;
+        if ((unsigned)sec >= 6u) hf = 0.f;
+        float tab[4];
+        tab[0] = vf;
+        tab[1] = vf * (1.f - sf);
+        tab[2] = vf * (1.f - sf * hf);
+        tab[3] = vf * (1.f - sf * (1.f - hf));
+        bb = tab[sector[sc][0]];
+        gg = tab[sector[sc][1]];
+        rr = tab[sector[sc][2]];
+    }
+    b = min(255, max(0, (int)rintf(bb * 255.f)));
+    g = min(255, max(0, (int)rintf(gg * 255.f)));
+    r = min(255, max(0, (int)rintf(rr * 255.f)));
+}
+
+// one axis of cv::computeResizeAreaTab for destination index d: source cells [s_lo, s_hi] with weights (first, 1/cell ..., last)
+struct AreaAxis { int lo, hi; float wlo, wmid, whi; bool has_lo, has_hi; };
+__device__ __forceinline__ AreaAxis area_axis(int d, int dn, int sn)
+{
+    const double scale = (double)sn / (double)dn;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)sn - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, sn - 1);
+    s1 = min(s1, s2);
+    AreaAxis a;
+    a.has_lo = s1 - f1 > 1e-3;
+    a.wlo = (float)((s1 - f1) / cell);
+    a.lo = s1;                                     // whole cells s1 .. s2 - 1; the leading partial cell is s1 - 1
+    a.hi = s2;
+    a.wmid = (float)(1.0 / cell);
+    a.has_hi = f2 - s2 > 1e-3;
+    a.whi = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+    return a;
+}
+
+__global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __restrict__ pool, const ResizeItem* __restrict__ items,
+                                                               const uint8_t* __restrict__ luts, uint8_t* __restrict__ stage)
+{
+    const ResizeItem it = items[blockIdx.y];
+    const int64_t npix = (int64_t)it.NH * it.NW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / it.NW), x = (int)(i - (int64_t)y * it.NW);
+        const uint8_t* src = pool + it.src_off;
+        int px[3];
+        if (it.interp == 2) {
+            const uint8_t* sp = src + ((int64_t)y * it.SW + x) * 3;
+            px[0] = sp[0]; px[1] = sp[1]; px[2] = sp[2];
+        } else if (it.interp == 0) {
+            auto coef = [](int o, int dn, int sn, int& s0, int& a0, int& a1) {
+                const double scale = (double)sn / (double)dn;
+                float f = (float)((o + 0.5) * scale - 0.5);
+                int si = (int)floorf(f);
+                f -= (float)si;
+                if (si < 0) { f = 0.f; si = 0; }
+                if (si >= sn - 1) { f = 0.f; si = sn - 1; }
+                s0 = si;
+                a0 = (int)rintf((1.f - f) * 2048.f);
+                a1 = (int)rintf(f * 2048.f);
+            };
+            int sx, ax0, ax1, sy, by0, by1;
+            coef(x, it.NW, it.SW, sx, ax0, ax1);
+            coef(y, it.NH, it.SH, sy, by0, by1);
+            const int sx1 = min(sx + 1, it.SW - 1), sy1 = min(sy + 1, it.SH - 1);
+            for (int c = 0; c < 3; c++) {
+                const int r0 = src[((int64_t)sy * it.SW + sx) * 3 + c] * ax0 + src[((int64_t)sy * it.SW + sx1) * 3 + c] * ax1;
+                const int r1 = src[((int64_t)sy1 * it.SW + sx) * 3 + c] * ax0 + src[((int64_t)sy1 * it.SW + sx1) * 3 + c] * ax1;
+                px[c] = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            }
+        } else {
+            const AreaAxis ax = area_axis(x, it.NW, it.SW), ay = area_axis(y, it.NH, it.SH);
+            float acc[3] = {0.f, 0.f, 0.f};
+            auto row = [&](int sy, float beta) {                  // horizontal pass of one source row into float, then * beta
+                float rsum[3] = {0.f, 0.f, 0.f};
+                const uint8_t* rp = src + (int64_t)sy * it.SW * 3;
+                if (ax.has_lo) for (int c = 0; c < 3; c++) rsum[c] += rp[(ax.lo - 1) * 3 + c] * ax.wlo;
+                for (int sx = ax.lo; sx < ax.hi; sx++) for (int c = 0; c < 3; c++) rsum[c] += rp[sx * 3 + c] * ax.wmid;
+                if (ax.has_hi) for (int c = 0; c < 3; c++) rsum[c] += rp[ax.hi * 3 + c] * ax.whi;
+                for (int c = 0; c < 3; c++) acc[c] += beta * rsum[c];
+            };
+            if (ay.has_lo) row(ay.lo - 1, ay.wlo);
+            for (int sy = ay.lo; sy < ay.hi; sy++) row(sy, ay.wmid);
+            if (ay.has_hi) row(ay.hi, ay.whi);
+            for (int c = 0; c < 3; c++) px[c] = min(255, max(0, (int)rintf(acc[c])));
+        }
+        if (it.lut >= 0) hsv_lut_pixel(px[0], px[1], px[2], luts + (int64_t)it.lut * 768);
+        uint8_t* d = stage + it.dst_off + i * 3;
+        d[0] = (uint8_t)px[0]; d[1] = (uint8_t)px[1]; d[2] = (uint8_t)px[2];
+    }
+}
+
+extern "C" int ryolo_resize_item_bytes(int* bytes) { if (!bytes) return RY_ERR_ARG; *bytes = (int)sizeof(ResizeItem); return RY_OK; }
+
+extern "C" int ryolo_resize_hsv_batch(const uint8_t* pool, const void* items_dev, int nitems, int64_t max_pixels, const uint8_t* luts, uint8_t* stage,
+                                      hipStream_t stream)
+{
+    if (nitems < 0 || max_pixels < 0) return RY_ERR_ARG;
+    if (nitems == 0 || max_pixels == 0) return RY_OK;
+    if (!pool || !items_dev || !stage || nitems > 65535) return RY_ERR_ARG;
+    const int64_t bx = ry_cdiv(max_pixels, 256);
+    hipLaunchKernelGGL(resize_hsv_batch_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)nitems), dim3(256), 0, stream, pool,
+                       reinterpret_cast<const ResizeItem*>(items_dev), luts, stage);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+// ---- label side of the sample composition (datasets/base_dataset.py:188-222 load_target, :318-330 the mosaic-9 crop, lib/augmentations.py:
+// 67-74 the warp of the vertices) for every label row a batch uses, one launch, element-wise: a row that a filter drops gets NaN vertices
+// and is removed — in order — by the compaction of ryolo_encode_labels (its bounds test is false for NaN), so the surviving rows keep
+// the reference's order without a scan here.  fp32 operations in the reference's order (-ffp-contract=off): x / w0, * w_, filter on
+// the mean vertex (strict), + pad; [crop filter, - crop origin]; [M (double 3x3) applied in double, stored as float].
+struct LabelRow {
+    float poly[8];               // as parsed from the label file
+    float cls;
+    int slot;                    // image slot of the batch (column 0 of the result)
+    float w0, h0;                // original image size; 0: labels are already normalised (normalized_labels)
+    float w1, h1;                // size after load_image's resize
+    float bx1, bx2, by1, by2;    // `boarder` of load_target (source-image coordinates); bx2 < 0: no filter
+    float padw, padh;
+    float cx1, cx2, cy1, cy2;    // mosaic-9 crop window on the 3s canvas; cx2 < 0: none.  The origin (cx1, cy1) is subtracted afterwards
+    int mat;                     // index into the warp matrices, -1: none
+};
+
+__global__ __launch_bounds__(256) void label_stage_kernel(const LabelRow* __restrict__ rows, int64_t n, const double* __restrict__ mats,
+                                                          float* __restrict__ out /*[n][10]*/)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const LabelRow r = rows[i];
+    float q[8];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        float x = r.poly[k], y = r.poly[k + 1];
+        if (r.w0 > 0.f) { x = x / r.w0; y = y / r.h0; }
+        q[k] = x * r.w1;
+        q[k + 1] = y * r.h1;
+    }
+    auto mean_ok = [&](float x1, float x2, float y1, float y2) {
+        const float mx = (((q[0] + q[2]) + q[4]) + q[6]) / 4.0f;
+        const float my = (((q[1] + q[3]) + q[5]) + q[7]) / 4.0f;
+        return (mx > x1) && (mx < x2) && (my > y1) && (my < y2);
+    };
+    if (r.bx2 >= 0.f) ok = mean_ok(r.bx1, r.bx2, r.by1, r.by2);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) { q[k] = q[k] + r.padw; q[k + 1] = q[k + 1] + r.padh; }
+    if (ok && r.cx2 >= 0.f) {
+        ok = mean_ok(r.cx1, r.cx2, r.cy1, r.cy2);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) { q[k] = q[k] - r.cx1; q[k + 1] = q[k + 1] - r.cy1; }
+    }
+    if (r.mat >= 0) {
+        const double* m = mats + (int64_t)r.mat * 9;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const double x = (double)q[k], y = (double)q[k + 1];
+            q[k] = (float)((m[0] * x + m[1] * y) + m[2]);
+            q[k + 1] = (float)((m[3] * x + m[4] * y) + m[5]);
+        }
+    }
+    float* o = out + i * 10;
+    o[0] = (float)r.slot;
+    o[1] = r.cls;
+    const float nanv = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[2 + k] = ok ? q[k] : nanv;
+}
+
+extern "C" int ryolo_label_row_bytes(int* bytes) { if (!bytes) return RY_ERR_ARG; *bytes = (int)sizeof(LabelRow); return RY_OK; }
+
+extern "C" int ryolo_label_stage(const void* rows_dev, int64_t nrows, const double* mats, float* out, hipStream_t stream)
+{
+    if (nrows < 0) return RY_ERR_ARG;
+    if (nrows == 0) return RY_OK;
+    if (!rows_dev || !out) return RY_ERR_ARG;
+    hipLaunchKernelGGL(label_stage_kernel, dim3((unsigned)ry_cdiv(nrows, 256)), dim3(256), 0, stream, reinterpret_cast<const LabelRow*>(rows_dev), nrows,
+                       mats, out);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
 extern "C" int ryolo_letterbox_u8(const uint8_t* src, int SH, int SW, int NH, int NW, int top, int left, uint8_t* dst, int OH, int OW, int fill,
                                   hipStream_t stream)
 {

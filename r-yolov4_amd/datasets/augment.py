@@ -1,26 +1,40 @@
-"""Device-side mosaic / warp / hsv / mixup of the reference's loader (datasets/base_dataset.py:83-128,170-330,
+"""Device-side sample composition of the reference's loader (datasets/base_dataset.py:83-128,170-330,
 lib/augmentations.py:8-74) over a uint8 image cache resident in HBM.
 
-Split of the work (as in the reference, but per batch instead of per sample and per worker process):
-  host     the random draws and the rectangle / label arithmetic — a few integers and a few dozen polygons per sample, kept in the
-           reference's exact order of operations (mosaic4_plan / mosaic9_plan / load_target / warp_matrix / warp_targets);
-  device   every pixel: paste (csrc/augment.hip paste_rects), perspective warp, hsv gain, mixup — then finalize_batch
-           (datasets/base_dataset.py of this package) turns the uint8 canvases into the fp32 training batch.
-Parity: plans, labels, paste and mixup are pinned to the imported reference (tests/golden/make_golden_aug.py ran the real
-load_mosaic / load_mosaic9 / load_target / mixup / random_warping label code); the pixels of warp and hsv restate OpenCV (absent
-here, version un-pinned by the reference): parity unpinned, checked against oracle/ref_data.py's numpy restatement only.
+The reference builds every training sample on a CPU worker with cv2.  Here nothing per pixel and nothing per label coordinate happens on
+the host: the host only draws the random numbers and turns them into small TABLES — which rectangle of which cached image lands where
+(placements), which 3x3 matrix a canvas is warped with, which parameters a label row is carried through — and the device applies them to
+the whole batch, one launch per stage (csrc/augment.hip):
+
+    resize_hsv_batch   load_image's cv2.resize + hsv for every source image a batch uses       (base_dataset.py:170-186)
+    paste_rects        mosaic-4 / mosaic-9 assembly (and the letterbox paste) from a rectangle table   (:224-330)
+    warp_perspective   random_warping's cv2.warpPerspective, one matrix per canvas               (lib/augmentations.py:45-65)
+    mixup              uint8(a r + b (1 - r))                                                    (lib/augmentations.py:24-28)
+    label_stage        load_target / mosaic crop / vertex warp of every label row, element-wise   (:188-222,318-330; :67-74)
+
+A mosaic placement is data, not code: image i of a 4-mosaic hangs on the mosaic centre by one of its corners (MOSAIC4_CORNER), image i
+of a 9-mosaic sits at an origin that is a fixed integer combination of the sizes of the first, the previous and the current image
+(MOSAIC9_ORIGIN); everything else — the clipped source rectangle, the label shift, the label filter window — follows from intersecting
+the placed rectangle with a window (`place`).
+
+Parity: placements, paste, mixup and labels are pinned to the imported reference (fixtures G11 / G13: the real load_mosaic /
+load_mosaic9 / load_target / mixup / random_warping / __getitem__ ran); the pixels of resize, warp and hsv restate OpenCV (absent here,
+version un-pinned by the reference): parity unpinned, checked against oracle/ref_data.py's numpy restatement only.
 """
 import ctypes
 import math
+from collections import namedtuple
 
 import numpy as np
 import torch
 
 from .. import hip
 
+_I, _L, _P = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+
 
 class ImagePool:
-    """uint8 HWC (BGR) images of different sizes packed into one device buffer (what cv2.imread + resize + hsv leave per file)."""
+    """uint8 HWC (BGR) images of different sizes packed into one device buffer (what cv2.imread leaves per file)."""
 
     def __init__(self, images, device):
         self.shapes = [tuple(im.shape[:2]) for im in images]
@@ -35,169 +49,205 @@ class ImagePool:
         self.buf = host.to(device)
 
 
-# ------------------------------------------------------------------------------------------------ plans (host integers)
-def mosaic4_plan(s, shapes, yc, xc):
-    """datasets/base_dataset.py:224-268: for the 4 (h, w) shapes -> [(x1a, y1a, x2a, y2a, x1b, y1b, x2b, y2b)] on the 2s x 2s canvas."""
-    out = []
-    for i, (h, w) in enumerate(shapes):
-        if i == 0:
-            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
-            x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
-        elif i == 1:
-            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s * 2), yc
-            x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
-        elif i == 2:
-            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s * 2, yc + h)
-            x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
-        else:
-            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
-            x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
-        out.append((x1a, y1a, x2a, y2a, x1b, y1b, x2b, y2b))
-    return out
+# ------------------------------------------------------------------------------------------------ placements (host integers)
+# 4-mosaic (base_dataset.py:224-268): quadrant i touches the centre (xc, yc) with the corner named here — (1, 1) = its bottom-right
+# corner, i.e. origin = centre - (w, h); (0, 0) = its top-left corner, origin = centre.
+MOSAIC4_CORNER = ((1, 1), (0, 1), (1, 0), (0, 0))
+# 9-mosaic (base_dataset.py:270-315): origin of image i on the 3s canvas = (s, s) + (ax . (w0, wp, w), ay . (h0, hp, h)) with
+# (w0, h0) the first, (wp, hp) the previous and (w, h) the current image: centre, top, top-right, right, bottom-right, bottom,
+# bottom-left, left, top-left — each image abuts the previous one.
+MOSAIC9_ORIGIN = (((0, 0, 0), (0, 0, 0)), ((0, 0, 0), (0, 0, -1)), ((0, 1, 0), (0, 0, -1)), ((1, 0, 0), (0, 0, 0)), ((1, 0, 0), (0, 1, 0)),
+                  ((1, 0, -1), (1, 0, 0)), ((1, -1, -1), (1, 0, 0)), ((0, 0, -1), (1, 0, -1)), ((0, 0, -1), (1, -1, -1)))
+
+Placed = namedtuple("Placed", "sx sy dx dy w h")        # canvas[dy:dy+h, dx:dx+w] = image[sy:sy+h, sx:sx+w]; w or h <= 0: nothing
 
 
-def mosaic9_plan(s, shapes):
-    """datasets/base_dataset.py:270-315: placement of the 9 images on the 3s x 3s canvas -> [(padx, pady, x1, y1, x2, y2)]."""
+def place(ox, oy, w, h, win):
+    """Image of size (w, h) with its top-left corner at (ox, oy); win = (x0, y0, x1, y1): the part inside the window, in source
+    coordinates and in coordinates relative to the window's origin."""
+    x0, y0 = max(ox, win[0]), max(oy, win[1])
+    x1, y1 = min(ox + w, win[2]), min(oy + h, win[3])
+    return Placed(x0 - ox, y0 - oy, x0 - win[0], y0 - win[1], x1 - x0, y1 - y0)
+
+
+def mosaic4_origins(shapes, yc, xc):
+    return [(xc - qx * w, yc - qy * h) for (h, w), (qx, qy) in zip(shapes, MOSAIC4_CORNER)]
+
+
+def mosaic9_origins(s, shapes):
     out = []
-    hp = wp = h_ = w_ = 0
-    for i, (h, w) in enumerate(shapes):
-        if i == 0:
-            h_, w_ = h, w
-            c = s, s, s + w, s + h
-        elif i == 1:
-            c = s, s - h, s + w, s
-        elif i == 2:
-            c = s + wp, s - h, s + wp + w, s
-        elif i == 3:
-            c = s + w_, s, s + w_ + w, s + h
-        elif i == 4:
-            c = s + w_, s + hp, s + w_ + w, s + hp + h
-        elif i == 5:
-            c = s + w_ - w, s + h_, s + w_, s + h_ + h
-        elif i == 6:
-            c = s + w_ - wp - w, s + h_, s + w_ - wp, s + h_ + h
-        elif i == 7:
-            c = s - w, s + h_ - h, s, s + h_
-        else:
-            c = s - w, s + h_ - hp - h, s, s + h_ - hp
-        padx, pady = c[:2]
-        x1, y1, x2, y2 = [max(x, 0) for x in c]
-        out.append((padx, pady, x1, y1, x2, y2))
+    (h0, w0), (hp, wp) = shapes[0], (0, 0)
+    for (h, w), (ax, ay) in zip(shapes, MOSAIC9_ORIGIN):
+        out.append((s + ax[0] * w0 + ax[1] * wp + ax[2] * w, s + ay[0] * h0 + ay[1] * hp + ay[2] * h))
         hp, wp = h, w
     return out
 
 
-def filtering(targets, boarder):
-    """datasets/base_dataset.py:332-345 (strict inequalities on the mean vertex)."""
-    x1, x2, y1, y2 = boarder
-    x = torch.mean(targets[:, [2, 4, 6, 8]], dim=1)
-    y = torch.mean(targets[:, [3, 5, 7, 9]], dim=1)
-    return targets[(x > x1) & (x < x2) & (y > y1) & (y < y2)]
+# one source image placed on a canvas: paste rectangle + what its label rows need (load_target's pad and `boarder`, the crop window)
+Use = namedtuple("Use", "img rect pad border crop")
 
 
-def load_target(polys, labels, pad, img_size0, img_size, normalized_labels, boarder=None):
-    """datasets/base_dataset.py:188-222 after the label file was parsed: polys [n, 8] float32 (modified in place like the
-    reference's), labels [n] -> targets [m, 10] in canvas pixels."""
-    if not len(labels):
-        return torch.zeros((0, 10))
-    if not normalized_labels:
-        h0, w0 = img_size0
-        polys[:, [0, 2, 4, 6]] /= w0
-        polys[:, [1, 3, 5, 7]] /= h0
-    h_, w_ = img_size
-    polys[:, [0, 2, 4, 6]] *= w_
-    polys[:, [1, 3, 5, 7]] *= h_
-    targets = torch.zeros((len(labels), 10))
-    targets[:, 1:] = torch.cat((labels.unsqueeze(-1), polys), -1)
-    if boarder is not None:
-        targets = filtering(targets, boarder)
-    targets[:, [2, 4, 6, 8]] += pad[1]
-    targets[:, [3, 5, 7, 9]] += pad[0]
-    return targets
+def mosaic4_uses(shapes, indices, s, yc, xc):
+    """4 images around (xc, yc) on the 2s x 2s canvas.  Labels: shifted by the image origin, kept when their mean vertex lies strictly
+    inside the visible source rectangle (base_dataset.py:262-264)."""
+    uses = []
+    for img, (h, w), (ox, oy) in zip(indices, shapes, mosaic4_origins(shapes, yc, xc)):
+        r = place(ox, oy, w, h, (0, 0, 2 * s, 2 * s))
+        uses.append(Use(img, r, (oy, ox), (r.sx, r.sx + r.w, r.sy, r.sy + r.h), None))
+    return uses
+
+
+def mosaic9_uses(shapes, indices, s, yc, xc):
+    """9 images on the 3s x 3s canvas, of which the window [xc, xc + 2s) x [yc, yc + 2s) is kept (base_dataset.py:270-330): the crop is
+    folded into the paste coordinates; labels are filtered against the source rectangle left of / above which the canvas clipped the
+    image (:311), shifted by the origin, filtered against the crop window and shifted by its corner (:321-328)."""
+    uses = []
+    for img, (h, w), (ox, oy) in zip(indices, shapes, mosaic9_origins(s, shapes)):
+        on_canvas = place(ox, oy, w, h, (0, 0, 3 * s, 3 * s))
+        r = place(ox, oy, w, h, (max(xc, 0), max(yc, 0), min(xc + 2 * s, 3 * s), min(yc + 2 * s, 3 * s)))
+        r = r._replace(dx=r.dx + max(xc, 0) - xc, dy=r.dy + max(yc, 0) - yc)
+        uses.append(Use(img, r, (oy, ox), (on_canvas.sx, w, on_canvas.sy, h), (xc, xc + 2 * s, yc, yc + 2 * s)))
+    return uses
+
+
+def affine(tx=0.0, ty=0.0, a_deg=0.0, scale=1.0):
+    """3x3 float64: rotation by a_deg about the origin (OpenCV's getRotationMatrix2D convention: positive = counter-clockwise in image
+    coordinates, i.e. [[c, s], [-s, c]]) times `scale`, then translation by (tx, ty)."""
+    m = np.eye(3)
+    ang = a_deg * math.pi / 180.0
+    m[0, 0] = m[1, 1] = scale * math.cos(ang)
+    m[0, 1] = scale * math.sin(ang)
+    m[1, 0] = -m[0, 1]
+    m[0, 2], m[1, 2] = tx, ty
+    return m
 
 
 def warp_matrix(shape, a, s, tx, ty, border=(0, 0)):
-    """lib/augmentations.py:45-65 with the four random draws made explicit: rotation angle a (deg), scale s, translation
-    fractions tx, ty.  Returns (M 3x3 float64, (width, height)).  cv2.getRotationMatrix2D is OpenCV's documented closed form."""
-    height = shape[0] + border[0] * 2
-    width = shape[1] + border[1] * 2
-    C = np.eye(3)
-    C[0, 2] = -shape[1] / 2
-    C[1, 2] = -shape[0] / 2
-    R = np.eye(3)
-    ang = a * math.pi / 180.0
-    alpha, beta = s * math.cos(ang), s * math.sin(ang)
-    R[:2] = np.array([[alpha, beta, 0.0], [-beta, alpha, 0.0]])      # center (0, 0): both translation terms vanish
-    T = np.eye(3)
-    T[0, 2] = tx * width
-    T[1, 2] = ty * height
-    return T @ R @ C, (width, height)
+    """Matrix of random_warping (lib/augmentations.py:45-65) for its four draws: rotation angle a (deg), scale s, translation fractions
+    tx, ty.  The image centre goes to the origin, is rotated / scaled there, and the result is moved by (tx, ty) of the OUTPUT size
+    (input size + 2 * border).  Returns (M 3x3 float64, (width, height) of the output)."""
+    height, width = shape[0] + border[0] * 2, shape[1] + border[1] * 2
+    M = affine(tx * width, ty * height) @ affine(a_deg=a, scale=s) @ affine(-shape[1] / 2, -shape[0] / 2)
+    return M, (width, height)
 
 
-def warp_targets(targets, M):
-    """lib/augmentations.py:67-74: polygon vertices through M in double, written back into the float32 targets (in place)."""
-    Mt = torch.tensor(M, dtype=torch.double)
-    pts = targets[:, 2:].reshape(-1, 2)
-    pts = torch.cat((pts, torch.ones(pts.size()[0]).view(pts.size()[0], 1)), dim=-1).double()
-    pts = (torch.matmul(Mt, pts.t())).t()[:, :2]
-    targets[:, 2:] = pts.reshape(-1, 8)
-    return targets
-
-
-# ------------------------------------------------------------------------------------------------ pixels (device)
+# ------------------------------------------------------------------------------------------------ tables -> device
 class _Rect(ctypes.Structure):
-    _fields_ = [("src_off", ctypes.c_int64), ("src_w", ctypes.c_int), ("sx", ctypes.c_int), ("sy", ctypes.c_int), ("dx", ctypes.c_int),
-                ("dy", ctypes.c_int), ("w", ctypes.c_int), ("h", ctypes.c_int), ("canvas", ctypes.c_int)]
+    _fields_ = [("src_off", _L), ("src_w", _I), ("sx", _I), ("sy", _I), ("dx", _I), ("dy", _I), ("w", _I), ("h", _I), ("canvas", _I)]
 
 
-def paste(pool, rects, ncanvas, CH, CW, fill=114):
-    """rects: [(image index in the pool, sx, sy, dx, dy, w, h, canvas index)] in paste order -> canvases [ncanvas, CH, CW, 3] uint8."""
-    n = ctypes.c_int()
-    hip.call("ryolo_paste_rect_bytes", n)
-    assert n.value == ctypes.sizeof(_Rect)
-    arr = (_Rect * max(len(rects), 1))()
-    k = 0
-    for (img, sx, sy, dx, dy, w, h, cv) in rects:
-        if w <= 0 or h <= 0:
-            continue                                              # empty numpy slices paste nothing
-        arr[k] = _Rect(pool.offsets[img], pool.shapes[img][1], sx, sy, dx, dy, w, h, cv)
-        k += 1
-    dev = pool.buf.device
-    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+class _ResizeItem(ctypes.Structure):
+    _fields_ = [("src_off", _L), ("dst_off", _L), ("SH", _I), ("SW", _I), ("NH", _I), ("NW", _I), ("interp", _I), ("lut", _I)]
+
+
+class _LabelRow(ctypes.Structure):
+    _fields_ = [("poly", ctypes.c_float * 8), ("cls", ctypes.c_float), ("slot", _I), ("w0", ctypes.c_float), ("h0", ctypes.c_float),
+                ("w1", ctypes.c_float), ("h1", ctypes.c_float), ("bx1", ctypes.c_float), ("bx2", ctypes.c_float), ("by1", ctypes.c_float),
+                ("by2", ctypes.c_float), ("padw", ctypes.c_float), ("padh", ctypes.c_float), ("cx1", ctypes.c_float), ("cx2", ctypes.c_float),
+                ("cy1", ctypes.c_float), ("cy2", ctypes.c_float), ("mat", _I)]
+
+
+LABEL_ROW_DTYPE = np.dtype([("poly", np.float32, 8), ("cls", np.float32), ("slot", np.int32), ("w0", np.float32), ("h0", np.float32),
+                            ("w1", np.float32), ("h1", np.float32), ("bx1", np.float32), ("bx2", np.float32), ("by1", np.float32),
+                            ("by2", np.float32), ("padw", np.float32), ("padh", np.float32), ("cx1", np.float32), ("cx2", np.float32),
+                            ("cy1", np.float32), ("cy2", np.float32), ("mat", np.int32)])
+INTERP_LINEAR, INTERP_AREA, INTERP_COPY = 0, 1, 2
+_checked = False
+
+
+def _check_layouts():
+    global _checked
+    if _checked:
+        return
+    n = _I()
+    for name, t in (("ryolo_paste_rect_bytes", _Rect), ("ryolo_resize_item_bytes", _ResizeItem), ("ryolo_label_row_bytes", _LabelRow)):
+        hip.call(name, n)
+        if n.value != ctypes.sizeof(t):
+            raise RuntimeError(f"ryolov4_amd: struct layout mismatch for {t.__name__}: C {n.value} vs ctypes {ctypes.sizeof(t)}")
+    if LABEL_ROW_DTYPE.itemsize != ctypes.sizeof(_LabelRow):
+        raise RuntimeError("ryolov4_amd: LABEL_ROW_DTYPE drifted from LabelRow")
+    _checked = True
+
+
+def _to_device(arr, dev):
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+
+def paste(src_buf, rects, ncanvas, CH, CW, fill=114):
+    """rects: [(source byte offset, source row pitch in pixels, Placed, canvas index)] in paste order (later rectangles win) ->
+    canvases [ncanvas, CH, CW, 3] uint8, `fill` where nothing was pasted."""
+    _check_layouts()
+    live = [(off, pitch, r, cv) for off, pitch, r, cv in rects if r.w > 0 and r.h > 0]         # empty numpy slices paste nothing
+    arr = (_Rect * max(len(live), 1))()
+    for k, (off, pitch, r, cv) in enumerate(live):
+        arr[k] = _Rect(off, pitch, r.sx, r.sy, r.dx, r.dy, r.w, r.h, cv)
+    dev = src_buf.device
+    table = _to_device(arr, dev)
     canvas = torch.empty((ncanvas, CH, CW, 3), dtype=torch.uint8, device=dev)
-    hip.call("ryolo_paste_rects", hip.ptr(pool.buf), hip.ptr(table), k, hip.ptr(canvas), ncanvas, CH, CW, fill, hip.stream())
+    hip.call("ryolo_paste_rects", hip.ptr(src_buf), hip.ptr(table), len(live), hip.ptr(canvas), ncanvas, CH, CW, fill, hip.stream())
     return canvas
 
 
-def mosaic4(pool, indices, s, yc, xc, canvas=0):
-    """Rectangles of one 4-image mosaic (datasets/base_dataset.py:224-268) for paste(): returns (rects, [(padh, padw), boarder] per image)."""
-    rects, meta = [], []
-    for img, (x1a, y1a, x2a, y2a, x1b, y1b, x2b, y2b) in zip(indices, mosaic4_plan(s, [pool.shapes[i] for i in indices], yc, xc)):
-        # numpy slice assignment img4[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]: both sides have the same extent by construction
-        rects.append((img, x1b, y1b, x1a, y1a, x2a - x1a, y2a - y1a, canvas))
-        meta.append(((y1a - y1b, x1a - x1b), (x1b, x2b, y1b, y2b)))
-    return rects, meta
+def pool_rects(pool, uses, canvas=0):
+    """paste() rows for source images read straight from an ImagePool (no resize / hsv stage in between)."""
+    return [(pool.offsets[u.img], pool.shapes[u.img][1], u.rect, canvas) for u in uses]
 
 
-def mosaic9(pool, indices, s, yc, xc, canvas=0):
-    """One 9-image mosaic cropped to [yc, yc + 2s) x [xc, xc + 2s) (datasets/base_dataset.py:270-330): the crop is folded into the
-    destination coordinates.  Returns (rects, [(pady, padx), boarder] per image)."""
-    rects, meta = [], []
-    for img, (padx, pady, x1, y1, x2, y2) in zip(indices, mosaic9_plan(s, [pool.shapes[i] for i in indices])):
-        h, w = pool.shapes[img]
-        # img9[y1:y2, x1:x2] = img[y1 - pady:, x1 - padx:]  (canvas 3s x 3s clips x2 / y2; the source slice runs to the image end)
-        sx, sy = x1 - padx, y1 - pady
-        ww, hh = min(x2, 3 * s) - x1, min(y2, 3 * s) - y1
-        ww, hh = min(ww, w - sx), min(hh, h - sy)
-        dx, dy = x1 - xc, y1 - yc
-        # clip against the crop window
-        cx0, cy0 = max(0, -dx), max(0, -dy)
-        cw, ch = min(ww, 2 * s - dx) - cx0, min(hh, 2 * s - dy) - cy0
-        rects.append((img, sx + cx0, sy + cy0, dx + cx0, dy + cy0, cw, ch, canvas))
-        meta.append(((pady, padx), (x1 - padx, w, y1 - pady, h)))
-    return rects, meta
+def resize_hsv_batch(pool, items, luts=None):
+    """items: [(pool image index, (NH, NW), interp, lut index or -1)] -> (staging buffer, [byte offset of every resized image]).
+    luts: uint8 [n, 3, 256] (hsv_luts per image) or None."""
+    _check_layouts()
+    dev = pool.buf.device
+    arr = (_ResizeItem * max(len(items), 1))()
+    offs, total, maxpix = [], 0, 0
+    for k, (img, (nh, nw), interp, lut) in enumerate(items):
+        sh, sw = pool.shapes[img]
+        arr[k] = _ResizeItem(pool.offsets[img], total, sh, sw, nh, nw, interp, lut)
+        offs.append(total)
+        total += ((nh * nw * 3 + 15) // 16) * 16
+        maxpix = max(maxpix, nh * nw)
+    stage = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+    if items:
+        lt = None if luts is None or not len(luts) else torch.as_tensor(np.ascontiguousarray(luts, dtype=np.uint8)).to(dev)
+        hip.call("ryolo_resize_hsv_batch", hip.ptr(pool.buf), hip.ptr(_to_device(arr, dev)), len(items), maxpix, hip.ptr(lt), hip.ptr(stage),
+                 hip.stream())
+    return stage, offs
 
 
+def label_stage(rows, mats, device):
+    """rows: numpy structured array (LABEL_ROW_DTYPE), mats: [n, 3, 3] float64 warp matrices (or empty) -> targets10 [nrows, 10] on the
+    device = (slot, class, 8 vertex coordinates), NaN vertices for rows a filter dropped (ryolo_encode_labels removes them in order)."""
+    _check_layouts()
+    n = len(rows)
+    out = torch.empty((n, 10), dtype=torch.float32, device=device)
+    if n:
+        table = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy()).to(device)
+        mt = None if mats is None or not len(mats) else torch.as_tensor(np.ascontiguousarray(mats, dtype=np.float64).reshape(-1, 9)).to(device)
+        hip.call("ryolo_label_stage", hip.ptr(table), n, hip.ptr(mt), hip.ptr(out), hip.stream())
+    return out
+
+
+def label_rows(polys, labels, slot, img_size0, img_size, use, mat=-1, normalized_labels=False):
+    """The LABEL_ROW_DTYPE rows of one placed source image: its parsed polygons [n, 8] / classes [n] with the parameters of
+    load_target (original and resized size, `boarder`, pad), of the mosaic-9 crop and the index of the canvas' warp matrix."""
+    n = len(labels)
+    rows = np.zeros(n, dtype=LABEL_ROW_DTYPE)
+    if not n:
+        return rows
+    rows["poly"], rows["cls"], rows["slot"], rows["mat"] = polys, labels, slot, mat
+    if not normalized_labels:
+        rows["h0"], rows["w0"] = img_size0
+    rows["h1"], rows["w1"] = img_size
+    rows["padh"], rows["padw"] = use.pad
+    rows["bx2"] = rows["cx2"] = -1.0
+    if use.border is not None:
+        rows["bx1"], rows["bx2"], rows["by1"], rows["by2"] = use.border
+    if use.crop is not None:
+        rows["cx1"], rows["cx2"], rows["cy1"], rows["cy2"] = use.crop
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ pixels (device), single-stage wrappers
 def warp_perspective(imgs, Ms, dsize, border=114):
     """imgs [B, H, W, 3] uint8 on the device, Ms [B] 3x3 (what the reference hands to cv2.warpPerspective), dsize (width, height)."""
     hip.require_device(imgs, "warp_perspective")
@@ -235,12 +285,9 @@ def pad_to_square_plan(shape, new_shape):
     """datasets/base_dataset.py:33-56, the integer part: (new_unpad (w, h), (top, bottom, left, right), (dh, dw))."""
     r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
     new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
-    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
-    dw /= 2
-    dh /= 2
-    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
-    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
-    return new_unpad, (top, bottom, left, right), (dh, dw)
+    dw, dh = (new_shape[1] - new_unpad[0]) / 2, (new_shape[0] - new_unpad[1]) / 2
+    edges = tuple(int(round(v)) for v in (dh - 0.1, dh + 0.1, dw - 0.1, dw + 0.1))
+    return new_unpad, edges, (dh, dw)
 
 
 def pad_to_square(img, new_shape, pad_value=114):

@@ -7,12 +7,22 @@ AFTER the cv2 stages (mosaic / warp / hsv) plus collate_fn, for a whole batch in
 `imgs_u8` [B, S, S, 3] uint8 BGR and `targets10` [nt, 10] = (image slot, class, x1, y1, ..., x4, y4 in pixels) are what the
 reference holds at line 128; `flags[b]` bit 0 / 1 = the fliplr / flipud decisions (hyp['fliplr'], hyp['flipud'] draws, :133-138).
 Returns (imgs [B, 3, S, S] fp32 RGB in [0, 1], targets [n, 7 | 187]) exactly as collate_fn hands them to train.py:183.
-The cv2 stages themselves (imread, resize, hsv, mosaic, warpPerspective, mixup) are not rebuilt (no cv2 in this image to pin them).
+
+    BaseDataset                                        base_dataset.py:70-128: the sample composition itself — mosaic-4 / mosaic-9 /
+                                                       mixup probabilities, load_image's resize + hsv, random_warping, letterbox —
+                                                       for a WHOLE BATCH on the device (`assemble_batch`), the random draws made on the
+                                                       host in the reference's order.  Subclasses (DOTA_dataset.py, UCASAOD_dataset.py)
+                                                       only list files and parse labels, as in the reference.
+Image decode (cv2.imread) stays on the host: `imread` is injectable, the decoded uint8 images live in ONE device buffer (ImagePool).
 """
+import os
+import random as _py_random
+
 import numpy as np
 import torch
 
 from .. import hip
+from . import augment as A
 
 
 def gaussian_label(label, num_class, u=0, sig=4.0):
@@ -47,3 +57,231 @@ def finalize_batch(imgs_u8, targets10, flags=None, csl=False):
              hip.ptr(out) if nt else None, count.data_ptr(), None if ws is None else ws.data_ptr(), hip.stream())
     n = int(count.item()) if nt else 0            # the one host read: collate_fn's torch.cat needs the row count too
     return imgs, out[:n]
+
+
+def _default_imread(path):
+    """cv2.imread when OpenCV is installed, else PIL (RGB -> BGR); the hot path never decodes — images are cached on the device."""
+    try:
+        import cv2
+        return cv2.imread(path)
+    except ImportError:
+        pass
+    try:
+        from PIL import Image
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    except ImportError:
+        raise RuntimeError("ryolov4_amd.datasets: no image decoder (cv2 / PIL) — pass imread=callable(path) -> uint8 HWC BGR")
+
+
+class BaseDataset:
+    """Same constructor and subclass contract as the reference's BaseDataset (datasets/base_dataset.py:70-77): subclasses fill
+    `img_files` / `label_files` and implement `load_files(label_path) -> (polys float32 [n, 8], labels [n])`.  Differences by design:
+    a sample is never built alone on a CPU worker — `assemble_batch(indices)` builds the whole batch on the device and returns what
+    collate_fn returns; `__getitem__` / `collate_fn` exist for API parity and go through it.
+
+    Random numbers: the reference draws from the global `random` and `numpy.random` modules; `rng=(random-like, numpy.random-like)`
+    defaults to exactly those, and every draw is made in the reference's order (base_dataset.py:83-138, lib/augmentations.py:11,25,
+    53-61), so the same seeds give the same sample composition (fixture G13: the imported reference's __getitem__ ran)."""
+
+    def __init__(self, hyp, img_size, augment, csl, normalized_labels, device=None, imread=None, rng=None):
+        self.hyp, self.img_size, self.augment, self.csl, self.normalized_labels = hyp, img_size, augment, csl, normalized_labels
+        self.mosaic_border = [-img_size // 2, -img_size // 2]
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self.imread = imread or _default_imread
+        self.rng = rng or (_py_random, np.random)
+        self.img_files, self.label_files = [], []
+        self._pool = self._labels = None
+
+    def __len__(self):
+        return len(self.img_files)
+
+    def load_files(self, label_path):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ cache: decoded images + parsed labels, resident
+    def set_arrays(self, images, polys, labels):
+        """Use already decoded images (uint8 HWC BGR, 1- or 3-channel) and parsed labels instead of reading files."""
+        imgs = [self._three_channels(np.asarray(im)) for im in images]
+        self._pool = A.ImagePool(imgs, self.device)
+        self._labels = [(np.asarray(p, dtype=np.float32).reshape(-1, 8), np.asarray(c, dtype=np.float32).reshape(-1)) for p, c in zip(polys, labels)]
+        if not self.img_files:
+            self.img_files = [f"<array {i}>" for i in range(len(imgs))]
+            self.label_files = list(self.img_files)
+
+    @staticmethod
+    def _three_channels(img):
+        if img.ndim == 2:
+            img = img[:, :, None]
+        if img.shape[2] != 3:                                    # base_dataset.py:177-178: grey images are stacked to 3 channels
+            img = np.repeat(img[:, :, :1], 3, axis=2)
+        return np.ascontiguousarray(img, dtype=np.uint8)
+
+    def cache(self):
+        if self._pool is None:
+            images, polys, labels = [], [], []
+            for ip, lp in zip(self.img_files, self.label_files):
+                images.append(self.imread(ip))
+                lp = lp.rstrip()
+                assert os.path.exists(lp), "Label file {} not found".format(lp)          # base_dataset.py:221
+                p, c = self.load_files(lp)
+                polys.append(p.numpy() if isinstance(p, torch.Tensor) else p)
+                labels.append(c.numpy() if isinstance(c, torch.Tensor) else (c if len(c) else np.zeros(0, np.float32)))
+            self.set_arrays(images, polys, labels)
+        return self._pool
+
+    # ------------------------------------------------------------------ the draws, in the reference's order
+    def _load_image_plan(self, index, items, luts):
+        """load_image (base_dataset.py:170-186) as a table row: resized size, interpolation, the hsv tables of this use.
+        Returns (row index into `items`, (h0, w0), (h, w))."""
+        h0, w0 = self._pool.shapes[index]
+        r = self.img_size / max(h0, w0)
+        h, w, interp = h0, w0, A.INTERP_COPY
+        if r != 1:
+            interp = A.INTERP_AREA if (r < 1 and not self.augment) else A.INTERP_LINEAR
+            w, h = int(w0 * r), int(h0 * r)
+        lut = -1
+        hy = self.hyp
+        if self.augment and (hy["hsv_h"] or hy["hsv_s"] or hy["hsv_v"]):
+            gains = self.rng[1].uniform(-1, 1, 3) * [hy["hsv_h"], hy["hsv_s"], hy["hsv_v"]] + 1
+            lut = len(luts)
+            luts.append(A.hsv_luts(gains))
+        items.append((index, (h, w), interp, lut))
+        return len(items) - 1, (h0, w0), (h, w)
+
+    def _mosaic_plan(self, index, nine, items, luts):
+        rnd, s, n = self.rng[0], self.img_size, len(self.img_files)
+        if not nine:
+            yc, xc = [int(rnd.uniform(-x, 2 * s + x)) for x in self.mosaic_border]
+        indices = [index] + rnd.choices(range(n), k=8 if nine else 3)
+        loaded = [self._load_image_plan(i, items, luts) for i in indices]
+        if nine:
+            yc, xc = [int(rnd.uniform(0, s)) for _ in self.mosaic_border]
+        shapes = [hw for _, _, hw in loaded]
+        uses = (A.mosaic9_uses if nine else A.mosaic4_uses)(shapes, [k for k, _, _ in loaded], s, yc, xc)
+        return [(u, indices[j], loaded[j][1], loaded[j][2]) for j, u in enumerate(uses)]
+
+    def _warp_draws(self, shape, border):
+        rnd, hy = self.rng[0], self.hyp
+        a = rnd.uniform(-hy["rotate"], hy["rotate"])
+        sc = rnd.uniform(1 - hy["scale"], 1.1 + hy["scale"])
+        tx = rnd.uniform(0.3 - hy["translate"], 0.3 + hy["translate"])
+        ty = rnd.uniform(0.3 - hy["translate"], 0.3 + hy["translate"])
+        return A.warp_matrix(shape, a, sc, tx, ty, border)
+
+    # ------------------------------------------------------------------ one batch
+    def assemble_batch(self, indices):
+        """indices -> (paths, imgs [B, 3, S, S] fp32 RGB in [0, 1], targets [n, 7 | 187]) — what the reference's DataLoader hands to
+        train.py:183 / test.py:183 after collate_fn, built on the device: ~10 launches per batch, one small host->device table each."""
+        pool, s, dev = self.cache(), self.img_size, self.device
+        rnd, nrd = self.rng
+        B = len(indices)
+        items, luts = [], []                       # resize + hsv stage: one row per source-image use
+        canvases = []                              # per canvas: dict(kind, uses [(Use, dataset index, (h0, w0), (h, w))], M, slot)
+        mixes, flags = [], np.zeros(B, dtype=np.uint8)
+        out_of = []                                # per sample: index of the canvas that holds its image
+        for slot, index in enumerate(indices):
+            if self.augment and rnd.random() < self.hyp["mosaic"]:
+                nine = not (rnd.random() < 0.8)
+                cv = dict(kind="mosaic", uses=self._mosaic_plan(index, nine, items, luts), slot=slot)
+                cv["M"], _ = self._warp_draws((2 * s, 2 * s), self.mosaic_border)
+                canvases.append(cv)
+                out_of.append(len(canvases) - 1)
+                if nrd.random() < self.hyp["mixup"]:
+                    nine2 = not (rnd.random() < 0.8)
+                    other = rnd.randint(0, len(self.img_files) - 1)
+                    cv2_ = dict(kind="mosaic", uses=self._mosaic_plan(other, nine2, items, luts), slot=slot)
+                    cv2_["M"], _ = self._warp_draws((2 * s, 2 * s), self.mosaic_border)
+                    canvases.append(cv2_)
+                    mixes.append((out_of[-1], len(canvases) - 1, nrd.beta(8.0, 8.0)))
+            else:
+                k, hw0, hw = self._load_image_plan(index, items, luts)
+                (nw, nh), (top, bottom, left, right), pad = A.pad_to_square_plan(hw, (s, s))
+                cv = dict(kind="letterbox", item=k, hw0=hw0, hw=hw, new=(nh, nw), edges=(top, bottom, left, right), pad=pad, index=index, slot=slot,
+                          M=None)
+                if self.augment:
+                    cv["M"], _ = self._warp_draws((top + nh + bottom, left + nw + right), (0, 0))
+                canvases.append(cv)
+                out_of.append(len(canvases) - 1)
+            if self.augment and nrd.random() < self.hyp["fliplr"]:
+                flags[slot] |= 1
+            if self.augment and nrd.random() < self.hyp["flipud"]:
+                flags[slot] |= 2
+        # ---- pixels -----------------------------------------------------------------------------------------------------------------
+        stage, offs = A.resize_hsv_batch(pool, items, np.stack(luts) if luts else None)
+        final = torch.empty((B, s, s, 3), dtype=torch.uint8, device=dev)
+        mos = [c for c in canvases if c["kind"] == "mosaic"]
+        warped = {}
+        if mos:
+            rects = []
+            for ci, c in enumerate(mos):
+                rects += [(offs[u.img], items[u.img][1][1], u.rect, ci) for u, _, _, _ in c["uses"]]
+            big = A.paste(stage, rects, len(mos), 2 * s, 2 * s)
+            small = A.warp_perspective(big, [c["M"] for c in mos], (s, s))
+            for ci, c in enumerate(mos):
+                warped[id(c)] = small[ci]
+        for c in canvases:
+            if c["kind"] == "letterbox":
+                nh0, nw0 = c["hw"]
+                src = stage[offs[c["item"]]:offs[c["item"]] + nh0 * nw0 * 3].view(nh0, nw0, 3)
+                sq, _ = A.pad_to_square(src, (s, s))
+                if tuple(sq.shape[:2]) != (s, s):
+                    raise RuntimeError("assemble_batch: letterbox did not produce a square canvas")
+                warped[id(c)] = A.warp_perspective(sq.unsqueeze(0), [c["M"]], (s, s))[0] if c["M"] is not None else sq
+        mixed = {a: (b, r) for a, b, r in mixes}
+        for slot in range(B):
+            ci = out_of[slot]
+            img = warped[id(canvases[ci])]
+            if ci in mixed:
+                b, r = mixed[ci]
+                img = A.mixup(img, warped[id(canvases[b])], r)
+            final[slot] = img
+        # ---- labels: one table row per label of every source-image use, in the reference's concatenation order --------------------
+        rows, mats = [], []
+        for c in canvases:
+            mat = -1
+            if c["M"] is not None:
+                mat = len(mats)
+                mats.append(c["M"])
+            if c["kind"] == "mosaic":
+                for u, ds_index, hw0, hw in c["uses"]:
+                    polys, cls = self._labels[ds_index]
+                    rows.append(A.label_rows(polys, cls, c["slot"], hw0, hw, u, mat, self.normalized_labels))
+            else:
+                polys, cls = self._labels[c["index"]]
+                u = A.Use(c["item"], None, c["pad"], None, None)
+                rows.append(A.label_rows(polys, cls, c["slot"], c["hw0"], c["hw"], u, mat, self.normalized_labels))
+        rows = np.concatenate(rows) if rows else np.zeros(0, dtype=A.LABEL_ROW_DTYPE)
+        # (mixup appends the second canvas' labels behind the first's: canvases of one sample are adjacent and in that order; samples are
+        # in slot order, so the rows are already ordered the way collate_fn's torch.cat orders them)
+        targets10 = A.label_stage(rows, np.stack(mats) if mats else None, dev)
+        imgs, targets = finalize_batch(final, targets10, torch.from_numpy(flags), self.csl)
+        return [self.img_files[i] for i in indices], imgs, targets
+
+    # ------------------------------------------------------------------ API parity with torch.utils.data.Dataset users
+    def __getitem__(self, index):
+        paths, imgs, targets = self.assemble_batch([index])
+        return paths[0], imgs[0], targets
+
+    def collate_fn(self, batch):
+        """base_dataset.py:159-166 for samples produced by __getitem__ (prefer assemble_batch: one pass for the whole batch)."""
+        paths, imgs, targets = list(zip(*batch))
+        for i, boxes in enumerate(targets):
+            boxes[:, 0] = i
+        return paths, torch.stack(imgs, 0), torch.cat(targets, 0)
+
+
+class DeviceLoader:
+    """Iterates a BaseDataset in batches assembled on the device (the role of torch.utils.data.DataLoader(dataset, batch_size, shuffle,
+    num_workers=8, collate_fn=dataset.collate_fn) at lib/load.py:19): yields (paths, imgs, targets)."""
+
+    def __init__(self, dataset, batch_size, shuffle):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+        for a in range(0, n, self.batch_size):
+            yield self.dataset.assemble_batch(order[a:a + self.batch_size])

@@ -147,6 +147,10 @@ class Graph:
         self.wprep = []                        # launches that depend on the weights only (eval-mode BN folding); run before fwd
         self._fork_open = False                # a side_branch() was emitted since the last join_side()
         self.static_weights = False            # True while a captured inference graph is recorded: pack + wprep already done
+        # test instrumentation (tests/test_gpu_teacher_forced.py): with Runtime.record_tape the argument objects of every launch stay
+        # inspectable, and `probe` = {(id(tape), index): (before, after)} runs host callables around single launches of a replay
+        self.tape_args = {} if getattr(rt, "record_tape", False) else None
+        self.probe = None
 
     # ------------------------------------------------------------------ helpers
     def new(self, N, H, W, Cc):
@@ -192,6 +196,8 @@ class Graph:
         tape.append((fn, conv, name))
         if self.dry:
             self._raw[(id(tape), len(tape) - 1)] = args
+        if self.tape_args is not None:
+            self.tape_args[(id(tape), len(tape) - 1)] = (name, args)
         self.meta[(id(tape), len(tape) - 1)] = self._describe(name, args)
         if tape is self.bwd:
             # which bytes of the flat gradient buffer this launch writes (data-parallel overlap: a bucket is reduced as soon as
@@ -286,8 +292,12 @@ class Graph:
             used = set()
         tid = id(tape)
         dirty, dirty2, pending, lane_stream = False, False, None, None
+        probe = self.probe
         for i, (fn, args, name) in enumerate(tape):
             on_side = False
+            pp = probe.get((tid, i)) if probe else None
+            if pp is not None and pp[0] is not None:
+                pp[0]()                              # enqueued on the main stream BEFORE the fork event of a side-stream launch is recorded
             if side_idx is not None:
                 on_side = i in side_idx
                 if on_side:                          # a weight gradient: its operands are final once everything before it ran
@@ -337,6 +347,8 @@ class Graph:
                 raise RuntimeError(f"{name} failed with code {rc}")
             if lag and on_side:
                 done[wpos[i]].record(lane_stream)
+            if pp is not None and pp[1] is not None:
+                pp[1]()                              # (the callable synchronises the device itself when it reads a side-stream result)
             if after:
                 cb = after.get(i)
                 if cb is not None:

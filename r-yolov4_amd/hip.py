@@ -33,6 +33,10 @@ _SIGNATURES = {
     "ryolo_hsv_gain_u8": [_P, _L, _P, _P],
     "ryolo_mixup_u8": [_P, _P, ctypes.c_double, _L, _P, _P],
     "ryolo_letterbox_u8": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "ryolo_resize_item_bytes": [ctypes.POINTER(_I)],
+    "ryolo_resize_hsv_batch": [_P, _P, _I, _L, _P, _P, _P],
+    "ryolo_label_row_bytes": [ctypes.POINTER(_I)],
+    "ryolo_label_stage": [_P, _L, _P, _P, _P],
     "ryolo_pp_emit": [_P, _P, _P, _I, _L, _L, _P, _P],
     "ryolo_map_match_workspace_bytes": [_L, _L, ctypes.POINTER(_Z)],
     "ryolo_map_match": [_P, _P, _P, _P, _I, _L, _L, _P, _I, _I, _P, _P, _Z, _P],

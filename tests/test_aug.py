@@ -1,9 +1,10 @@
 """SURVEY.md §8(f) N2 — mosaic-4 / mosaic-9 / mixup / warp / hsv of the reference's loader.
-CPU: the package's host-side plan and label code (datasets/augment.py) replayed with the random draws recorded in fixture G11 (the
-real reference load_mosaic / load_mosaic9 / load_target / mixup / random_warping ran: tests/golden/make_golden_aug.py) -> labels equal
-to the last bit, rectangles reproduce the reference's canvases when pasted with numpy.
-GPU: the same canvases from the device paste kernel and the device mixup, BIT-EXACT against the fixture; warp and hsv against this
-build's numpy restatement of OpenCV (parity unpinned: OpenCV is absent and un-versioned in the reference)."""
+CPU: the package's placement tables (datasets/augment.py) replayed with the random draws recorded in fixture G11 (the real reference
+load_mosaic / load_mosaic9 / load_target / mixup / random_warping ran: tests/golden/make_golden_aug.py) -> the rectangles reproduce the
+reference's canvases when pasted with numpy, the warp matrix reproduces its labels.
+GPU: the same canvases from the device paste kernel and the device mixup, BIT-EXACT against the fixture; the labels from the device
+label stage (mosaic: bit-exact); warp, hsv, resize against this build's numpy restatement of OpenCV (parity unpinned: OpenCV is absent
+and un-versioned in the reference)."""
 import os
 
 import numpy as np
@@ -19,59 +20,78 @@ def _images():
     return [G[f"img{i}"] for i in range(NIMG)]
 
 
-class _HostPool:                      # shapes / offsets only: enough for the plan code on CPU
-    def __init__(self, images):
-        self.shapes = [tuple(im.shape[:2]) for im in images]
-
-
-def _np_paste(images, rects, CH, CW):
+def _np_paste(images, uses, CH, CW):
     cv = np.full((CH, CW, 3), 114, np.uint8)
-    for (img, sx, sy, dx, dy, w, h, _) in rects:
-        if w > 0 and h > 0:
-            cv[dy:dy + h, dx:dx + w] = images[img][sy:sy + h, sx:sx + w]
+    for u in uses:
+        r = u.rect
+        if r.w > 0 and r.h > 0:
+            cv[r.dy:r.dy + r.h, r.dx:r.dx + r.w] = images[u.img][r.sy:r.sy + r.h, r.sx:r.sx + r.w]
     return cv
 
 
-def _labels(kind, case, meta, idx, xc=0, yc=0):
+def _uses(kind, case):
     from ryolov4_amd.datasets import augment as A
-    out = []
-    for i, (pad, boarder) in zip(idx, meta):
-        im = G[f"img{i}"]
-        out.append(A.load_target(torch.from_numpy(G[f"polys{i}"].copy()), torch.from_numpy(G[f"labels{i}"].copy()), pad,
-                                 im.shape[:2], im.shape[:2], True, boarder=boarder))
-    lab = torch.cat(out, 0)
-    if kind == "m9":
-        lab = A.filtering(lab, (xc, xc + 2 * S, yc, yc + 2 * S))
-        lab[:, [2, 4, 6, 8]] -= xc
-        lab[:, [3, 5, 7, 9]] -= yc
-    return lab
+    images = _images()
+    idx = [int(i) for i in G[f"{kind}_{case}_idx"]]
+    yc, xc = [int(v) for v in G[f"{kind}_{case}_yc_xc"]]
+    shapes = [images[i].shape[:2] for i in idx]
+    return (A.mosaic4_uses if kind == "m4" else A.mosaic9_uses)(shapes, idx, S, yc, xc), idx
 
 
 @pytest.mark.parametrize("case", range(4))
-def test_mosaic_plans_and_labels_replay_the_reference(case):
-    from ryolov4_amd.datasets import augment as A
+def test_mosaic_placements_replay_the_reference(case):
+    """The placement tables (MOSAIC4_CORNER / MOSAIC9_ORIGIN + window clipping) pasted with numpy reproduce the canvases the imported
+    reference's load_mosaic / load_mosaic9 built (fixture G11)."""
     images = _images()
-    pool = _HostPool(images)
-    idx = [int(i) for i in G[f"m4_{case}_idx"]]
-    yc, xc = [int(v) for v in G[f"m4_{case}_yc_xc"]]
-    rects, meta = A.mosaic4(pool, idx, S, yc, xc)
-    assert np.array_equal(_np_paste(images, rects, 2 * S, 2 * S), G[f"m4_{case}_img"])
-    assert torch.equal(_labels("m4", case, meta, idx), torch.from_numpy(G[f"m4_{case}_labels"]))
-    idx9 = [int(i) for i in G[f"m9_{case}_idx"]]
-    yc9, xc9 = [int(v) for v in G[f"m9_{case}_yc_xc"]]
-    rects9, meta9 = A.mosaic9(pool, idx9, S, yc9, xc9)
-    assert np.array_equal(_np_paste(images, rects9, 2 * S, 2 * S), G[f"m9_{case}_img"])
-    assert torch.equal(_labels("m9", case, meta9, idx9, xc9, yc9), torch.from_numpy(G[f"m9_{case}_labels"]))
+    for kind in ("m4", "m9"):
+        uses, _ = _uses(kind, case)
+        assert np.array_equal(_np_paste(images, uses, 2 * S, 2 * S), G[f"{kind}_{case}_img"]), kind
 
 
 @pytest.mark.parametrize("case", range(3))
-def test_warp_labels_replay_the_reference(case):
+def test_warp_matrix_replays_the_reference(case):
+    """warp_matrix for the four recorded draws: the fixture's warped labels (the reference's own double matrix product) follow from it."""
     from ryolov4_amd.datasets import augment as A
     a, s, tx, ty = [float(v) for v in G[f"warp_{case}_draws"]]
     M, (w, h) = A.warp_matrix((2 * S, 2 * S), a, s, tx, ty, border=(-S // 2, -S // 2))
-    assert (w, h) == (S, S)
-    tg = A.warp_targets(torch.from_numpy(G[f"m4_{case}_labels"].copy()), M)
-    assert torch.equal(tg, torch.from_numpy(G[f"warp_{case}_labels"]))
+    assert (w, h) == (S, S) and np.array_equal(M[2], [0.0, 0.0, 1.0])
+    lab = G[f"m4_{case}_labels"].astype(np.float64)
+    pts = np.concatenate((lab[:, 2:].reshape(-1, 2), np.ones((lab.shape[0] * 4, 1))), 1)
+    got = (pts @ M.T)[:, :2].reshape(-1, 8).astype(np.float32)
+    np.testing.assert_allclose(got, G[f"warp_{case}_labels"][:, 2:], rtol=1e-6, atol=1e-5)
+
+
+def _label_rows(kind, case, mat=-1):
+    from ryolov4_amd.datasets import augment as A
+    uses, idx = _uses(kind, case)
+    rows = []
+    for u, i in zip(uses, idx):
+        hw = G[f"img{i}"].shape[:2]
+        rows.append(A.label_rows(G[f"polys{i}"], G[f"labels{i}"], 0, hw, hw, u, mat, normalized_labels=True))
+    return np.concatenate(rows)
+
+
+def _survivors(t):
+    t = t.cpu().numpy()
+    return t[~np.isnan(t[:, 2])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(4))
+def test_device_label_stage_replays_the_reference(case):
+    """load_target / mosaic-9 crop / vertex warp of every label row in ONE element-wise launch: surviving rows, in order, equal the
+    labels the imported reference produced (fixture G11) — mosaic labels to the last bit, warped ones within 1e-5."""
+    from ryolov4_amd.datasets import augment as A
+    dev = torch.device("cuda:0")
+    for kind in ("m4", "m9"):
+        got = _survivors(A.label_stage(_label_rows(kind, case), None, dev))
+        want = G[f"{kind}_{case}_labels"]
+        assert got.shape == want.shape and np.array_equal(got[:, 1:], want[:, 1:]), (kind, case)
+    if case < 3:
+        a, s, tx, ty = [float(v) for v in G[f"warp_{case}_draws"]]
+        M, _ = A.warp_matrix((2 * S, 2 * S), a, s, tx, ty, border=(-S // 2, -S // 2))
+        got = _survivors(A.label_stage(_label_rows("m4", case, mat=0), M[None], dev))
+        np.testing.assert_allclose(got[:, 1:], G[f"warp_{case}_labels"][:, 1:], rtol=1e-6, atol=1e-5)
 
 
 def test_oracle_restatements_against_fixture():
@@ -92,14 +112,10 @@ def test_device_paste_and_mixup_bit_exact():
     pool = A.ImagePool(images, torch.device("cuda:0"))
     rects, want = [], []
     for case in range(4):
-        idx = [int(i) for i in G[f"m4_{case}_idx"]]
-        yc, xc = [int(v) for v in G[f"m4_{case}_yc_xc"]]
-        rects += A.mosaic4(pool, idx, S, yc, xc, canvas=2 * case)[0]
-        idx9 = [int(i) for i in G[f"m9_{case}_idx"]]
-        yc9, xc9 = [int(v) for v in G[f"m9_{case}_yc_xc"]]
-        rects += A.mosaic9(pool, idx9, S, yc9, xc9, canvas=2 * case + 1)[0]
+        rects += A.pool_rects(pool, _uses("m4", case)[0], canvas=2 * case)
+        rects += A.pool_rects(pool, _uses("m9", case)[0], canvas=2 * case + 1)
         want += [G[f"m4_{case}_img"], G[f"m9_{case}_img"]]
-    canv = A.paste(pool, rects, 8, 2 * S, 2 * S)                                       # ONE launch for the eight canvases
+    canv = A.paste(pool.buf, rects, 8, 2 * S, 2 * S)                                   # ONE launch for the eight canvases
     for k, w in enumerate(want):
         assert np.array_equal(canv[k].cpu().numpy(), w), k
     for case in range(2):
@@ -141,3 +157,26 @@ def test_device_letterbox_against_numpy_restatement(shape, new):
     got, pad = A.pad_to_square(torch.from_numpy(img).cuda(), new)
     assert pad == pad_ref and tuple(got.shape) == ref.shape
     assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_device_resize_hsv_batch_against_numpy_restatement():
+    """load_image's resize (+ hsv) for a whole batch of source images in one launch: INTER_LINEAR, INTER_AREA (eval loader, r < 1), and
+    the r == 1 copy, with and without the hsv tables — equal to the numpy restatements bit for bit (parity unpinned: OpenCV restated)."""
+    from oracle import ref_data
+    from ryolov4_amd.datasets import augment as A
+    rs = np.random.RandomState(5)
+    images = [rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in ((40, 64), (64, 48), (33, 61), (16, 16), (50, 37))]
+    pool = A.ImagePool(images, torch.device("cuda:0"))
+    gains = [(1.01, 1.4, 0.7), (0.99, 0.5, 1.3)]
+    luts = np.stack([A.hsv_luts(np.asarray(g, dtype=np.float64)) for g in gains])
+    items = [(0, (20, 32), A.INTERP_LINEAR, -1), (1, (32, 24), A.INTERP_AREA, -1), (2, (17, 32), A.INTERP_AREA, 0), (3, (16, 16), A.INTERP_COPY, 1),
+             (4, (64, 47), A.INTERP_LINEAR, 1), (0, (13, 21), A.INTERP_AREA, -1), (1, (32, 24), A.INTERP_LINEAR, 0)]
+    stage, offs = A.resize_hsv_batch(pool, items, luts)
+    for (img, (nh, nw), interp, lut), off in zip(items, offs):
+        src = images[img]
+        ref = src if interp == A.INTERP_COPY else (ref_data.resize_area_numpy if interp == A.INTERP_AREA else ref_data.resize_linear_numpy)(src, (nw, nh))
+        if lut >= 0:
+            ref = ref_data.hsv_gain_numpy(ref, gains[lut])
+        got = stage[off:off + nh * nw * 3].view(nh, nw, 3).cpu().numpy()
+        assert np.array_equal(got, ref), (img, nh, nw, interp, lut, int(np.abs(got.astype(int) - ref.astype(int)).max()))

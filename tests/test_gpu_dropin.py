@@ -1,15 +1,23 @@
-"""GPU: the drop-in boundary itself (VERDICT r1 "install_dropin() has no test").  A fresh interpreter calls
-ryolov4_amd.install_dropin() and then runs the reference's OWN import lines and loops, restated from train.py / test.py:
+"""GPU: the drop-in boundary itself.  A fresh interpreter calls ryolov4_amd.install_dropin() and then runs the reference's OWN
+import lines — verbatim, cv2 stubbed (absent in this image) — and loops, restated from train.py / test.py:
 
-    from model.yolo import Yolo                      train.py:14   test.py:10
-    from lib.loss import ComputeCSLLoss, ComputeKFIoULoss     train.py:16   test.py:12
-    from lib.general import post_process             test.py:11
+    import cv2 as cv                                                          lib/general.py:3
+    from detectron2.layers.nms import nms_rotated                             lib/general.py:4
+    from detectron2.layers.rotated_boxes import pairwise_iou_rotated          lib/loss.py:5   test.py:7
+    from model.yolo import Yolo                                               train.py:14   test.py:10
+    from lib.loss import ComputeCSLLoss, ComputeKFIoULoss                     train.py:16   test.py:12
+    from lib.general import post_process                                      test.py:11
 
 * train.py:150-158,186-202: nominal batch 64 accumulation, warm-up interpolation of `accumulate` and the learning rate,
-  torch.optim.SGD(momentum 0.937, nesterov) + LambdaLR, `loss.backward()` / `optimizer.step()` / `optimizer.zero_grad()`;
+  torch.optim.SGD(momentum 0.937, nesterov) + LambdaLR, `loss.backward()` / `optimizer.step()` / `optimizer.zero_grad()`.  Batch 32
+  (accumulate = 2) so that the loop really STEPS: 12 iterations = 6 optimizer steps, 5 of them after the warm-up at the scheduler's
+  learning rate; the loss must fall visibly and follow the oracle's;
 * test.py:188-207: eval forward, loss under no_grad, post_process, `targets[:, 2:6] *= img_size`, batch statistics, AP.
-The same loops run on the torch-CPU oracle with the same weights and inputs; losses must agree within the bf16 noise of a
-random-init train-mode network (3 %), the evaluation loss within 1 %."""
+The same loops run on the torch-CPU oracle with the same weights and inputs.  Asserted: every training loss within 5 % of the
+oracle's (batch-statistics BatchNorm at random init: see tests/test_gpu_trajectory.py for what is and is not reproducible), a fall of
+more than 15 % over the loop on both sides, the detection-head parameter update aligned with the oracle's (cos > 0.99), the update of all
+parameters of the oracle's size (parameters within the size of one update of the oracle's), the evaluation loss items within 1 %; and the detectron2 stand-ins / torch.ops
+schemas answer like the C oracle."""
 import json
 import os
 import subprocess
@@ -21,21 +29,35 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCRIPT = r'''
-import json, math, sys
+import json, math, sys, types
 import numpy as np
 import torch
 import ryolov4_amd
 ryolov4_amd.install_dropin()
-from model.yolo import Yolo                                   # the reference's import lines
-from lib.loss import ComputeCSLLoss, ComputeKFIoULoss
-from lib.general import post_process
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))        # not in this image; the hot path never calls it
+import cv2 as cv                                               # lib/general.py:3 — the reference's import lines, verbatim
+from detectron2.layers.nms import nms_rotated                  # lib/general.py:4
+from detectron2.layers.rotated_boxes import pairwise_iou_rotated   # lib/loss.py:5, test.py:7
+from model.yolo import Yolo                                    # train.py:14, test.py:10
+from lib.loss import ComputeCSLLoss, ComputeKFIoULoss          # train.py:16, test.py:12
+from lib.general import post_process                           # test.py:11
 from ryolov4_amd.lib.evaluate import get_batch_statistics, calculate_eval_stats
-from ryolov4_amd.synth import CFG, fill_state, synth_batch
+from ryolov4_amd.synth import CFG, fill_state, synth_batch, synth_nms_boxes
+import oracle
 from oracle import ref_model, ref_ops                          # the checker
 
-hyp_cfg = {"fl_gamma": 0.0, "box": 0.05, "obj": 1.0, "obj_pw": 1.0, "cls": 0.5, "cls_pw": 1.0, "warmup_prop": 0.1, "lrf": 0.01}
-mode, ver, nc, img_size, batch_size, epochs, lr0 = "kfiou", "yolov7", 2, 96, 2, 2, 0.01
 device = torch.device("cuda:0")
+# the detectron2 names resolve to the HIP ops (python functions and torch.ops schemas): keep set / IoU matrix vs the C oracle
+bx, sc = synth_nms_boxes(1500, "C", seed=3)
+tb, ts = torch.from_numpy(bx).to(device), torch.from_numpy(sc).to(device)
+keep_ok = bool(np.array_equal(nms_rotated(tb, ts, 0.3).cpu().numpy(), oracle.nms_rotated(bx, sc, 0.3))
+               and np.array_equal(torch.ops.detectron2.nms_rotated(tb, ts, 0.3).cpu().numpy(), oracle.nms_rotated(bx, sc, 0.3)))
+iou_dev = pairwise_iou_rotated(tb[:40], tb[40:100]).cpu().numpy()
+iou_ok = bool(np.abs(iou_dev - oracle.pairwise_iou_rotated(bx[:40], bx[40:100])).max() < 1e-6
+              and np.array_equal(torch.ops.detectron2.box_iou_rotated(tb[:40], tb[40:100]).cpu().numpy(), iou_dev))
+
+hyp_cfg = {"fl_gamma": 0.0, "box": 0.05, "obj": 1.0, "obj_pw": 1.0, "cls": 0.5, "cls_pw": 1.0, "warmup_prop": 0.1, "lrf": 0.1}
+mode, ver, nc, img_size, batch_size, epochs, lr0 = "kfiou", "yolov7", 2, 64, 32, 3, 0.01
 model = Yolo(nc, CFG, mode, ver)
 sd = fill_state(model.state_dict())
 model.load_state_dict(sd)
@@ -44,7 +66,7 @@ orc = ref_model.Yolo(nc, CFG, mode, ver)
 orc.load_state_dict(sd)
 compute_loss = ComputeKFIoULoss(model, hyp_cfg)
 assert list(compute_loss.loss_items) == ["reg_loss", "conf_loss", "cls_loss", "total_loss"]     # train.py:178 reads the keys before the first call
-batches = [synth_batch(batch_size, img_size, nc, False, seed=100 + i, per_image=5) for i in range(3)]
+batches = [synth_batch(batch_size, img_size, nc, False, seed=100 + i, per_image=4) for i in range(4)]
 
 def one_cycle(y1=0.0, y2=1.0, steps=100):                     # lib/scheduler.py as used at train.py:160
     return lambda x: ((1 - math.cos(x * math.pi / steps)) / 2) * (y2 - y1) + y1
@@ -55,11 +77,11 @@ def train(model, loss_fn, to_dev):
     accumulate = max(round(nbs / batch_size), 1)
     optimizer = torch.optim.SGD(model.parameters(), lr=lr0, momentum=0.937, nesterov=True)
     num_iters_per_epoch = len(batches)
-    nw = max(int((epochs * num_iters_per_epoch) * hyp_cfg["warmup_prop"]), 4)          # (the reference's floor of 1000 shortened to 4)
+    nw = max(int((epochs * num_iters_per_epoch) * hyp_cfg["warmup_prop"]), 2)          # (the reference's floor of 1000 shortened to 2)
     lf = one_cycle(1, hyp_cfg["lrf"], epochs)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lf)
     initial_lr = optimizer.param_groups[0]["initial_lr"]
-    log = []
+    log, nsteps, lrs = [], 0, []
     for epoch in range(epochs):
         for batch, (imgs, targets) in enumerate(batches):
             global_step = num_iters_per_epoch * epoch + batch + 1
@@ -74,20 +96,33 @@ def train(model, loss_fn, to_dev):
             if global_step % accumulate == 0:
                 optimizer.step()
                 optimizer.zero_grad()
+                nsteps += 1
+                lrs.append(float(optimizer.param_groups[0]["lr"]))
             log.append(float(loss_items["total_loss"]))
         scheduler.step()
-    return log
+    return log, nsteps, lrs
 
-dev_log = train(model, compute_loss, lambda t: t.to(device))
-cpu_log = train(orc, lambda o, t: ref_ops.compute_loss(o, t, orc.anchors, nc, mode, hyp_cfg), lambda t: t)
+dev_log, dev_steps, dev_lrs = train(model, compute_loss, lambda t: t.to(device))
+cpu_log, cpu_steps, _ = train(orc, lambda o, t: ref_ops.compute_loss(o, t, orc.anchors, nc, mode, hyp_cfg), lambda t: t)
+dev_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+orc_sd = orc.state_dict()
+fk = [k for k in sd if sd[k].dtype.is_floating_point and "running" not in k]
+hk = [k for k in fk if k.startswith(("neck.conv5.", "neck.conv6.", "neck.conv7."))]
+cat = lambda d, ks: torch.cat([(d[k] - sd[k]).flatten() for k in ks]).double()
+du, ou = cat(dev_sd, hk), cat(orc_sd, hk)
+pa, po = torch.cat([dev_sd[k].flatten() for k in fk]).double(), torch.cat([orc_sd[k].flatten() for k in fk]).double()
+ua, uo = cat(dev_sd, fk), cat(orc_sd, fk)
+param = dict(cos_update_heads=float(du @ ou / (du.norm() * ou.norm())), update_norm_heads=float(ou.norm()),
+             cos_update_all=float(ua @ uo / (ua.norm() * uo.norm())), rel_update_vs_params=float(uo.norm() / po.norm()),
+             rel_params=float((pa - po).norm() / po.norm()), rel_update_all=float(cat(dev_sd, fk).norm() / cat(orc_sd, fk).norm()))
 
 def evaluate(model, loss_fn, pp, stats_fn, to_dev):
     model.eval()
     iouv = torch.linspace(0.5, 0.95, 10)
     niou = iouv.numel()
     stats, seen, total = [], 0, {}
-    for imgs, targets in batches:
-        imgs, targets = to_dev(imgs), to_dev(targets.clone())
+    for imgs, targets in batches[:2]:
+        imgs, targets = to_dev(imgs[:4]), to_dev(targets[targets[:, 0] < 4].clone())
         seen += len(imgs)
         with torch.no_grad():
             outputs, infer_outputs = model(imgs, training=False)
@@ -104,10 +139,14 @@ def evaluate(model, loss_fn, pp, stats_fn, to_dev):
         res = calculate_eval_stats(cat, nc)
     return total, seen, ndet, (float(res[-1]) if res is not None else None)
 
+# (evaluation on the SAME weights both sides: the oracle's trained weights are loaded into the device model first)
+model.load_state_dict(orc.state_dict())
 dev_eval = evaluate(model, compute_loss, post_process, get_batch_statistics, lambda t: t.to(device))
 cpu_eval = evaluate(orc, lambda o, t: ref_ops.compute_loss(o, t, orc.anchors, nc, mode, hyp_cfg), ref_ops.post_process,
                     ref_ops.get_batch_statistics, lambda t: t)
-print("RESULT " + json.dumps(dict(dev_log=dev_log, cpu_log=cpu_log, dev_eval=[dev_eval[0], dev_eval[1], dev_eval[2], dev_eval[3]],
+print("RESULT " + json.dumps(dict(dev_log=dev_log, cpu_log=cpu_log, steps=[dev_steps, cpu_steps], lrs=dev_lrs, param=param,
+                                  keep_ok=keep_ok, iou_ok=iou_ok,
+                                  dev_eval=[dev_eval[0], dev_eval[1], dev_eval[2], dev_eval[3]],
                                   cpu_eval=[cpu_eval[0], cpu_eval[1], cpu_eval[2], cpu_eval[3]],
                                   grads_are_flat_views=all(p.grad is None or p.grad.data_ptr() == model.runtime().grad_ptr(p) for p in model.parameters()))))
 '''
@@ -123,12 +162,22 @@ def test_reference_train_and_test_loops_through_install_dropin():
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     d = json.loads(line[len("RESULT "):])
-    assert len(d["dev_log"]) == 6 and all(x == x and abs(x) < 1e6 for x in d["dev_log"])
+    print("DROPIN", json.dumps({k: d[k] for k in ("dev_log", "cpu_log", "steps", "lrs", "param")}))
+    assert d["keep_ok"] and d["iou_ok"]                                  # detectron2.layers.* and torch.ops.detectron2.* answer like the C oracle
+    assert len(d["dev_log"]) == 12 and all(x == x and abs(x) < 1e6 for x in d["dev_log"])
+    assert d["steps"] == [6, 6] and min(d["lrs"][1:]) > 5e-4              # six optimizer steps, five of them at the post-warm-up learning rate
     for a, b in zip(d["dev_log"], d["cpu_log"]):
-        assert abs(a - b) < 3e-2 * abs(b), (d["dev_log"], d["cpu_log"])
+        assert abs(a - b) < 5e-2 * abs(b), (d["dev_log"], d["cpu_log"])
+    # the optimizer moves the loss: same batch at iteration 1 / 9 (epoch 0 / 2), visibly lower, on both sides
+    assert d["dev_log"][8] < 0.85 * d["dev_log"][0] and d["cpu_log"][8] < 0.85 * d["cpu_log"][0], (d["dev_log"], d["cpu_log"])
+    pr = d["param"]
+    # parameters after the loop: the detection heads (last layers) moved like the oracle's; over ALL parameters the update has the
+    # oracle's size, and the parameters agree to the size of that update (its direction in the 100 layers below the heads is not
+    # reproducible between two roundings at this initialisation — see the module docstring; measured rel 4e-2 with an update of 5e-2)
+    assert pr["cos_update_heads"] > 0.99 and 0.8 < pr["rel_update_all"] < 1.25 and pr["rel_params"] < 1.5 * pr["rel_update_vs_params"], pr
     dev_items, cpu_items = d["dev_eval"][0], d["cpu_eval"][0]
     assert set(dev_items) == set(cpu_items) == {"reg_loss", "conf_loss", "cls_loss", "total_loss"}
     for k in dev_items:
         assert abs(dev_items[k] - cpu_items[k]) < 1e-2 * max(abs(cpu_items[k]), 1e-6), (k, dev_items[k], cpu_items[k])
-    assert d["dev_eval"][1] == d["cpu_eval"][1] == 6
+    assert d["dev_eval"][1] == d["cpu_eval"][1] == 8
     assert d["grads_are_flat_views"]

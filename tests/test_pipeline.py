@@ -1,0 +1,103 @@
+"""SURVEY.md §8(f) N2, the whole loader: label parsers (datasets/DOTA_dataset.py:18-49, UCASAOD_dataset.py:20-51), load_data
+(lib/load.py:9-21) and the sample composition of BaseDataset.__getitem__ + collate_fn (datasets/base_dataset.py:83-166) as ONE
+device-side batch assembler, against fixture G13 — batches the imported reference's real datasets produced (tests/golden/
+make_golden_pipeline.py: real label files, real __getitem__, cv2 answered by the numpy restatement of OpenCV).
+Pinned by G13: parsing, the order and meaning of every random draw, placements, the label arithmetic (targets 1e-5, same rows in the
+same order).  Pixels of resize / hsv / warp: bit-equal to the numpy restatement, which is unpinned against OpenCV itself."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_pipeline.npz"))
+NIMG = int(G["nimg"])
+CLASSES = [str(c) for c in G["classes"]]
+HYP_KEYS = [str(k) for k in G["hyp_keys"]]
+CASES = ["dota_mosaic", "dota_mosaic_csl", "ucas_plain_aug", "ucas_eval", "dota_eval_up"]
+
+
+def _write_tree(tmp, kind):
+    base = os.path.join(str(tmp), kind)
+    os.makedirs(os.path.join(base, "images"), exist_ok=True)
+    os.makedirs(os.path.join(base, "annfiles"), exist_ok=True)
+    images = {}
+    for i in range(NIMG):
+        ip = os.path.join(base, "images", "%03d.png" % i) if kind == "DOTA" else os.path.join(base, "%03d.png" % i)
+        lp = ip.replace("images", "annfiles").replace(".png", ".txt") if kind == "DOTA" else ip.replace(".png", ".txt")
+        open(ip, "wb").close()
+        open(lp, "w").write(str(G[f"labels_{kind}_{i}"]))
+        images[ip] = G[f"img{i}"]
+    return base, images
+
+
+@pytest.mark.parametrize("kind", ["DOTA", "UCAS_AOD"])
+def test_label_parsers_and_file_lists(tmp_path, kind):
+    from ryolov4_amd.lib.load import load_data
+    base, images = _write_tree(tmp_path, kind)
+    ds, loader = load_data(base, CLASSES, kind, {}, False, img_size=32, batch_size=4, augment=False, shuffle=False, imread=lambda p: images[p])
+    assert len(ds) == NIMG and len(loader) == 3 and ds.img_files == sorted(images)
+    assert ds.category == {"plane": 0, "small-vehicle": 1, "ship": 2}
+    total = 0
+    for i, lp in enumerate(ds.label_files):
+        polys, labels = ds.load_files(lp)
+        lines = [ln for ln in str(G[f"labels_{kind}_{i}"]).splitlines() if ln]
+        assert polys.dtype == torch.float32 and tuple(polys.shape) == (len(lines), 8)
+        for row, cls, ln in zip(polys, labels, lines):
+            f = ln.split("\t" if kind == "UCAS_AOD" else " ")
+            coords = f[1:9] if kind == "UCAS_AOD" else f[0:8]
+            name = f[0] if kind == "UCAS_AOD" else f[8]
+            assert torch.equal(row, torch.tensor([float(v) for v in coords]).float()) and int(cls) == ds.category[name]
+        total += len(lines)
+    assert total > 20
+    bad = os.path.join(str(tmp_path), "bad.txt")
+    open(bad, "w").write("\t".join(["tank"] + ["1.0"] * 8) + "\n" if kind == "UCAS_AOD" else " ".join(["1.0"] * 8 + ["tank", "0"]) + "\n")
+    with pytest.raises(KeyError):
+        ds.load_files(bad)
+    with pytest.raises(NotImplementedError):
+        load_data(base, CLASSES, "custom", {}, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_assemble_batch_replays_the_reference_loader(tmp_path, case):
+    from ryolov4_amd.lib.load import load_data
+    kind, size, augment, csl, seed = [str(v) for v in G[f"{case}_cfg"]]
+    size, augment, csl, seed = int(size), bool(int(augment)), bool(int(csl)), int(seed)
+    hyp = {k: float(v) for k, v in zip(HYP_KEYS, G[f"{case}_hyp"])}
+    base, images = _write_tree(tmp_path, kind)
+    ds, _ = load_data(base, CLASSES, kind, hyp, csl, img_size=size, batch_size=4, augment=augment, shuffle=False, imread=lambda p: images[p],
+                      device="cuda:0")
+    indices = [int(i) for i in G[f"{case}_indices"]]
+    random.seed(seed)
+    np.random.seed(seed)                                       # the reference draws from the global generators; so does the default rng
+    paths, imgs, targets = ds.assemble_batch(indices)
+    assert list(paths) == [ds.img_files[i] for i in indices]
+    want_img, want_tg = G[f"{case}_imgs_u8"], G[f"{case}_targets"]
+    got_u8 = torch.round(imgs * 255).to(torch.uint8).cpu().numpy()
+    assert got_u8.shape == want_img.shape and imgs.dtype == torch.float32
+    assert torch.equal(imgs.cpu(), torch.from_numpy(got_u8).float() / 255)          # exactly uint8 / 255 (base_dataset.py:157)
+    diff = np.abs(got_u8.astype(int) - want_img.astype(int))
+    assert np.array_equal(got_u8, want_img), (case, int(diff.max()), int((diff > 0).sum()))
+    got_tg = targets.cpu().numpy()
+    assert got_tg.shape == want_tg.shape, (case, got_tg.shape, want_tg.shape)
+    assert np.array_equal(got_tg[:, :2], want_tg[:, :2])                             # image slot and class: exact, same row order
+    np.testing.assert_allclose(got_tg, want_tg, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_loader_iterates_batches(tmp_path):
+    from ryolov4_amd.lib.load import load_data
+    hyp = {k: float(v) for k, v in zip(HYP_KEYS, G["dota_mosaic_hyp"])}
+    base, images = _write_tree(tmp_path, "DOTA")
+    ds, loader = load_data(base, CLASSES, "DOTA", hyp, False, img_size=32, batch_size=5, augment=True, shuffle=True, imread=lambda p: images[p],
+                           device="cuda:0")
+    seen = 0
+    for paths, imgs, targets in loader:
+        assert imgs.is_cuda and imgs.shape[1:] == (3, 32, 32) and targets.shape[1] == 7 and len(paths) == imgs.shape[0]
+        assert targets.shape[0] == 0 or (int(targets[:, 0].max()) < imgs.shape[0] and bool(torch.isfinite(targets).all()))
+        seen += imgs.shape[0]
+    assert seen == NIMG
+    path, img, labels = ds[3]                                   # API parity with Dataset.__getitem__
+    assert path == ds.img_files[3] and tuple(img.shape) == (3, 32, 32) and labels.shape[1] == 7
