@@ -347,7 +347,7 @@ class Yolo(nn.Module):
             static_in.copy_(imgs)
             graph.replay()
             return (heads, infer) if plan is None else (heads, infer, dets, num)
-        run.graph, run.static_input = graph, static_in
+        run.graph, run.static_input, run.post_plan = graph, static_in, plan
         return run
 
 

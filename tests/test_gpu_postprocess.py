@@ -63,6 +63,22 @@ def test_nms_full_size_properties_50k():
     assert float(iou.max()) <= 0.3
 
 
+@pytest.mark.parametrize("dist", ["C", "U"])
+@pytest.mark.parametrize("thr", [0.2, 0.65])
+def test_nms_50k_keep_set_bit_exact_vs_oracle_fixture(golden_dir, dist, thr):
+    """BASELINE config C5's candidate count: 50 000 boxes, both synthetic sets, both thresholds — keep set bit-exact against fixture G12,
+    generated once by the C oracle (tests/golden/make_golden_nms50k.py: 5 ... 60 s per case on one core); the clustered set is also
+    checked live against the oracle (seconds)."""
+    g = _general()
+    fix = np.load(os.path.join(golden_dir, "g12_nms50k.npz"))
+    b, s = synth_nms_boxes(50000, dist, seed=9)
+    got = g.nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), thr).cpu().numpy()
+    want = fix[f"{dist}_{thr}"].astype(np.int64)
+    assert got.shape == want.shape and np.array_equal(got, want), (dist, thr, len(got), len(want))
+    if dist == "C":
+        assert np.array_equal(got, oracle.nms_rotated(b, s, thr))
+
+
 def test_pairwise_and_diag_iou():
     g = _general()
     b, _ = synth_nms_boxes(700, "C", seed=4)
