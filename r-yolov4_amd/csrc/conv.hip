@@ -35,9 +35,14 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 #define RY_STAGES 3
 #endif
 
-template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0, bool ID = false>
+// T1: single-tap launches on the identity grid with input grid == output grid, stride 1, tap (0, 0), weight index 0 — every 1x1 forward and
+// 1x1 stride-1 data gradient (the launcher checks it; requires ID and the LDS-DMA ring).  Row m of the GEMM IS input pixel m, so the tile
+// needs no (image, row, column) decomposition, no tap table in LDS (and not the workgroup barrier behind it), no bounds tests and no
+// per-stage scalar tap lookups: on an 8-32 step K loop that prologue was as long as the loop (tools/gemm_phases.py).
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0, bool ID = false, bool T1 = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
+    static_assert(!T1 || (ID && PIPE == 1), "T1 is an identity-grid LDS-DMA instantiation");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = (BM * 4 + 255) / 256, PB = (BN * 4 + 255) / 256;       // 16-byte pieces per thread
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BM % 64 == 0, "tile config");
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
     const int cchunks = p.Cin / KB;
-    const int nk = tc.ntaps * cchunks;
+    const int nk = T1 ? cchunks : tc.ntaps * cchunks;
     if constexpr (PIPE == 0) {
         // ---- per-thread gather bookkeeping -----------------------------------------------------------------
         int a_ih0[PA], a_iw0[PA];
@@ -170,8 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         // the tap class of this launch: 40 kernarg bytes as ten dwords, requested first so that their round trip overlaps the index math
         const unsigned* tcw = reinterpret_cast<const unsigned*>(&tc);
         unsigned tw[10];
+        if constexpr (!T1) {
 #pragma unroll
-        for (int i = 0; i < 10; i++) tw[i] = tcw[i];
+            for (int i = 0; i < 10; i++) tw[i] = tcw[i];
+        }
         constexpr int SPR = KB / 8;                             // 16-byte slots per row
         constexpr int RPP = 64 / SPR;                           // rows per 1-KiB piece
         constexpr int STG = (BM + BN) * KB;                     // elements per stage
@@ -183,17 +190,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         bool a_ok[NPA];
         // (img, oh, ow) of the tile's first row with ONE wave-uniform 64-bit division; rows inside the tile (< 256 further) by
         // small exact reciprocal divisions — the per-lane 64-bit divisions of the first version cost ~3k cycles of an 8-step K loop
-        const int64_t HWo = (int64_t)p.OH * p.OW;
-        const int t_img = (int)(m0 / HWo);
-        const int t_rem = (int)(m0 - (int64_t)t_img * HWo);
-        const int t_oh = t_rem / p.OW, t_ow = t_rem - t_oh * p.OW;
-        const float rOW = 1.0f / (float)p.OW, rOH = 1.0f / (float)p.OH;
+        int t_img = 0, t_oh = 0, t_ow = 0;
+        float rOW = 0.f, rOH = 0.f;
+        if constexpr (!T1) {
+            const int64_t HWo = (int64_t)p.OH * p.OW;
+            t_img = (int)(m0 / HWo);
+            const int t_rem = (int)(m0 - (int64_t)t_img * HWo);
+            t_oh = t_rem / p.OW;
+            t_ow = t_rem - t_oh * p.OW;
+            rOW = 1.0f / (float)p.OW;
+            rOH = 1.0f / (float)p.OH;
+        }
 #pragma unroll
         for (int u = 0; u < NPA; u++) {
             const int piece = wave + 4 * u;
             const int r = piece * RPP + lane / SPR;
             const int64_t m = m0 + r;
             a_ok[u] = piece < PCS_A && m < M;
+            if constexpr (T1) {                                   // GEMM row m = input pixel m
+                a_ih0[u] = 0;
+                a_iw0[u] = 0;
+                a_ptr[u] = p.A + (a_ok[u] ? m : 0) * p.ldA + ((lane % SPR) ^ swz(r)) * 8;
+                continue;
+            }
             const int o = t_ow + r;
             const int wr = small_div(o, p.OW, rOW);
             const int ow = o - wr * p.OW;
@@ -223,19 +242,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         // of a workgroup (cycle counters, tools/gemm_phases.py).  The 40-byte TapClass is fetched as ten dwords, bytes are cut out below.
         static_assert(sizeof(TapClass) == 40 && offsetof(TapClass, dh) == 12 && offsetof(TapClass, dw) == 12 + RY_MAX_TAPS &&
                       offsetof(TapClass, widx) == 12 + 2 * RY_MAX_TAPS, "TapClass layout");
+        if constexpr (!T1) {
 #pragma unroll
-        for (int t = 0; t < RY_MAX_TAPS; t++) {
-            const unsigned bdh = (tw[(12 + t) >> 2] >> (((12 + t) & 3) * 8)) & 0xffu;
-            const unsigned bdw = (tw[(21 + t) >> 2] >> (((21 + t) & 3) * 8)) & 0xffu;
-            const unsigned bwi = (tw[(30 + t) >> 2] >> (((30 + t) & 3) * 8)) & 0xffu;
-            if (tid == t && t < (int)tw[0]) taptab[t] = (int)(bdh | (bdw << 8) | (bwi << 16));
+            for (int t = 0; t < RY_MAX_TAPS; t++) {
+                const unsigned bdh = (tw[(12 + t) >> 2] >> (((12 + t) & 3) * 8)) & 0xffu;
+                const unsigned bdw = (tw[(21 + t) >> 2] >> (((21 + t) & 3) * 8)) & 0xffu;
+                const unsigned bwi = (tw[(30 + t) >> 2] >> (((30 + t) & 3) * 8)) & 0xffu;
+                if (tid == t && t < (int)tw[0]) taptab[t] = (int)(bdh | (bdw << 8) | (bwi << 16));
+            }
+            __syncthreads();
         }
-        __syncthreads();
         int is_t = 0, is_c0 = 0;                                  // (tap, channel chunk) of the next stage to issue
         int cur_dh = 0, cur_dw = 0;
         int64_t cur_a_off = 0, cur_b_off = 0;
         bf16_t* cur_stage = smem;
         auto issue_prep = [&](int step) {                         // scalar part of a stage issue
+            if constexpr (T1) {                                   // one tap (0, 0), weight index 0: the stage is a channel offset
+                cur_a_off = cur_b_off = (int64_t)step * KB;
+                cur_stage = smem + (step % NSTG) * STG;
+                return;
+            }
             const int packed = __builtin_amdgcn_readfirstlane(taptab[is_t]);         // wave-uniform -> scalar registers
             cur_dh = (int)(signed char)(packed & 0xff);
             cur_dw = (int)(signed char)((packed >> 8) & 0xff);
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 const int u = it;
                 const int piece = wave + 4 * u;
                 if (piece < PCS_A) {                                          // wave-uniform
-                    const bool ok = a_ok[u] && (unsigned)(a_ih0[u] + cur_dh) < (unsigned)p.IH && (unsigned)(a_iw0[u] + cur_dw) < (unsigned)p.IW;
+                    const bool ok = T1 ? a_ok[u] : (a_ok[u] && (unsigned)(a_ih0[u] + cur_dh) < (unsigned)p.IH && (unsigned)(a_iw0[u] + cur_dw) < (unsigned)p.IW);
                     const bf16_t* src = ok ? a_ptr[u] + cur_a_off : p.zeros;
                     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(cur_stage + piece * 512), 16, 0, 0);
                 }
@@ -355,13 +381,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     // uniform branches, 64-bit divisions and waits (3 300 cycles per workgroup for eight 16-byte stores per lane).
     const bool identity = ID || (p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && tc.oh_add == 0 && tc.ow_add == 0);
     const int h = lane >> 5;
-    auto out_pixel = [&](int64_t m) -> int64_t {
+    // Output pixel of tile row rt (GEMM row m0 + rt) on a NON-identity grid (strided data gradients: parity classes, depth-to-space): the
+    // tile's first row is decomposed once per workgroup (wave-uniform 64-bit division), rows inside the tile by small exact reciprocal
+    // divisions — the per-row 64-bit divisions this replaces cost ~10 k cycles of a store loop (every stride-2 data gradient;
+    // 64->128 taps4 @400^2: the slowest launch of the step).
+    int e_img = 0, e_oh = 0, e_ow = 0;
+    float e_rOW = 0.f, e_rOH = 0.f;
+    if (!ID && !identity) {
+        const int64_t HWo = (int64_t)p.OH * p.OW;
+        e_img = (int)(m0 / HWo);
+        const int rem = (int)(m0 - (int64_t)e_img * HWo);
+        e_oh = rem / p.OW;
+        e_ow = rem - e_oh * p.OW;
+        e_rOW = 1.0f / (float)p.OW;
+        e_rOH = 1.0f / (float)p.OH;
+    }
+    auto out_pixel = [&](int rt, int64_t m) -> int64_t {
         if constexpr (ID) return m;
         if (identity) return m;
-        const int img = (int)(m / ((int64_t)p.OH * p.OW));
-        const int rem = (int)(m - (int64_t)img * p.OH * p.OW);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        return ((int64_t)img * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
+        const int o = e_ow + rt;
+        const int wr = small_div(o, p.OW, e_rOW);
+        const int ow = o - wr * p.OW, orow = e_oh + wr;
+        const int wi = small_div(orow, p.OH, e_rOH);
+        const int oh = orow - wi * p.OH;
+        return ((int64_t)(e_img + wi) * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
     };
 
     if (p.epi == EPI_F32_BIAS) {
@@ -371,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         for (int i = 0; i < TM; i++) {
             const int64_t m = m0 + wm * WTM + i * 32 + (lane & 31);
             if (m >= M) continue;
-            float* orow = reinterpret_cast<float*>(p.out) + out_pixel(m) * p.ldC;
+            float* orow = reinterpret_cast<float*>(p.out) + out_pixel(wm * WTM + i * 32 + (lane & 31), m) * p.ldC;
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -455,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                     const int r = (g0 + k) * RPI + r0;
                     const int64_t m = m0 + wm * WTM + r;
                     lv[k] = m < M && n < p.Nout;
-                    const int64_t pix = out_pixel(lv[k] ? m : 0);
+                    const int64_t pix = lv[k] ? out_pixel(wm * WTM + r, m) : 0;
                     pixv[k] = pix;
                     bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n_s;
                     if (!ID && p.s2d_cin) {                            // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
@@ -519,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 const int r = it * RPI + r0;
                 const int64_t m = m0 + wm * WTM + r;
                 if (m >= M || n >= p.Nout) continue;
-                const int64_t pix = out_pixel(m);
+                const int64_t pix = out_pixel(wm * WTM + r, m);
                 uint4 v = *reinterpret_cast<const uint4*>(stage + r * EP_LD + ch * 8);
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n;
                 if (!ID && p.pool_idx) {
@@ -620,8 +663,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 // pixel-major LDS rows of 128 channels + 32 pad: row stride 320 B = 64 B (mod 256 B), so the 4 rows x 32 B a 16-lane group of
 // ds_read_b64_tr_b16 touches (and the neighbouring group's +32 B) fall on 8 disjoint bank ranges -> conflict free
 #define WG_LD 160
-template <int BM>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
+// exact n / d for 0 <= n < 2^31 as mulhi(n, m) >> s (host: wg_magic): output pixels per image and per row — the X gather decomposes
+// its pixel index without the loop-carried (image, row, column) walk of the first version, whose `while` carries compiled to a chain of
+// divergent branches (5 per K step; ~270 instructions per K step for 8 MFMAs).
+struct WgMagic { unsigned m_img, s_img, m_row, s_row; };
+// P1: single tap (0, 0), stride 1, input grid == output grid (every 1x1 layer: 40 of yolov7's 46 generic weight gradients): the X row of
+// output pixel m IS input pixel m — both operands walk their tensors with plain pointer increments.
+template <int BM, bool P1>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, const WgMagic mg)
 {
     constexpr int BN = 128;
     constexpr int WM = BM == 128 ? 2 : 1, WN = 4 / WM;
@@ -668,9 +717,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         b_tap[u] = qq / cchunks;
         b_c0[u] = (qq - b_tap[u] * cchunks) * BK + (id & 3) * 8;
     }
-    int b_dh[2], b_dw[2];
+    int b_dh[2] = {0, 0}, b_dw[2] = {0, 0};
+    if constexpr (!P1) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) { b_dh[u] = p.dh[b_tap[u]]; b_dw[u] = p.dw[b_tap[u]]; }
+        for (int u = 0; u < 2; u++) { b_dh[u] = p.dh[b_tap[u]]; b_dw[u] = p.dw[b_tap[u]]; }
+    }
     // Loop-carried gather state (no division and no 64-bit multiply chain per K step — the first version of this loop
     // recomputed (img, oh, ow) from the pixel index with two integer divisions per piece per step):
     //   A pieces walk dY rows linearly: pointer += BK*ldY per step;
@@ -687,15 +738,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         a_ptr[u] = p.dY + (kbeg + px) * (int64_t)p.ldY + i0 + pc * 8;
     }
     const int b_px = (tid & 127) >> 2;
-    int b_img, b_oh, b_ow;
-    {
-        const int64_t m = kbeg + b_px;
-        b_img = (int)(m / ((int64_t)p.OH * p.OW));
-        const int rem = (int)(m - (int64_t)b_img * p.OH * p.OW);
-        b_oh = rem / p.OW;
-        b_ow = rem - b_oh * p.OW;
+    const unsigned HWo = (unsigned)(p.OH * p.OW);
+    const bf16_t* b_ptr[2] = {nullptr, nullptr};
+    if constexpr (P1) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) b_ptr[u] = p.X + (kbeg + b_px) * (int64_t)p.ldX + b_c0[u];
     }
-    int64_t m_step = kbeg;                                   // first pixel of the step being loaded
+    int64_t m_step = kbeg;                                   // first pixel of the step being loaded (M < 2^31: host check)
     auto gload = [&](RegSet& rs) {
         // loads are UNCONDITIONAL (invalid pieces read a safe address and are zeroed when stored): a branch around a load makes
         // hipcc fall back to s_waitcnt vmcnt(0) at the join, which would serialise the three-deep pipeline again
@@ -708,21 +757,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             a_ptr[u] += (int64_t)BK * p.ldY;
         }
         const bool pix_ok = m_step + b_px < kend;
+        if constexpr (P1) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int ih = b_oh * p.sh + b_dh[u], iw = b_ow * p.sw + b_dw[u];
-            const bool v = pix_ok && b_chunk_ok[u] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            const bf16_t* src = v ? p.X + (((int64_t)b_img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0[u] : p.X;
-            rs.b[u] = *reinterpret_cast<const uint4*>(src);
-            ok |= v ? (0x100u << u) : 0u;
+            for (int u = 0; u < 2; u++) {
+                const bool v = pix_ok && b_chunk_ok[u];
+                rs.b[u] = *reinterpret_cast<const uint4*>(v ? b_ptr[u] : p.X);
+                ok |= v ? (0x100u << u) : 0u;
+                b_ptr[u] += (int64_t)BK * p.ldX;
+            }
+        } else {
+            // (image, row, column) of output pixel m_step + b_px: two exact multiply-high divisions, no loop-carried state
+            const unsigned m = (unsigned)(m_step + b_px);
+            const unsigned b_img = mg.m_img ? __umulhi(m, mg.m_img) >> mg.s_img : m;          // (m_* == 0: division by one)
+            const unsigned rem = m - b_img * HWo;
+            const unsigned b_oh = mg.m_row ? __umulhi(rem, mg.m_row) >> mg.s_row : rem;
+            const unsigned b_ow = rem - b_oh * (unsigned)p.OW;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int ih = (int)b_oh * p.sh + b_dh[u], iw = (int)b_ow * p.sw + b_dw[u];
+                const bool v = pix_ok && b_chunk_ok[u] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+                const bf16_t* src = v ? p.X + (((int64_t)b_img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0[u] : p.X;
+                rs.b[u] = *reinterpret_cast<const uint4*>(src);
+                ok |= v ? (0x100u << u) : 0u;
+            }
         }
         rs.ok = ok;
         m_step += BK;
-        b_ow += BK;
-        while (b_ow >= p.OW) {
-            b_ow -= p.OW;
-            if (++b_oh >= p.OH) { b_oh = 0; b_img++; }
-        }
     };
     auto sstore = [&](int buf, const RegSet& rs) {
 #pragma unroll
@@ -841,6 +901,141 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     }
 }
 
+// ---- 1x1 (pointwise) weight gradient on an LDS-DMA ring -------------------------------------------------------------------
+// dW[co][ci] = sum_p dY[p][co] * X[p][ci] for single-tap stride-1 layers (40 of yolov7's 46 generic weight gradients).  The
+// register-staged kernel above spends ~200 instructions per 32-pixel K step (global loads into VGPRs, validity selects, four
+// ds_write_b128, the gather bookkeeping) around 8 MFMAs; with both operands plain [pixel][channel] rows the stage can be filled by
+// global_load_lds straight into the layout the transposed fragment reads want — the design of conv3x3_wgrad_kernel without its halo
+// ring: a stage = 4 + 4 channel quarters of [32 pixels][64 B] (lane-linear 1-KiB DMA pieces = 16 pixel rows x 64 B, conflict-free for
+// ds_read_b64_tr_b16), 3 stages, counted vmcnt, one barrier per step.  Workgroup tile 128 co x 128 ci, wave (wm, wn) owns 64 x 64:
+// per step and wave 4 DMA pieces + 16 transposed reads + 8 MFMAs.  Split-K slabs + the deterministic reduce as before.
+#define W1_NS 3
+__global__ __launch_bounds__(256, 3) void wgrad1x1_dma_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char w1_lds[W1_NS * 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t M = (int64_t)p.NB * p.OH * p.OW;
+    const int gx = (p.Cout + 127) / 128, gy = (p.Cin + 127) / 128;
+    const int t_id = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t_id % gx, by = (t_id / gx) % gy, bz = t_id / (gx * gy);
+    const int i0 = bx * 128, j0 = by * 128;
+    const int64_t kbeg = (int64_t)bz * p.kchunk;
+    const int64_t kend = min(M, kbeg + p.kchunk);
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg + 31) >> 5);
+
+    // DMA pieces: id = 4 * wave + u; ids 0-7 = dY, ids 8-15 = X; piece k of an operand = pixel rows 4k .. 4k + 3 of the stage, WHOLE
+    // 256-byte rows (128 channels): lane -> (row = lane >> 4, 64-byte quarter position = (lane >> 2) & 3, 16-byte slot = lane & 3).
+    // (A first version cut the stage into per-quarter [32 px][64 B] blocks like conv3x3_wgrad_kernel: its pieces fetched 16 rows x 64
+    // bytes — four half-line requests per 256-byte row — and lost 8 % on the HBM-bound high-resolution layers against the
+    // register-staged kernel, whose loads walk whole rows.)  The LDS image is lane-linear, i.e. plain [pixel][256 B] rows; four
+    // consecutive rows of one quarter would sit on the same banks, so the quarter POSITION is swizzled with the row on the source
+    // side: position qp of row r holds channel quarter qp ^ (r & 3); the reader applies the same XOR (its rows are 4-aligned groups).
+    const int prow = lane >> 4, qpos = (lane >> 2) & 3, slot = lane & 3;
+    const int qsrc = qpos ^ (prow & 3);                            // (piece rows start at multiples of 4: r & 3 == prow & 3)
+    const bf16_t* src[4];
+    bool chan_ok[4];
+    int pix0[4];                                                   // pixel (relative to kbeg) of this lane's row in stage 0
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int id = 4 * wave + u, k = id & 7;
+        pix0[u] = 4 * k + prow;
+        if (id < 8) {
+            chan_ok[u] = i0 + 32 * qsrc + slot * 8 < p.CoutPad;
+            src[u] = p.dY + (kbeg + pix0[u]) * (int64_t)p.ldY + i0 + 32 * qsrc + slot * 8;
+        } else {
+            chan_ok[u] = j0 + 32 * qsrc < p.Cin;
+            src[u] = p.X + (kbeg + pix0[u]) * (int64_t)p.ldX + j0 + 32 * qsrc + slot * 8;
+        }
+    }
+    const int64_t step_a = 32 * (int64_t)p.ldY, step_b = 32 * (int64_t)p.ldX;
+    const int npix = (int)(kend - kbeg);
+    int issued = 0;                                                // stages issued so far
+    auto issue_stage = [&]() {
+        unsigned char* st = w1_lds + (issued % W1_NS) * 16384;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int id = 4 * wave + u;
+            const bool ok = chan_ok[u] && pix0[u] + 32 * issued < npix;
+            const bf16_t* s_ = ok ? src[u] : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)s_, (lds_void_t*)(st + id * 1024), 16, 0, 0);
+            src[u] += id < 8 ? step_a : step_b;
+        }
+        issued++;
+    };
+    issue_stage();
+    if (nk > 1) issue_stage();
+
+    // transposed fragment reads (conv_internal.h): lane -> pixel row (grp >> 1) * 8 + (s16 >> 2) [+ 16 ks, + 4 for the second read],
+    // channels 16 (grp & 1) + 4 (s16 & 3) .. + 3 of the quarter.  Row stride 256 B; quarter q of row r sits at position q ^ (r & 3)
+    const int s16 = lane & 15, grp = lane >> 4;
+    const unsigned fr_row = (unsigned)((grp >> 1) * 8 + (s16 >> 2));
+    const unsigned fr_col = (unsigned)((16 * (grp & 1) + 4 * (s16 & 3)) * 2);
+    unsigned fa[2], fbq[2];                                        // byte offsets inside an operand's 8-KiB stage half for ks = 0, first read
+#pragma unroll
+    for (int i = 0; i < 2; i++) fa[i] = fr_row * 256u + (unsigned)(((2 * wm + i) ^ (int)(fr_row & 3u)) * 64) + fr_col;
+#pragma unroll
+    for (int j = 0; j < 2; j++) fbq[j] = fr_row * 256u + (unsigned)(((2 * wn + j) ^ (int)(fr_row & 3u)) * 64) + fr_col;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    for (int s = 0; s < nk; s++) {
+        if (s + 1 >= nk) gemm_wait_vm<0>();                        // the stage issued during step s - 1 (operands of step s + 1) may stay in flight
+        else gemm_wait_vm<4>();
+        __builtin_amdgcn_s_barrier();                               // stage s visible to every wave; stage s - 1 fully consumed
+        if (s + 2 < nk) issue_stage();
+        const unsigned base = lds_addr(w1_lds + (s % W1_NS) * 16384);
+        // fragments through the asm reads (the builtin would make hipcc drain vmcnt(0), i.e. the DMA just issued: conv_internal.h); second
+        // read of a fragment = 4 rows further (1024 B: same row & 3, same quarter position), ks = 1: 16 rows further (4096 B)
+        bf16x8 af[2][2], bq[2][2];
+        // (lgkmcnt is a 4-bit counter: never more than 12 of this wave's reads in flight)
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[0][i] = lds_tr16x2(base + fa[i], 1024u);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bq[0][j] = lds_tr16x2(base + 8192u + fbq[j], 1024u);
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[1][i] = lds_tr16x2(base + fa[i] + 4096u, 1024u);
+        lds_wait2<4>(af[0][0], af[0][1]);                           // later reads: the four of af[1][*]
+        lds_wait2<4>(bq[0][0], bq[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bq[1][j] = lds_tr16x2(base + 8192u + fbq[j] + 4096u, 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bq[0][j], acc[i][j], 0, 0, 0);
+        lds_wait2<0>(af[1][0], af[1][1]);
+        lds_wait2<0>(bq[1][0], bq[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bq[1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // split-K partial tile -> workspace [z][Cout][Cin] fp32: acc[i][j][e] = (co = i0 + 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), ci = j0 + 64 wn + 32 j + (lane & 31))
+    float* part = p.partial + (int64_t)bz * p.Cout * p.Cin;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int ci = j0 + 64 * wn + 32 * j + (lane & 31);
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int co = i0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (co < p.Cout) part[(int64_t)co * p.Cin + ci] = acc[i][j][e];
+            }
+    }
+}
+
 // dW[co][cin][tap] += sum_z partial[z][co][tap*Cin + cin]   (torch weight layout; fixed summation order => deterministic).
 // One workgroup per (co, CH-channel chunk): P = ntaps*CH/4 float4 positions x ZL split lanes stream the split-K slabs with
 // 16-byte loads (the first version used 4-byte loads, 32 channel lanes x 32 split lanes: 1.9 TB/s over 5.5 GB of slabs per step,
@@ -913,6 +1108,18 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const dim3 grid((unsigned)(gm * gn), 1, p.nclasses);
     const bool ident = p.nclasses == 1 && p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && p.cls[0].oh_add == 0 &&
                        p.cls[0].ow_add == 0 && !p.pool_idx && !p.s2d_cin;
+    // single tap (0, 0) on the identity grid, input grid == output grid: the 1x1 instantiations (no tile decomposition, no tap table)
+    static const bool t1_on = !(getenv("RYOLO_GEMM_T1") && atoi(getenv("RYOLO_GEMM_T1")) == 0);      // A/B knob
+    const bool t1 = PIPE == 1 && ident && t1_on && p.cls[0].ntaps == 1 && p.cls[0].dh[0] == 0 && p.cls[0].dw[0] == 0 && p.cls[0].widx[0] == 0 &&
+                    p.sh == 1 && p.sw == 1 && p.IH == p.OH && p.IW == p.OW;
+    if constexpr (PIPE == 1) {
+        if (t1) {
+            if (p.nbstat) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true, true>), grid, dim3(256), 0, stream, p);
+            else if (p.epi == EPI_ACCUM) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true, true>), grid, dim3(256), 0, stream, p);
+            return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
+        }
+    }
     if (p.nbstat) {                                             // (identity grid by gemm_check; the pool gradient may ride along)
         if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, false>), grid, dim3(256), 0, stream, p);
@@ -1095,10 +1302,36 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
         RY_CHECK_LAUNCH();
         return RY_OK;
     }
-    if (bm == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<128>), dim3((unsigned)((int64_t)gx * gy * p.splitk)), dim3(256), 0, stream, p);
+    if ((int64_t)p.NB * p.OH * p.OW >= (1ll << 31)) return RY_ERR_UNSUPPORTED;       // 32-bit pixel indices in the gather
+    auto wg_magic = [](unsigned d, unsigned& m, unsigned& sh) {      // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31
+        if (d < 2) { m = 0; sh = 0; return; }                        // division by one: flagged with m == 0
+        unsigned l = 0;
+        while ((1ull << l) < d) l++;
+        m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+        sh = l - 1;
+    };
+    WgMagic mg;
+    wg_magic((unsigned)(p.OH * p.OW), mg.m_img, mg.s_img);
+    wg_magic((unsigned)p.OW, mg.m_row, mg.s_row);
+    const bool p1 = p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.sh == 1 && p.sw == 1 && p.IH == p.OH && p.IW == p.OW && p.OH * p.OW > 1 &&
+                    !(getenv("RYOLO_WGRAD_P1") && (atoi(getenv("RYOLO_WGRAD_P1")) & 1) == 0);
+    const dim3 wgrid((unsigned)((int64_t)gx * gy * p.splitk));
+    // pointwise layers wider than 64 output channels: the LDS-DMA ring kernel (same tiles, same slabs: bm == 128 gives gx = ceil(Cout / 128),
+    // gy = ceil(Cin / 128) there too); 0x2 in RYOLO_WGRAD_P1 switches it off for A/B runs
+    static const int p1_mode = getenv("RYOLO_WGRAD_P1") ? atoi(getenv("RYOLO_WGRAD_P1")) : 3;
+    if (p1 && bm == 128 && (p1_mode & 2) && p.zeros && ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0) {
+        hipLaunchKernelGGL(wgrad1x1_dma_kernel, wgrid, dim3(256), 0, stream, p);
+        launch_wgrad_reduce(p, p.splitk, stream);
+        RY_CHECK_LAUNCH();
+        return RY_OK;
+    }
+    if (bm == 64) {
+        if (p1) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), wgrid, dim3(256), 0, stream, p, mg);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), wgrid, dim3(256), 0, stream, p, mg);
+    } else {
+        if (p1) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), wgrid, dim3(256), 0, stream, p, mg);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), wgrid, dim3(256), 0, stream, p, mg);
+    }
     launch_wgrad_reduce(p, p.splitk, stream);
     RY_CHECK_LAUNCH();
     return RY_OK;

@@ -559,38 +559,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
     // while-loops and cost ~1600 cycles of DMA issue per K step — cycle counters).
     const int prow_l = lane >> 2, slot = lane & 3;
     const int kend32 = (int)kend, Mp32 = (int)g.Mp;               // Mp < 2^31 (host check)
-    struct Cur { int q, img, ihp, iwp; };
-    auto decomp = [&](int qa, Cur& c) {
-        const int per = HPp * PWp;
-        const int q = qa < 0 ? 0 : qa;
-        c.q = qa;
-        c.img = q / per;
-        const int rem = q - c.img * per;
-        c.ihp = rem / PWp;
-        c.iwp = rem - c.ihp * PWp;
+    // Branch-free: a stream keeps only the padded index q of this lane's row; (image, padded row, padded column) come from two exact
+    // multiply-high divisions by the launch constants (W3Geom.m_img / m_row) — the first version carried (img, ihp, iwp) through
+    // while-loops, which compile to divergent branch chains: ~200 of the ~430 instructions of a K step were DMA address generation.
+    const unsigned per = (unsigned)(HPp * PWp);
+    auto locate = [&](int q, int limit, bool& ok) -> int {            // pixel index of padded position q (valid iff ok)
+        const unsigned uq = (unsigned)q;
+        const unsigned img = __umulhi(uq, g.m_img) >> g.s_img;
+        const unsigned rem = uq - img * per;
+        const unsigned ihp = __umulhi(rem, g.m_row) >> g.s_row;
+        const unsigned iwp = rem - ihp * (unsigned)PWp;
+        ok = uq < (unsigned)limit && (ihp - 1u) < (unsigned)H && (iwp - 1u) < (unsigned)W;     // (negative q: uq >= 2^31 > limit)
+        return (int)((img * (unsigned)H + ihp - 1u) * (unsigned)W + iwp - 1u);                // < 2^31 when ok (host check)
     };
-    auto advance = [&](Cur& c, int by) {                          // by >= 0, c.q >= 0 (a loop that rarely iterates beat a branch-free
-        c.q += by;                                                // triple select: 582 vs 544 TF/s at 128->128 @100^2)
-        c.iwp += by;
-        while (c.iwp >= PWp) {
-            c.iwp -= PWp;
-            if (++c.ihp >= HPp) { c.ihp = 0; c.img++; }
-        }
-    };
-    auto interior = [&](const Cur& c) { return (unsigned)(c.ihp - 1) < (unsigned)H && (unsigned)(c.iwp - 1) < (unsigned)W; };
-    auto pixel = [&](const Cur& c) { return (c.img * H + c.ihp - 1) * W + c.iwp - 1; };     // < 2^31 (host check)
     // dY rows of step s, half u: padded pixel kbeg + 32 s + 16 u + prow_l
-    Cur dc[NDY];
+    int dq[NDY];
 #pragma unroll
-    for (int u = 0; u < NDY; u++) decomp((int)kbeg + 16 * (CO64 ? kh : u) + prow_l, dc[u]);
+    for (int u = 0; u < NDY; u++) dq[u] = (int)kbeg + 16 * (CO64 ? kh : u) + prow_l;
     const bool d_chan_ok = (i0 + 32 * cow + slot * 8) < p.CoutPad;
     const bf16_t* const dy_base = p.dY + i0 + 32 * cow + slot * 8;
     const bf16_t* const x_base = p.X + ci0 + slot * 8;
     auto issue_dy1 = [&](int stage, int u) {
-        const bool ok = d_chan_ok && dc[u].q < kend32 && interior(dc[u]);
-        const bf16_t* src = ok ? dy_base + (int64_t)pixel(dc[u]) * p.ldY : p.zeros;
+        bool ok;
+        const int pix = locate(dq[u], kend32, ok);
+        const bf16_t* src = (ok && d_chan_ok) ? dy_base + (int64_t)pix * p.ldY : p.zeros;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + cow * 2048 + (CO64 ? kh : u) * 1024), 16, 0, 0);
-        advance(dc[u], 32);
+        dq[u] += 32;
     };
     auto issue_dy = [&](int stage) {
 #pragma unroll
@@ -601,23 +595,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
     // of steps 0 and 1 with their halos); steady state: waves 0 and 1 append the next 32 rows each step (for step s + 2).
     const int x0 = (int)(((kbeg - HALO) >> 5) << 5);                 // aligned down to 32 (arithmetic shift: also for negatives)
     const int pro_iters = ((int)kbeg + 64 + HALO - x0 + 63) >> 6;
-    Cur xc;
-    decomp(x0 + 16 * wave + prow_l, xc);                             // this lane's row in its current piece
+    int xq = x0 + 16 * wave + prow_l;                                // this lane's row in its current piece
     auto issue_x = [&]() {
-        const bool ok = xc.q >= 0 && xc.q < Mp32 && interior(xc);
-        const bf16_t* src = ok ? x_base + (int64_t)pixel(xc) * p.ldX : p.zeros;
-        const unsigned row0 = (unsigned)(xc.q - prow_l) & rmask;      // wave-uniform, 16-aligned
+        bool ok;
+        const int pix = locate(xq, Mp32, ok);
+        const bf16_t* src = ok ? x_base + (int64_t)pix * p.ldX : p.zeros;
+        const unsigned row0 = (unsigned)(xq - prow_l) & rmask;        // wave-uniform, 16-aligned
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring + row0 * 64), 16, 0, 0);
     };
-    auto step_x = [&](int by) {
-        if (xc.q < 0) { if (xc.q + by >= 0) decomp(xc.q + by, xc); else xc.q += by; }
-        else advance(xc, by);
-    };
+    auto step_x = [&](int by) { xq += by; };
     for (int it = 0; it < pro_iters; it++) {
         issue_x();
         step_x(64);
     }
-    // now xc.q = x0 + 64 * pro_iters + 16 * wave + prow_l: exactly where waves 0 and 1 continue
+    // now xq = x0 + 64 * pro_iters + 16 * wave + prow_l: exactly where waves 0 and 1 continue
     issue_dy(0);
     if (nk > 1) issue_dy(1);
 
@@ -806,6 +797,14 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.kchunk = ry_cdiv(ry_cdiv(g.Mp, sk), 32) * 32;
     g.splitk = (int)ry_cdiv(g.Mp, g.kchunk);
     for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
+    auto magic = [](unsigned d, unsigned& m, unsigned& sh) {         // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (d >= 3 here: padded sizes)
+        unsigned l = 0;
+        while ((1ull << l) < d) l++;
+        m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+        sh = l - 1;
+    };
+    magic((unsigned)(g.HPp * g.PWp), g.m_img, g.s_img);
+    magic((unsigned)g.PWp, g.m_row, g.s_row);
     g.lds_bytes = W3_NS * (g.co64 ? 4096u : 8192u) + (unsigned)g.RX * 64u;
     g.slabs = g.splitk * (g.co64 ? 2 : 1);
     g.ok = 1;

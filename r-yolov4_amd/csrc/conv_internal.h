@@ -193,6 +193,9 @@ struct W3Geom {
     int64_t kchunk;            // padded pixels per split (multiple of 32)
     int toff[9];               // dh * PWp + dw per tap (caller's tap order)
     unsigned lds_bytes;
+    // exact n / d for 0 <= n < 2^31 as (mulhi(n, m) >> s): d = HPp * PWp (padded pixels per image) and d = PWp (padded row length) —
+    // the DMA address generation decomposes a padded pixel index without loops or branches
+    unsigned m_img, s_img, m_row, s_row;
 };
 bool w3_geometry(const WgradParams& p, W3Geom& g);
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);

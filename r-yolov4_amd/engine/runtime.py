@@ -63,7 +63,15 @@ class Runtime:
         once per model and shared by all of its plans."""
         st = self._side_streams.get(lane)
         if st is None:
-            st = self._side_streams[lane] = torch.cuda.Stream(device=self.device)
+            # RYOLO_SIDE_PRIO: HIP stream priority of the engine's extra streams (0 = default; positive = lower than the main stream where
+            # the runtime offers it): a lower-priority weight-gradient stream fills the tails of the main stream's launches instead of
+            # competing with them for compute units (A/B in DESIGN.md)
+            prio = int(os.environ.get("RYOLO_SIDE_PRIO", "0"))
+            try:
+                st = torch.cuda.Stream(device=self.device, priority=prio)
+            except Exception:
+                st = torch.cuda.Stream(device=self.device)
+            self._side_streams[lane] = st
         return st
 
     # ------------------------------------------------------------------ parameters
@@ -261,12 +269,18 @@ class NetFunction(torch.autograd.Function):
         g.run(g.fwd, g.timer)
         if g.batch_stats:
             rt.nbt += 1
-        ctx.rt, ctx.g = rt, g
+        # the plan's buffers hold THIS forward's activations until its backward ran: a later forward of the same plan overwrites them
+        g.generation = getattr(g, "generation", 0) + 1
+        ctx.rt, ctx.g, ctx.generation = rt, g, g.generation
         return tuple(h["out"].detach() for h in g.heads)      # fresh tensor objects over the plan's output buffers
 
     @staticmethod
     def backward(ctx, *grads):
         rt, g = ctx.rt, ctx.g
+        if getattr(ctx, "generation", None) != getattr(g, "generation", None):
+            raise RuntimeError("ryolov4_amd: backward of a forward whose activations were overwritten — another forward with the same "
+                               "(batch, size, mode) ran on this model in between; run forward -> backward pairs in order (or use a "
+                               "different batch size for the interleaved forward)")
         rt.prepare_grads()
         for h, go in zip(g.heads, grads):
             if go is None:

@@ -101,7 +101,8 @@ def evaluate(forward, loss_fn, pp, stats_fn, batches, to_dev, host_ap):
 
 
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    torch.set_num_threads(min(32, os.cpu_count() or 1))          # torch-CPU oversubscribes on the 256-thread GPU hosts (bench.py's cpu_baseline notes)
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     ver = sys.argv[2] if len(sys.argv) > 2 else "yolov7"
     mode = sys.argv[3] if len(sys.argv) > 3 else "kfiou"
     csl = mode == "csl"
