@@ -107,85 +107,6 @@ static inline const float* fold_rows(const float* partial, int& rows, int KC, fl
     return scratch;
 }
 
-// ------------------------------------------------------------------------------------------------ fold + finalize in ONE launch
-// The finalize kernels want few partial rows; big layers produce tens of thousands (one per GEMM M tile).  fold_rows_kernel + a finalize
-// launch cost two dependent ~5 us launches per BatchNorm and direction (~350 per step).  The fused form: grid (channel groups of 32, FS
-// slices); every workgroup sums its slice of the rows in double, publishes [K][32] doubles, takes a ticket; the LAST workgroup of a channel
-// group adds the FS published rows in slice order (deterministic whoever arrives last) and runs the finalize arithmetic.
-// Cross-workgroup visibility (MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup visibility"): the published values are
-// agent-scope (sc1, write-through) 8-byte atomic stores, drained with s_waitcnt vmcnt(0) by the publishing wave before ITS lane 0 takes
-// the ticket (a returning agent-scope atomic); the last workgroup executes an agent-scope acquire fence and reads them back with
-// agent-scope atomic loads (L1 bypassed).  The ticket words are zeroed by a memset node in front of the launch (no state survives a call).
-#define FS 31                                     // slices; 31 x [K <= 3][32] doubles + the ticket words fit the 64 scratch rows callers append
-template <int K>
-__device__ __forceinline__ bool fold_publish_and_elect(const double (&mine)[K], double* __restrict__ pub /*[FS][K][32]*/, unsigned* __restrict__ ticket,
-                                                       int cl, bool writer, unsigned* lds_flag)
-{
-    // called by every thread of a 1024-thread workgroup; `writer`: threads 0..31 (row lane 0 = the first half of wave 0) hold the slice sums
-    if (writer) {
-#pragma unroll
-        for (int q = 0; q < K; q++)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(pub + ((int64_t)blockIdx.y * K + q) * 32 + cl),
-                               (unsigned long long)__double_as_longlong(mine[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < 64) {                       // wave 0: its stores are complete before its ticket
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) *lds_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const bool last = *lds_flag == (unsigned)gridDim.y - 1u;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return last;
-}
-__device__ __forceinline__ double fold_read(const double* __restrict__ pub, int slice, int K, int q, int cl)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(pub + ((int64_t)slice * K + q) * 32 + cl),
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// forward: partial [rows][2][ld] -> coefficients of channels [c0, c0 + C) (see bn_finalize_kernel below for the arithmetic)
-__global__ __launch_bounds__(1024) void bn_fold_finalize_kernel(const float* __restrict__ partial, int rows, int ld, int c0, int C, double count, float eps,
-                                                                float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                float* __restrict__ out /*[4][C]*/, double* __restrict__ pub_all, unsigned* __restrict__ tickets)
-{
-    __shared__ double red[2][1024];
-    __shared__ unsigned flag;
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double acc[2] = {0.0, 0.0};
-    if (c < C)
-        for (int r = blockIdx.y * 32 + rl; r < rows; r += 32 * FS) {
-            acc[0] += (double)partial[((int64_t)r * 2 + 0) * ld + c0 + c];
-            acc[1] += (double)partial[((int64_t)r * 2 + 1) * ld + c0 + c];
-        }
-    red[0][threadIdx.x] = acc[0];
-    red[1][threadIdx.x] = acc[1];
-    __syncthreads();
-    if (rl == 0)
-        for (int k = 1; k < 32; k++) { acc[0] += red[0][k * 32 + cl]; acc[1] += red[1][k * 32 + cl]; }
-    double* pub = pub_all + (int64_t)blockIdx.x * FS * 2 * 32;
-    if (!fold_publish_and_elect<2>(acc, pub, tickets + blockIdx.x, cl, rl == 0, &flag)) return;
-    if (rl == 0 && c < C) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < FS; k++) { s += fold_read(pub, k, 2, 0, cl); q += fold_read(pub, k, 2, 1, cl); }
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        out[0 * C + c] = (float)mean;
-        out[1 * C + c] = invstd;
-        out[2 * C + c] = sc;
-        out[3 * C + c] = beta[c] - (float)mean * sc;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ BN finalize
 // partial [rows][2][C] (sum, sumsq of the stored bf16 conv output) -> mean/invstd/scale/shift; running stats update
 // (momentum 0.1, unbiased variance — nn.BatchNorm2d defaults used by model/utils.py:17)
@@ -382,54 +303,6 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
         double gx2 = 0.0;
         if constexpr (K == 3) gx2 = (double)co2[C + c] * (s[2] - (double)co2[c] * s[0]);
         // frozen statistics (eval-mode BatchNorm used as a fixed affine map): no coupling through the batch mean/variance
-        const double rc = 1.0 / count;
-        bco[0 * C + c] = frozen ? 0.f : (float)(s[0] * rc);
-        bco[1 * C + c] = frozen ? 0.f : (float)(gx1 * rc);
-        if constexpr (K == 3) bco[2 * C + c] = frozen ? 0.f : (float)(gx2 * rc);
-        if (dgamma1) { dgamma1[c] += (float)gx1; dbeta1[c] += (float)s[0]; }
-        if constexpr (K == 3)
-            if (dgamma2) { dgamma2[c] += (float)gx2; dbeta2[c] += (float)s[0]; }
-    }
-}
-
-// the same with the block rows folded in the launch itself (see bn_fold_finalize_kernel): grid (C / 32, FS)
-template <int K>
-__global__ __launch_bounds__(1024) void bn_bwd_fold_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count, int frozen,
-                                                                    const float* __restrict__ co1, const float* __restrict__ co2,
-                                                                    float* __restrict__ bco, float* __restrict__ dgamma1, float* __restrict__ dbeta1,
-                                                                    float* __restrict__ dgamma2, float* __restrict__ dbeta2,
-                                                                    double* __restrict__ pub_all, unsigned* __restrict__ tickets)
-{
-    __shared__ double red[K][1024];
-    __shared__ unsigned flag;
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s[K];
-#pragma unroll
-    for (int q = 0; q < K; q++) s[q] = 0.0;
-    if (c < C)
-        for (int r = blockIdx.y * 32 + rl; r < nblk; r += 32 * FS)
-#pragma unroll
-            for (int q = 0; q < K; q++) s[q] += (double)partial[((int64_t)r * K + q) * C + c];
-#pragma unroll
-    for (int q = 0; q < K; q++) red[q][threadIdx.x] = s[q];
-    __syncthreads();
-    if (rl == 0)
-#pragma unroll
-        for (int k = 1; k < 32; k++)
-#pragma unroll
-            for (int q = 0; q < K; q++) s[q] += red[q][k * 32 + cl];
-    double* pub = pub_all + (int64_t)blockIdx.x * FS * K * 32;
-    if (!fold_publish_and_elect<K>(s, pub, tickets + blockIdx.x, cl, rl == 0, &flag)) return;
-    if (rl == 0 && c < C) {
-#pragma unroll
-        for (int q = 0; q < K; q++) s[q] = 0.0;
-        for (int k = 0; k < FS; k++)
-#pragma unroll
-            for (int q = 0; q < K; q++) s[q] += fold_read(pub, k, K, q, cl);
-        const double gx1 = (double)co1[C + c] * (s[1] - (double)co1[c] * s[0]);
-        double gx2 = 0.0;
-        if constexpr (K == 3) gx2 = (double)co2[C + c] * (s[2] - (double)co2[c] * s[0]);
         const double rc = 1.0 / count;
         bco[0 * C + c] = frozen ? 0.f : (float)(s[0] * rc);
         bco[1 * C + c] = frozen ? 0.f : (float)(gx1 * rc);
@@ -1209,21 +1082,7 @@ extern "C" int ryolo_bn_finalize_slice(const float* partial, int rows, int ld, i
                                        hipStream_t stream)
 {
     if (!partial || !gamma || !beta || !coeffs || C <= 0 || rows <= 0 || c0 < 0 || c0 + C > ld) return RY_ERR_ARG;
-    // many rows: folded inside the launch (bn_fold_finalize_kernel); its publish area and ticket words live in the 64 scratch rows the
-    // caller appends to the partial buffer (rows + FOLD_S rows allocated): [C/32 groups][FS][2][32] doubles, then one word per group
-    static const bool fuse_fold = !(getenv("RYOLO_FUSE_FOLD") && atoi(getenv("RYOLO_FUSE_FOLD")) == 0);      // A/B knob
-    if (rows > 4 * FOLD_S && fuse_fold && (c0 & 31) == 0 && (ld & 31) == 0) {
-        float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * ld;
-        // (sibling BatchNorms share the statistics buffer: each owns the publish rows / tickets of ITS channel groups)
-        double* pub = reinterpret_cast<double*>(scratch) + (int64_t)(c0 / 32) * FS * 2 * 32;
-        unsigned* tickets = reinterpret_cast<unsigned*>(scratch + (int64_t)(FOLD_S - 1) * 2 * ld) + c0 / 32;
-        const unsigned ncg = (unsigned)ry_cdiv(C, 32);
-        if (hipMemsetAsync(tickets, 0, ncg * sizeof(unsigned), stream) != hipSuccess) return RY_ERR_LAUNCH;
-        hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3(ncg, FS), dim3(1024), 0, stream, partial, rows, ld, c0, C, count, eps, momentum, gamma, beta,
-                           running_mean, running_var, coeffs, pub, tickets);
-        RY_CHECK_LAUNCH();
-        return RY_OK;
-    }
+    // many rows: folded into a scratch area the caller appends to the partial buffer (rows + FOLD_S rows allocated)
     if (rows > 4 * FOLD_S) {
         float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * ld;
         partial = fold_rows(partial, rows, 2 * ld, scratch, stream);
@@ -1324,25 +1183,8 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     }
 #undef RY_RED
     int frows = nblk;
-    static const bool fuse_fold_b = !(getenv("RYOLO_FUSE_FOLD") && atoi(getenv("RYOLO_FUSE_FOLD")) == 0);
-    if (nblk > 4 * FOLD_S && fuse_fold_b && (p.C & 31) == 0) {
-        // fold + finalize in one launch; publish area + tickets in the nblk + 64 rows the caller allocates ([C/32][FS][K][32] doubles fill 62 of them)
-        float* scratch = p.partial + (int64_t)nblk * K * p.C;
-        double* pub = reinterpret_cast<double*>(scratch);
-        unsigned* tickets = reinterpret_cast<unsigned*>(scratch + (int64_t)(FOLD_S - 1) * K * p.C);
-        const unsigned ncg = (unsigned)(p.C / 32);
-        if (hipMemsetAsync(tickets, 0, ncg * sizeof(unsigned), stream) != hipSuccess) return RY_ERR_LAUNCH;
-        if (K == 3)
-            hipLaunchKernelGGL(bn_bwd_fold_finalize_kernel<3>, dim3(ncg, FS), dim3(1024), 0, stream, p.partial, nblk, p.C, (double)p.M, frozen, p.co1,
-                               p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2, pub, tickets);
-        else
-            hipLaunchKernelGGL(bn_bwd_fold_finalize_kernel<2>, dim3(ncg, FS), dim3(1024), 0, stream, p.partial, nblk, p.C, (double)p.M, frozen, p.co1,
-                               p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2, pub, tickets);
-        frows = -1;                                  // done
-    }
-    const float* fpart = frows < 0 ? nullptr : fold_rows(p.partial, frows, K * p.C, p.partial + (int64_t)nblk * K * p.C, stream);   // caller allocates nblk + 64 rows
-    if (frows < 0) {
-    } else if (K == 3)
+    const float* fpart = fold_rows(p.partial, frows, K * p.C, p.partial + (int64_t)nblk * K * p.C, stream);   // caller allocates nblk + 64 rows
+    if (K == 3)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<3>, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, fpart, frows, p.C,
                            (double)p.M, frozen, p.co1, p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2);
     else

@@ -2,7 +2,7 @@
 # HBM traffic of every kernel class of one training step: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes
 # (MI355X_MICROARCH.md: they do not fit one pass; never combined with sys/hip tracing).  Run on the GPU box from the repo root:
 #   bash tools/pmc_step.sh [round tag, default r02]   ->  gpurun_out/<tag>_pmc_step_traffic.json  (copy to profiles/)
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 STEPS=3
@@ -29,6 +29,11 @@ for k,v in raw.items():
 steps=kern.get("sgd_nesterov_kernel",{}).get("launches",0)
 doc={"_doc":"HBM traffic per launch from rocprofv3 PMC passes over bench.py (batch 64, yolov7 kfiou nc=16 800^2; launches of sgd_nesterov_kernel = steps_profiled, warm-up and loss read-back steps included): FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes (tools/pmc_step.sh); units KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so hbm_bytes = (2*FETCH + WRITE)*1024 (MI355X_MICROARCH.md, HBM section; the x2 applies to wide 16-B/lane reads, kernels with 4-byte gathers are over-counted by it)",
      "steps_profiled":steps,"kernels":kern}
+import hashlib
+h=hashlib.sha256()
+for f in sorted(glob.glob(R+"/r-yolov4_amd/csrc/*.hip")+glob.glob(R+"/r-yolov4_amd/csrc/*.h")+glob.glob(R+"/include/*.h")+glob.glob(R+"/r-yolov4_amd/engine/*.py")+glob.glob(R+"/r-yolov4_amd/model/*.py")):
+    h.update(open(f,"rb").read())
+doc["source_sha256"]=h.hexdigest()      # bench.py reports `traffic` only while the kernels and the plan are the ones that were profiled
 json.dump(doc,open(R+f"/gpurun_out/${TAG}_pmc_step_traffic.json","w"),indent=1)
 skip=("nms_","bitonic_","compose_kernel","topk_")
 tot=sum(v["hbm_bytes_per_launch"]*v["launches"] for k,v in kern.items() if not k.startswith(skip))/max(steps,1)
