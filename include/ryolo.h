@@ -131,7 +131,8 @@ int ryolo_pp_emit(const float* dets, const int64_t* keep, const int32_t* num_kee
  * classes on grid.z).  Epilogues (p->epi): 0 raw bf16, 1 raw + per-tile BatchNorm partial sums, 2 folded-BN + activation,
  * 3 fp32 + bias (detection heads), 4 bf16 accumulate (tensor with several consumers). */
 int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
-/* number of [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem under mainloop variant `pipe` */
+/* UPPER BOUND of the [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem (sizing only: the exact count, which
+ * the reduction must use, depends on the tile ryolo_conv_gemm picks and is ryolo_conv_gemm_plan's stats_rows) */
 int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows);
 /* which kernel ryolo_conv_gemm runs for *p (0 generic implicit GEMM, 1 the 3x3 stride-1 halo-patch kernel, enabled by pipe bit
  * 0x200 for eligible layers) and the number of partial-statistics rows its epilogue 1 writes; `kernel` may be null */

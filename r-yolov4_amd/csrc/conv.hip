@@ -909,10 +909,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
 // ring: a stage = 4 + 4 channel quarters of [32 pixels][64 B] (lane-linear 1-KiB DMA pieces = 16 pixel rows x 64 B, conflict-free for
 // ds_read_b64_tr_b16), 3 stages, counted vmcnt, one barrier per step.  Workgroup tile 128 co x 128 ci, wave (wm, wn) owns 64 x 64:
 // per step and wave 4 DMA pieces + 16 transposed reads + 8 MFMAs.  Split-K slabs + the deterministic reduce as before.
-#define W1_NS 3
-__global__ __launch_bounds__(256, 3) void wgrad1x1_dma_kernel(const WgradParams p)
+// PX = pixels per K step: 32 (three 16-KiB stages, two in flight, three workgroups per CU) or 64 (two 32-KiB stages, one in flight, two
+// workgroups per CU, 16 MFMAs per wave between barriers instead of 8 — the lesson of conv3x3_wgrad64_kernel).
+template <int PX>
+__global__ __launch_bounds__(256, PX == 64 ? 2 : 3) void wgrad1x1_dma_kernel(const WgradParams p)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char w1_lds[W1_NS * 16384];
+    constexpr int NS = PX == 64 ? 2 : 3;                           // ring stages
+    constexpr int OPB = PX * 256;                                  // bytes of one operand in a stage: [PX pixels][256 B]
+    constexpr int STB = 2 * OPB;                                   // stage bytes
+    constexpr int NP = PX / 8;                                     // DMA pieces per wave and step (PX / 4 per operand, 2 operands, 4 waves)
+    __shared__ __attribute__((aligned(1024))) unsigned char w1_lds[NS * STB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
@@ -923,10 +929,10 @@ __global__ __launch_bounds__(256, 3) void wgrad1x1_dma_kernel(const WgradParams 
     const int64_t kbeg = (int64_t)bz * p.kchunk;
     const int64_t kend = min(M, kbeg + p.kchunk);
     if (kbeg >= kend) return;
-    const int nk = (int)((kend - kbeg + 31) >> 5);
+    const int nk = (int)((kend - kbeg + PX - 1) / PX);
 
-    // DMA pieces: id = 4 * wave + u; ids 0-7 = dY, ids 8-15 = X; piece k of an operand = pixel rows 4k .. 4k + 3 of the stage, WHOLE
-    // 256-byte rows (128 channels): lane -> (row = lane >> 4, 64-byte quarter position = (lane >> 2) & 3, 16-byte slot = lane & 3).
+    // DMA pieces: id = NP * wave + u; the first PX / 4 ids = dY, the rest = X; piece k of an operand = pixel rows 4k .. 4k + 3 of the stage,
+    // WHOLE 256-byte rows (128 channels): lane -> (row = lane >> 4, 64-byte quarter position = (lane >> 2) & 3, 16-byte slot = lane & 3).
     // (A first version cut the stage into per-quarter [32 px][64 B] blocks like conv3x3_wgrad_kernel: its pieces fetched 16 rows x 64
     // bytes — four half-line requests per 256-byte row — and lost 8 % on the HBM-bound high-resolution layers against the
     // register-staged kernel, whose loads walk whole rows.)  The LDS image is lane-linear, i.e. plain [pixel][256 B] rows; four
@@ -934,14 +940,14 @@ __global__ __launch_bounds__(256, 3) void wgrad1x1_dma_kernel(const WgradParams 
     // side: position qp of row r holds channel quarter qp ^ (r & 3); the reader applies the same XOR (its rows are 4-aligned groups).
     const int prow = lane >> 4, qpos = (lane >> 2) & 3, slot = lane & 3;
     const int qsrc = qpos ^ (prow & 3);                            // (piece rows start at multiples of 4: r & 3 == prow & 3)
-    const bf16_t* src[4];
-    bool chan_ok[4];
-    int pix0[4];                                                   // pixel (relative to kbeg) of this lane's row in stage 0
+    const bf16_t* src[NP];
+    bool chan_ok[NP];
+    int pix0[NP];                                                  // pixel (relative to kbeg) of this lane's row in stage 0
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int id = 4 * wave + u, k = id & 7;
+    for (int u = 0; u < NP; u++) {
+        const int id = NP * wave + u, k = id % (PX / 4);
         pix0[u] = 4 * k + prow;
-        if (id < 8) {
+        if (id < PX / 4) {
             chan_ok[u] = i0 + 32 * qsrc + slot * 8 < p.CoutPad;
             src[u] = p.dY + (kbeg + pix0[u]) * (int64_t)p.ldY + i0 + 32 * qsrc + slot * 8;
         } else {
@@ -949,30 +955,30 @@ __global__ __launch_bounds__(256, 3) void wgrad1x1_dma_kernel(const WgradParams 
             src[u] = p.X + (kbeg + pix0[u]) * (int64_t)p.ldX + j0 + 32 * qsrc + slot * 8;
         }
     }
-    const int64_t step_a = 32 * (int64_t)p.ldY, step_b = 32 * (int64_t)p.ldX;
+    const int64_t step_a = PX * (int64_t)p.ldY, step_b = PX * (int64_t)p.ldX;
     const int npix = (int)(kend - kbeg);
     int issued = 0;                                                // stages issued so far
     auto issue_stage = [&]() {
-        unsigned char* st = w1_lds + (issued % W1_NS) * 16384;
+        unsigned char* st = w1_lds + (issued % NS) * STB;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int id = 4 * wave + u;
-            const bool ok = chan_ok[u] && pix0[u] + 32 * issued < npix;
+        for (int u = 0; u < NP; u++) {
+            const int id = NP * wave + u;
+            const bool ok = chan_ok[u] && pix0[u] + PX * issued < npix;
             const bf16_t* s_ = ok ? src[u] : p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)s_, (lds_void_t*)(st + id * 1024), 16, 0, 0);
-            src[u] += id < 8 ? step_a : step_b;
+            src[u] += id < PX / 4 ? step_a : step_b;
         }
         issued++;
     };
     issue_stage();
-    if (nk > 1) issue_stage();
+    if (NS == 3 && nk > 1) issue_stage();
 
     // transposed fragment reads (conv_internal.h): lane -> pixel row (grp >> 1) * 8 + (s16 >> 2) [+ 16 ks, + 4 for the second read],
     // channels 16 (grp & 1) + 4 (s16 & 3) .. + 3 of the quarter.  Row stride 256 B; quarter q of row r sits at position q ^ (r & 3)
     const int s16 = lane & 15, grp = lane >> 4;
     const unsigned fr_row = (unsigned)((grp >> 1) * 8 + (s16 >> 2));
     const unsigned fr_col = (unsigned)((16 * (grp & 1) + 4 * (s16 & 3)) * 2);
-    unsigned fa[2], fbq[2];                                        // byte offsets inside an operand's 8-KiB stage half for ks = 0, first read
+    unsigned fa[2], fbq[2];                                        // byte offsets inside an operand's stage half for ks = 0, first read
 #pragma unroll
     for (int i = 0; i < 2; i++) fa[i] = fr_row * 256u + (unsigned)(((2 * wm + i) ^ (int)(fr_row & 3u)) * 64) + fr_col;
 #pragma unroll
@@ -986,39 +992,42 @@ __global__ __launch_bounds__(256, 3) void wgrad1x1_dma_kernel(const WgradParams 
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
     for (int s = 0; s < nk; s++) {
-        if (s + 1 >= nk) gemm_wait_vm<0>();                        // the stage issued during step s - 1 (operands of step s + 1) may stay in flight
-        else gemm_wait_vm<4>();
+        if (NS == 2 || s + 1 >= nk) gemm_wait_vm<0>();             // NS == 3: the stage issued during step s - 1 (operands of step s + 1) may stay in flight
+        else gemm_wait_vm<NP>();
         __builtin_amdgcn_s_barrier();                               // stage s visible to every wave; stage s - 1 fully consumed
-        if (s + 2 < nk) issue_stage();
-        const unsigned base = lds_addr(w1_lds + (s % W1_NS) * 16384);
-        // fragments through the asm reads (the builtin would make hipcc drain vmcnt(0), i.e. the DMA just issued: conv_internal.h); second
-        // read of a fragment = 4 rows further (1024 B: same row & 3, same quarter position), ks = 1: 16 rows further (4096 B)
-        bf16x8 af[2][2], bq[2][2];
-        // (lgkmcnt is a 4-bit counter: never more than 12 of this wave's reads in flight)
+        if (s + NS - 1 < nk) issue_stage();
 #pragma unroll
-        for (int i = 0; i < 2; i++) af[0][i] = lds_tr16x2(base + fa[i], 1024u);
+        for (int hh = 0; hh < PX / 32; hh++) {
+            const unsigned base = lds_addr(w1_lds + (s % NS) * STB) + (unsigned)(hh * 8192);
+            // fragments through the asm reads (the builtin would make hipcc drain vmcnt(0), i.e. the DMA just issued: conv_internal.h); second
+            // read of a fragment = 4 rows further (1024 B: same row & 3, same quarter position), ks = 1: 16 rows further (4096 B)
+            bf16x8 af[2][2], bq[2][2];
+            // (lgkmcnt is a 4-bit counter: never more than 12 of this wave's reads in flight)
 #pragma unroll
-        for (int j = 0; j < 2; j++) bq[0][j] = lds_tr16x2(base + 8192u + fbq[j], 1024u);
+            for (int i = 0; i < 2; i++) af[0][i] = lds_tr16x2(base + fa[i], 1024u);
 #pragma unroll
-        for (int i = 0; i < 2; i++) af[1][i] = lds_tr16x2(base + fa[i] + 4096u, 1024u);
-        lds_wait2<4>(af[0][0], af[0][1]);                           // later reads: the four of af[1][*]
-        lds_wait2<4>(bq[0][0], bq[0][1]);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; j++) bq[0][j] = lds_tr16x2(base + (unsigned)OPB + fbq[j], 1024u);
 #pragma unroll
-        for (int j = 0; j < 2; j++) bq[1][j] = lds_tr16x2(base + 8192u + fbq[j] + 4096u, 1024u);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 2; i++) af[1][i] = lds_tr16x2(base + fa[i] + 4096u, 1024u);
+            lds_wait2<4>(af[0][0], af[0][1]);                       // later reads: the four of af[1][*]
+            lds_wait2<4>(bq[0][0], bq[0][1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) bq[1][j] = lds_tr16x2(base + (unsigned)OPB + fbq[j] + 4096u, 1024u);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bq[0][j], acc[i][j], 0, 0, 0);
-        lds_wait2<0>(af[1][0], af[1][1]);
-        lds_wait2<0>(bq[1][0], bq[1][1]);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bq[0][j], acc[i][j], 0, 0, 0);
+            lds_wait2<0>(af[1][0], af[1][1]);
+            lds_wait2<0>(bq[1][0], bq[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bq[1][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bq[1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // split-K partial tile -> workspace [z][Cout][Cin] fp32: acc[i][j][e] = (co = i0 + 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), ci = j0 + 64 wn + 32 j + (lane & 31))
     float* part = p.partial + (int64_t)bz * p.Cout * p.Cin;
@@ -1133,12 +1142,21 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 
+// rows of one generic-kernel tile for these parameters: the SAME decision ryolo_conv_gemm's dispatch makes (statistics rows = M tiles)
+static bool gemm_k64(const ConvGemmParams& p) { return (p.Cin % 64 == 0) && p.cls[0].ntaps > 1 && p.Cin <= 256 && !(p.pipe & 0x100); }
+static bool gemm_wide_n64(const ConvGemmParams& p)
+{
+    static const int n64_wide = getenv("RYOLO_GEMM_N64") ? atoi(getenv("RYOLO_GEMM_N64")) : 1;   // 0 off, 1 large grids, 2 every grid (parity tests on small grids)
+    return (p.pipe & 0xff) && p.Nout > 32 && p.Nout <= 64 && n64_wide && !gemm_k64(p) && ((int64_t)p.NB * p.OH * p.OW >= 256ll * 1536 || n64_wide == 2);
+}
+static int gemm_tile_rows(const ConvGemmParams& p) { return (p.Nout <= 32 || gemm_wide_n64(p)) ? 256 : 128; }
+
 extern "C" int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows)
 {
-    // number of [2][Nout] partial-statistics rows the EPI_STATS epilogue writes (== gridM of the chosen tile)
+    // upper bound of the [2][Nout] partial-statistics rows the EPI_STATS epilogue writes (exact: ryolo_conv_gemm_plan, which knows the tile)
     if (!rows) return RY_ERR_ARG;
     (void)pipe;
-    *rows = (int)ry_cdiv(M, Nout <= 32 ? 256 : 128);               // (n tiles share the row; every generic tile is 128 pixels but the 256x32 one)
+    *rows = (int)ry_cdiv(M, Nout <= 32 ? 256 : 128);               // (n tiles share the row; every generic tile is 128 pixels but the 256-pixel ones)
     return RY_OK;
 }
 
@@ -1211,7 +1229,8 @@ extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, i
         return RY_OK;
     }
     if (kernel) *kernel = 0;
-    return ryolo_conv_gemm_stats_rows((int64_t)p.NB * p.OH * p.OW, p.Nout, p.pipe & 0xff, stats_rows);
+    *stats_rows = (int)ry_cdiv((int64_t)p.NB * p.OH * p.OW, gemm_tile_rows(p));
+    return RY_OK;
 }
 
 extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
@@ -1232,8 +1251,11 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         if (!p.zeros) return RY_ERR_ARG;
         // 64-channel (full 128-byte line) stages: measured +1..5 % on 3x3 layers up to 256 channels, -4..-10 % on 1x1 / 512-channel
         // layers (tools/bench_conv.py matrix in DESIGN.md); 0x100 forces 32-channel stages for A/B runs
-        const bool k64 = (p.Cin % 64 == 0) && p.cls[0].ntaps > 1 && p.Cin <= 256 && !(p.pipe & 0x100);
+        const bool k64 = gemm_k64(p);
         if (p.Nout <= 32) return launch_gemm<256, 32, 4, 1, 1>(p, stream);
+        // <= 64 output columns: 256 x 64 tiles (each wave 64 x 64: 8 MFMAs per K step; the 128 x 64 tile gives a wave 64 x 32 = 4 MFMAs per
+        // step around the same barrier / DMA issue) when the grid still fills the chip; RYOLO_GEMM_N64 = 0 restores 128 x 64 (A/B)
+        if (gemm_wide_n64(p)) return launch_gemm<256, 64, 4, 1, 1>(p, stream);
         if (p.Nout <= 64 || (p.pipe & 0x800)) return k64 ? launch_gemm<128, 64, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 64, 2, 2, 1>(p, stream);   // 0x800: A/B, 64-wide N tiles everywhere
         return k64 ? launch_gemm<128, 128, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 128, 2, 2, 1>(p, stream);
     }
@@ -1318,9 +1340,10 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     const dim3 wgrid((unsigned)((int64_t)gx * gy * p.splitk));
     // pointwise layers wider than 64 output channels: the LDS-DMA ring kernel (same tiles, same slabs: bm == 128 gives gx = ceil(Cout / 128),
     // gy = ceil(Cin / 128) there too); 0x2 in RYOLO_WGRAD_P1 switches it off for A/B runs
-    static const int p1_mode = getenv("RYOLO_WGRAD_P1") ? atoi(getenv("RYOLO_WGRAD_P1")) : 3;
+    static const int p1_mode = getenv("RYOLO_WGRAD_P1") ? atoi(getenv("RYOLO_WGRAD_P1")) : 3;      // bit 0 pointwise addressing, bit 1 the LDS-DMA kernel, bit 2 its 64-pixel steps
     if (p1 && bm == 128 && (p1_mode & 2) && p.zeros && ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0) {
-        hipLaunchKernelGGL(wgrad1x1_dma_kernel, wgrid, dim3(256), 0, stream, p);
+        if (p1_mode & 4) hipLaunchKernelGGL(wgrad1x1_dma_kernel<64>, wgrid, dim3(256), 0, stream, p);      // 0x4: 64-pixel K steps (A/B)
+        else hipLaunchKernelGGL(wgrad1x1_dma_kernel<32>, wgrid, dim3(256), 0, stream, p);
         launch_wgrad_reduce(p, p.splitk, stream);
         RY_CHECK_LAUNCH();
         return RY_OK;

@@ -762,18 +762,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
 #endif
 }
 
-// ---- <= 64 output channels, 64-pixel K steps ------------------------------------------------------------------------------------
-// conv3x3_wgrad_kernel<true> splits a 32-pixel step over the wave pairs: 9 MFMAs per wave between two barriers — 64->64 @400^2 ran at
-// 415 TF/s (1.82 ms where its bytes allow 0.5), the step's fixed cost (barrier, DMA wait, fragment addressing) larger than its matrix work.
-// Here a step covers 64 padded pixels: wave w multiplies channel quarter w & 1 with pixel half w >> 1 (32 pixels = two 16-pixel MFMA
-// slices): 18 MFMAs per wave and step like the 128-channel kernel, three DMA pieces per wave and step (two dY, one of the 64 new ring rows:
-// balanced over the four waves).  Both streams run ONE step ahead (two dY stages): 2 x 8 KiB + the 1024-row ring = 80 KiB, two workgroups
-// per CU; ring rows live = 2 halos + this step + the next + alignment slack <= 1015 for a 400-pixel map.
+// ---- 64-pixel K steps -------------------------------------------------------------------------------------------------------------------
+// The first ring kernels take 32 padded pixels per step.  For <= 64 output channels the wave PAIRS of conv3x3_wgrad_kernel<true> split such a
+// step: 9 MFMAs per wave between two barriers — 64->64 @400^2 ran at 415 TF/s (1.82 ms where its bytes allow 0.5): the step's fixed cost
+// (barrier, DMA wait, fragment addressing, DMA issue) was larger than its matrix work.  Here a step covers 64 pixels:
+//   CO64 (<= 64 output channels): wave w multiplies channel quarter w & 1 with pixel half w >> 1 (32 pixels): 18 MFMAs per wave and step;
+//   128-channel tiles: wave w owns channel quarter w and all 64 pixels: 36 MFMAs per wave and step (two passes of the 18-MFMA schedule).
+// DMA pieces per wave and step: its own dY rows (2 / 4 pieces) + ONE of the four 16-row pieces of the 64 new ring rows — balanced over
+// the waves (the 32-pixel kernels give the ring to waves 0 and 1).  Both streams run ONE step ahead (two dY stages, a step is long enough
+// to cover the HBM latency): CO64 2 x 8 KiB + the 1024-row ring = 80 KiB; 128 channels 2 x 16 KiB + a 512-row ring = 64 KiB: two workgroups
+// per CU.  Ring rows live = 2 halos + this step + the next + alignment slack (<= 1015 for a 400-pixel map).
+// Measured (kernel + reduce, batch 64): 64->64 @400^2 1822 -> 1092 us, @200^2 503 -> 317; the training step 746 -> 777 img/s.
+template <bool CO64>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradParams p, const W3Geom g)
 {
-    constexpr int DYS = 8192;                                      // one dY stage: [2 quarters][64 px][64 B]
+    constexpr int DYS = CO64 ? 8192 : 16384;                       // one dY stage: [2 | 4 quarters][64 px][64 B]
+    constexpr int NDY = CO64 ? 2 : 4;                              // dY pieces per wave and step
+    constexpr int NH = CO64 ? 1 : 2;                               // 32-pixel halves a wave multiplies per step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cow = wave & 1, kh = wave >> 1;
+    const int cow = CO64 ? (wave & 1) : wave, kh = CO64 ? (wave >> 1) : 0;
     const int t_id = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = t_id % g.gx, bc = (t_id / g.gx) % g.gc, bz = t_id / (g.gx * g.gc);
     const int i0 = bx * 128, ci0 = bc * 32;
@@ -798,17 +805,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradPara
         ok = uq < (unsigned)limit && (ihp - 1u) < (unsigned)H && (iwp - 1u) < (unsigned)W;
         return (int)((img * (unsigned)H + ihp - 1u) * (unsigned)W + iwp - 1u);
     };
-    // dY: wave (cow, kh) stages the two 16-row pieces of ITS quarter and ITS pixel half — what it will read itself (and its partner wave
-    // of the other half never touches): rows 32 kh + 16 u + prow_l of the step
-    int dq[2];
+    // dY: a wave stages the 16-row pieces of ITS quarter that it will read itself: CO64 rows 32 kh + 16 u + prow_l, else rows 16 u + prow_l
+    int dq[NDY];
 #pragma unroll
-    for (int u = 0; u < 2; u++) dq[u] = (int)kbeg + 32 * kh + 16 * u + prow_l;
+    for (int u = 0; u < NDY; u++) dq[u] = (int)kbeg + 32 * kh + 16 * u + prow_l;
     const bool d_chan_ok = (i0 + 32 * cow + slot * 8) < p.CoutPad;
     const bf16_t* const dy_base = p.dY + i0 + 32 * cow + slot * 8;
     const bf16_t* const x_base = p.X + ci0 + slot * 8;
     auto issue_dy = [&](int stage) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NDY; u++) {
             bool ok;
             const int pix = locate(dq[u], kend32, ok);
             const bf16_t* src = (ok && d_chan_ok) ? dy_base + (int64_t)pix * p.ldY : p.zeros;
@@ -841,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradPara
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
     const unsigned kb32 = (unsigned)(int)kbeg;
+    const unsigned xr_a = lds_addr(xring) + (unsigned)fr_col;
     for (int s = 0; s < nk; s++) {
         wait_vm<0>();                                                 // everything this wave issued one step ago has landed
         __builtin_amdgcn_s_barrier();                                 // ... and everybody else's; step s - 1 fully consumed
@@ -848,42 +855,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradPara
             issue_x();
             issue_dy((s + 1) & 1);
         }
-        const unsigned char* da = dyst + (s & 1) * DYS + cow * 4096 + (32 * kh) * 64;
-        const unsigned q0 = kb32 + 64u * (unsigned)s + 32u * (unsigned)kh;
-        const unsigned da_a = lds_addr(da) + (unsigned)(fr_row * 64 + fr_col);
-        const unsigned xr_a = lds_addr(xring) + (unsigned)fr_col;
-        auto read_a = [&](int ks) { return lds_tr16x2(da_a + (unsigned)(ks * 16 * 64), 256u); };
-        auto read_b = [&](int i) {
-            const int ks = i / 9, t = i % 9;
-            const unsigned qq = q0 + (unsigned)(g.toff[t] + ks * 16 + fr_row);
-            const ry_s16x4 lo = lds_tr16(xr_a + (qq & rmask) * 64u), hi = lds_tr16(xr_a + ((qq + 4u) & rmask) * 64u);
-            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        };
-        // the 18-MFMA schedule of conv3x3_wgrad_kernel<false>: a0, b0..b3, a1, then b(i + 4) in front of MFMA i (counted lgkmcnt)
-        constexpr int PF = 4;
-        bf16x8 af[2], bq[18];
-        af[0] = read_a(0);
 #pragma unroll
-        for (int i = 0; i < PF; i++) bq[i] = read_b(i);
-        af[1] = read_a(1);
+        for (int hh = 0; hh < NH; hh++) {
+            const int half = CO64 ? kh : hh;
+            const unsigned char* da = dyst + (s & 1) * DYS + cow * 4096 + (32 * half) * 64;
+            const unsigned q0 = kb32 + 64u * (unsigned)s + 32u * (unsigned)half;
+            const unsigned da_a = lds_addr(da) + (unsigned)(fr_row * 64 + fr_col);
+            auto read_a = [&](int ks) { return lds_tr16x2(da_a + (unsigned)(ks * 16 * 64), 256u); };
+            auto read_b = [&](int i) {
+                const int ks = i / 9, t = i % 9;
+                const unsigned qq = q0 + (unsigned)(g.toff[t] + ks * 16 + fr_row);
+                const ry_s16x4 lo = lds_tr16(xr_a + (qq & rmask) * 64u), hi = lds_tr16(xr_a + ((qq + 4u) & rmask) * 64u);
+                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+            // the 18-MFMA schedule of conv3x3_wgrad_kernel<false>: a0, b0..b3, a1, then b(i + 4) in front of MFMA i (counted lgkmcnt)
+            constexpr int PF = 4;
+            bf16x8 af[2], bq[18];
+            af[0] = read_a(0);
 #pragma unroll
-        for (int i = 0; i < 18; i++) {
+            for (int i = 0; i < PF; i++) bq[i] = read_b(i);
+            af[1] = read_a(1);
+#pragma unroll
+            for (int i = 0; i < 18; i++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + PF < 18) bq[i + PF] = read_b(i + PF);
+                if (i < 4) lds_wait2<10>(af[0], bq[i]);
+                else if (i < 14) lds_wait2<8>(af[1], bq[i]);
+                else if (i == 14) lds_wait<6>(bq[i]);
+                else if (i == 15) lds_wait<4>(bq[i]);
+                else if (i == 16) lds_wait<2>(bq[i]);
+                else lds_wait<0>(bq[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (i + PF < 18) bq[i + PF] = read_b(i + PF);
-            if (i < 4) lds_wait2<10>(af[0], bq[i]);
-            else if (i < 14) lds_wait2<8>(af[1], bq[i]);
-            else if (i == 14) lds_wait<6>(bq[i]);
-            else if (i == 15) lds_wait<4>(bq[i]);
-            else if (i == 16) lds_wait<2>(bq[i]);
-            else lds_wait<0>(bq[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
-    // split-K partial tile -> workspace: two slabs per K range (one per pixel half), summed by the deterministic reduce
+    // split-K partial tile -> workspace (CO64: two slabs per K range, one per pixel half, summed by the deterministic reduce)
     const int NK = 9 * p.Cin;
-    float* part = p.partial + ((int64_t)bz * 2 + kh) * p.Cout * NK;
+    float* part = p.partial + ((int64_t)bz * (CO64 ? 2 : 1) + kh) * p.Cout * NK;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int kc = t * p.Cin + ci0 + (lane & 31);
@@ -910,12 +920,20 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.HPp = p.OH + 2;
     g.Mp = (int64_t)p.NB * g.HPp * g.PWp;
     g.co64 = p.Cout <= 64 ? 1 : 0;
-    static const bool co64_v2 = !(getenv("RYOLO_W3_CO64_V2") && atoi(getenv("RYOLO_W3_CO64_V2")) == 0);      // A/B knob
-    if (g.co64 && co64_v2) g.co64 = 2;                            // 64-pixel K steps (conv3x3_wgrad64_kernel)
-    const int need = 2 * (g.PWp + 1) + (g.co64 == 2 ? 209 : 160);
+    // RYOLO_W3_STEP64 (A/B knob): bit 0 = 64-pixel K steps for <= 64 output channels, bit 1 = for the 128-channel tiles (conv3x3_wgrad64_kernel)
+    static const int step64 = getenv("RYOLO_W3_STEP64") ? atoi(getenv("RYOLO_W3_STEP64")) : 3;
+    bool s64 = (step64 >> (g.co64 ? 0 : 1)) & 1;
+    int need = 2 * (g.PWp + 1) + (s64 ? 209 : 160);
     int rx = 256;
     while (rx < need) rx <<= 1;
+    if (s64 && rx > (g.co64 ? 1024 : 512)) {                      // the 64-pixel form would not leave two workgroups per CU: 32-pixel steps
+        s64 = false;
+        need = 2 * (g.PWp + 1) + 160;
+        rx = 256;
+        while (rx < need) rx <<= 1;
+    }
     if (rx > (g.co64 ? 1024 : 512)) return false;                 // <= 80 KiB LDS: two workgroups per CU; wider maps stay on the generic kernel
+    g.step64 = s64 ? 1 : 0;
     g.RX = rx;
     g.gx = (int)ry_cdiv(p.Cout, 128);
     g.gc = p.Cin / 32;
@@ -929,7 +947,7 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     static const bool force = getenv("RYOLO_W3_FORCE") != nullptr;   // A/B runs: ignore the size heuristic
     if (sk < 1) sk = 1;
     if ((int64_t)g.gx * g.gc * sk < 128 && !force) return false;
-    const int kstep = g.co64 == 2 ? 64 : 32;
+    const int kstep = g.step64 ? 64 : 32;
     g.kchunk = ry_cdiv(ry_cdiv(g.Mp, sk), kstep) * kstep;
     g.splitk = (int)ry_cdiv(g.Mp, g.kchunk);
     for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
@@ -941,7 +959,7 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     };
     magic((unsigned)(g.HPp * g.PWp), g.m_img, g.s_img);
     magic((unsigned)g.PWp, g.m_row, g.s_row);
-    g.lds_bytes = (g.co64 == 2 ? 2u * 8192u : W3_NS * (g.co64 ? 4096u : 8192u)) + (unsigned)g.RX * 64u;
+    g.lds_bytes = (g.step64 ? 2u * (g.co64 ? 8192u : 16384u) : W3_NS * (g.co64 ? 4096u : 8192u)) + (unsigned)g.RX * 64u;
     g.slabs = g.splitk * (g.co64 ? 2 : 1);
     g.ok = 1;
     return true;
@@ -949,14 +967,17 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
 
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream)
 {
-    static RyLdsAttr attr_f, attr_t, attr_64;
+    static RyLdsAttr attr_f, attr_t, attr_64f, attr_64t;
     if (ry_max_dynamic_lds(attr_f, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<false>), 160 * 1024) ||
         ry_max_dynamic_lds(attr_t, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<true>), 160 * 1024) ||
-        ry_max_dynamic_lds(attr_64, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel), 160 * 1024))
+        ry_max_dynamic_lds(attr_64f, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<false>), 160 * 1024) ||
+        ry_max_dynamic_lds(attr_64t, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<true>), 160 * 1024))
         return RY_ERR_LAUNCH;
     const dim3 grid((unsigned)((int64_t)g.gx * g.gc * g.splitk));
-    if (g.co64 == 2)
-        hipLaunchKernelGGL(conv3x3_wgrad64_kernel, grid, dim3(256), g.lds_bytes, stream, p, g);
+    if (g.step64 && g.co64)
+        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<true>), grid, dim3(256), g.lds_bytes, stream, p, g);
+    else if (g.step64)
+        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<false>), grid, dim3(256), g.lds_bytes, stream, p, g);
     else if (g.co64)
         hipLaunchKernelGGL((conv3x3_wgrad_kernel<true>), grid, dim3(256), g.lds_bytes, stream, p, g);
     else

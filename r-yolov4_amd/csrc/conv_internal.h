@@ -190,6 +190,7 @@ struct W3Geom {
     int RX;                    // ring rows (power of two)
     int gx, gc;                // output-channel tiles of 128, input-channel chunks of 32
     int splitk, slabs, co64;   // K ranges; fp32 slabs written (2 per range for the <= 64 output-channel variant)
+    int step64;                // 1: 64-pixel K steps (conv3x3_wgrad64_kernel), 0: 32-pixel steps
     int64_t kchunk;            // padded pixels per split (multiple of 32)
     int toff[9];               // dh * PWp + dw per tap (caller's tap order)
     unsigned lds_bytes;

@@ -22,3 +22,17 @@ def test_block_and_network_parity_with_3x3_kernels_forced():
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_block_and_network_parity_with_wide_64_column_tile_forced():
+    """RYOLO_GEMM_N64=2: the 256 x 64 tile of the generic kernel (layers with 33..64 output columns, by default only when the grid has
+    >= 1536 such tiles) on the small grids of the block / network parity tests, batch-statistics epilogue included."""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    env = dict(os.environ, RYOLO_GEMM_N64="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py", "-q", "-m", "gpu",
+                        "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
