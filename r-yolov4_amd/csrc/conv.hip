@@ -1216,7 +1216,7 @@ static int gemm_check(const ConvGemmParams& p)
 
 // Which kernel ryolo_conv_gemm will run for these parameters and how many [2][Nout] partial-statistics rows its EPI_STATS
 // epilogue writes (= number of M tiles).  kernel: 0 generic implicit GEMM (conv.hip), 1 3x3 halo-patch kernel (conv3x3.hip,
-// selected by pipe bit 0x200 when the layer is eligible).
+// selected by pipe bit 0x200 when the layer is eligible), 2 weight-stationary persistent 1x1 kernel (gemm1x1.hip; rows = waves).
 extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, int* kernel)
 {
     if (!pp || !stats_rows) return RY_ERR_ARG;
@@ -1226,6 +1226,12 @@ extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, i
     if ((p.pipe & 0x200) && p3_geometry(p, g)) {
         *stats_rows = (int)g.gm;
         if (kernel) *kernel = 1;
+        return RY_OK;
+    }
+    Ws1Geom wg;
+    if (p.nclasses == 1 && ws1_geometry(p, wg)) {
+        *stats_rows = wg.stats_rows;
+        if (kernel) *kernel = 2;
         return RY_OK;
     }
     if (kernel) *kernel = 0;
@@ -1249,6 +1255,8 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
     }
     if (p.pipe & 0xff) {
         if (!p.zeros) return RY_ERR_ARG;
+        Ws1Geom wg;
+        if (ws1_geometry(p, wg)) return ws1_launch(p, wg, stream);
         // 64-channel (full 128-byte line) stages: measured +1..5 % on 3x3 layers up to 256 channels, -4..-10 % on 1x1 / 512-channel
         // layers (tools/bench_conv.py matrix in DESIGN.md); 0x100 forces 32-channel stages for A/B runs
         const bool k64 = gemm_k64(p);

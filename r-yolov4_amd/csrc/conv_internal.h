@@ -200,3 +200,14 @@ struct W3Geom {
 };
 bool w3_geometry(const WgradParams& p, W3Geom& g);
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
+
+// ---- weight-stationary persistent 1x1 GEMM (gemm1x1.hip): Cin <= 256, identity grid, bf16 epilogues ---------------------------------
+struct Ws1Geom {
+    int ok;
+    int nk;                    // 32-channel K steps
+    int gridN, wgn;            // 128-channel n tiles; workgroups per n tile (grid = gridN * wgn <= CUs, one workgroup per CU)
+    int stats_rows;            // partial-statistics rows = waves per n tile (one row per wave for the whole launch)
+    unsigned lds_bytes;
+};
+bool ws1_geometry(const ConvGemmParams& p, Ws1Geom& g);
+int ws1_launch(const ConvGemmParams& p, const Ws1Geom& g, hipStream_t stream);

@@ -231,6 +231,8 @@ class Graph:
             hip.call("ryolo_conv_gemm_plan", p, S.I(), kern)
             if kern.value == 1:
                 return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl, by)
+            if kern.value == 2:
+                return ("gemm1x1_ws_kernel", fl, by)
             tile = "256x32" if p.Nout <= 32 else ("128x64" if p.Nout <= 64 else "128x128")
             return (f"conv_gemm_kernel<{tile}>", fl, by)
         if name == "ryolo_conv_wgrad":

@@ -36,3 +36,18 @@ def test_block_and_network_parity_with_wide_64_column_tile_forced():
                         "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_block_and_network_parity_with_persistent_1x1_kernel_forced():
+    """RYOLO_GEMM_WS=2: the weight-stationary persistent 1x1 kernel (gemm1x1.hip; by default only grids with >= 6 tiles per wave) on the
+    small, ragged grids of the block / network / per-node parity tests: raw, statistics, accumulate and (eval plans) affine epilogues."""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    env = dict(os.environ, RYOLO_GEMM_WS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py",
+                        "tests/test_gpu_parity_e2e.py", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
