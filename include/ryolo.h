@@ -134,8 +134,9 @@ int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
 /* UPPER BOUND of the [2][Nout] partial-statistics rows epilogue 1 writes for an M x Nout problem (sizing only: the exact count, which
  * the reduction must use, depends on the tile ryolo_conv_gemm picks and is ryolo_conv_gemm_plan's stats_rows) */
 int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows);
-/* which kernel ryolo_conv_gemm runs for *p (0 generic implicit GEMM, 1 the 3x3 stride-1 halo-patch kernel, enabled by pipe bit
- * 0x200 for eligible layers) and the number of partial-statistics rows its epilogue 1 writes; `kernel` may be null */
+/* which kernel ryolo_conv_gemm runs for *p and the number of partial-statistics rows its epilogue 1 writes; `kernel` may be null.
+ * *kernel & 0xff: 0 generic implicit GEMM, 1 the 3x3 stride-1 halo-patch kernel (pipe bit 0x200, eligible layers), 2 the weight-stationary
+ * persistent 1x1 kernel (RYOLO_GEMM_WS); for 0 also bit 0x100 = the 1x1 instantiation, bits 12-15 = tile rows / 64, bits 16-19 = tile columns / 32 */
 int ryolo_conv_gemm_plan(const ConvGemmParams* p, int* stats_rows, int* kernel);
 /* weight gradient: split-K over output pixels into p->partial ([splitk][Cout][taps*Cin] fp32, size from _plan), then a
  * deterministic reduction that accumulates into the torch-layout .grad [Cout][Cin][kh*kw] (no float atomics). */

@@ -1108,6 +1108,19 @@ static void launch_wgrad_reduce(const WgradParams& p, int splitk, hipStream_t st
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+static bool gemm_ident(const ConvGemmParams& p)
+{
+    return p.nclasses == 1 && p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && p.cls[0].oh_add == 0 && p.cls[0].ow_add == 0 &&
+           !p.pool_idx && !p.s2d_cin;
+}
+// single tap (0, 0) on the identity grid, input grid == output grid: the 1x1 instantiations (no tile decomposition, no tap table)
+static bool gemm_is_t1(const ConvGemmParams& p)
+{
+    static const bool t1_on = !(getenv("RYOLO_GEMM_T1") && atoi(getenv("RYOLO_GEMM_T1")) == 0);      // A/B knob
+    return (p.pipe & 0xff) == 1 && gemm_ident(p) && t1_on && p.cls[0].ntaps == 1 && p.cls[0].dh[0] == 0 && p.cls[0].dw[0] == 0 && p.cls[0].widx[0] == 0 &&
+           p.sh == 1 && p.sw == 1 && p.IH == p.OH && p.IW == p.OW;
+}
+
 template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32>
 static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
 {
@@ -1115,12 +1128,8 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(gm * gn), 1, p.nclasses);
-    const bool ident = p.nclasses == 1 && p.oh_mul == 1 && p.ow_mul == 1 && p.OHf == p.OH && p.OWf == p.OW && p.cls[0].oh_add == 0 &&
-                       p.cls[0].ow_add == 0 && !p.pool_idx && !p.s2d_cin;
-    // single tap (0, 0) on the identity grid, input grid == output grid: the 1x1 instantiations (no tile decomposition, no tap table)
-    static const bool t1_on = !(getenv("RYOLO_GEMM_T1") && atoi(getenv("RYOLO_GEMM_T1")) == 0);      // A/B knob
-    const bool t1 = PIPE == 1 && ident && t1_on && p.cls[0].ntaps == 1 && p.cls[0].dh[0] == 0 && p.cls[0].dw[0] == 0 && p.cls[0].widx[0] == 0 &&
-                    p.sh == 1 && p.sw == 1 && p.IH == p.OH && p.IW == p.OW;
+    const bool ident = gemm_ident(p);
+    const bool t1 = PIPE == 1 && gemm_is_t1(p);
     if constexpr (PIPE == 1) {
         if (t1) {
             if (p.nbstat) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true, true>), grid, dim3(256), 0, stream, p);
@@ -1234,8 +1243,12 @@ extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, i
         if (kernel) *kernel = 2;
         return RY_OK;
     }
-    if (kernel) *kernel = 0;
-    *stats_rows = (int)ry_cdiv((int64_t)p.NB * p.OH * p.OW, gemm_tile_rows(p));
+    // generic kernel: bits 8 = the 1x1 instantiation (T1), bits 12-15 = tile rows / 64, bits 16-19 = tile columns / 32 (what rocprofv3 lists
+    // as separate kernels; tools and bench.py label their per-kernel tables with it)
+    const int rows = gemm_tile_rows(p);
+    const int cols = p.Nout <= 32 ? 32 : ((p.Nout <= 64 || ((p.pipe & 0xff) && (p.pipe & 0x800))) ? 64 : 128);
+    if (kernel) *kernel = 0 | (gemm_is_t1(p) ? 0x100 : 0) | ((rows / 64) << 12) | ((cols / 32) << 16);
+    *stats_rows = (int)ry_cdiv((int64_t)p.NB * p.OH * p.OW, rows);
     return RY_OK;
 }
 

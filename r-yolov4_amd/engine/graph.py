@@ -229,12 +229,13 @@ class Graph:
             by = p.NB * p.IH * p.IW * p.Cin * 2 + p.Nout * p.wtaps * p.Cin * 2 + outb
             kern = S.I()
             hip.call("ryolo_conv_gemm_plan", p, S.I(), kern)
-            if kern.value == 1:
+            fam, kv = kern.value & 0xff, kern.value
+            if fam == 1:
                 return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl, by)
-            if kern.value == 2:
+            if fam == 2:
                 return ("gemm1x1_ws_kernel", fl, by)
-            tile = "256x32" if p.Nout <= 32 else ("128x64" if p.Nout <= 64 else "128x128")
-            return (f"conv_gemm_kernel<{tile}>", fl, by)
+            # the generic kernel's instantiations as rocprofv3 lists them: tile shape, and the 1x1 form (no tap table / tile decomposition)
+            return (f"conv_gemm_kernel<{((kv >> 12) & 15) * 64}x{((kv >> 16) & 15) * 32}{',1x1' if kv & 0x100 else ''}>", fl, by)
         if name == "ryolo_conv_wgrad":
             p = args[0]
             fl = 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin
@@ -408,7 +409,7 @@ class Graph:
         if bstat:
             rows, kern = S.I(), S.I()
             hip.call("ryolo_conv_gemm_plan", p, rows, kern)
-            if not (self.rt.fuse_bn_kernels >> kern.value) & 1 or A.N * OH * OW * Nout > self.rt.fuse_bn_max_elems:
+            if not (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1 or A.N * OH * OW * Nout > self.rt.fuse_bn_max_elems:
                 bstat = None
         if bstat:
             p.nbstat = len(bstat)

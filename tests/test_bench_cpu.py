@@ -15,7 +15,7 @@ def test_committed_pmc_profile_resolves_for_the_default_workload():
     fresh = os.path.exists(path) and json.load(open(path)).get("source_sha256") == bench.source_sha256()
     t = bench.pmc_traffic(args)
     if fresh:
-        for cls in ("conv_gemm_kernel<128x128>", "conv_gemm_kernel<128x64>", "conv3x3_patch_kernel<256x128>", "conv3x3_patch_kernel<256x64>",
+        for cls in ("conv_gemm_kernel<128x128,1x1>", "conv_gemm_kernel<128x128>", "conv_gemm_kernel<256x64>", "conv3x3_patch_kernel<256x128>", "conv3x3_patch_kernel<256x64>",
                     "conv_wgrad_kernel<128>", "conv3x3_wgrad_kernel<128x9x32>"):
             assert t.get(cls, 0) > 1_000_000, (cls, t.get(cls))
         assert 150e9 < bench.pmc_step_bytes(args) < 400e9

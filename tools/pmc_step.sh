@@ -33,7 +33,7 @@ import hashlib
 h=hashlib.sha256()
 for f in sorted(glob.glob(R+"/r-yolov4_amd/csrc/*.hip")+glob.glob(R+"/r-yolov4_amd/csrc/*.h")+glob.glob(R+"/include/*.h")+glob.glob(R+"/r-yolov4_amd/engine/*.py")+glob.glob(R+"/r-yolov4_amd/model/*.py")):
     h.update(open(f,"rb").read())
-doc["source_sha256"]=h.hexdigest()      # bench.py reports `traffic` only while the kernels and the plan are the ones that were profiled
+doc["source_sha256"]=h.hexdigest()      # bench.py reports traffic only while the kernels and the plan are the ones that were profiled
 json.dump(doc,open(R+f"/gpurun_out/${TAG}_pmc_step_traffic.json","w"),indent=1)
 skip=("nms_","bitonic_","compose_kernel","topk_")
 tot=sum(v["hbm_bytes_per_launch"]*v["launches"] for k,v in kern.items() if not k.startswith(skip))/max(steps,1)
