@@ -202,7 +202,7 @@ int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, in
 int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
                           bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
-/* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= ceil(M/1024)*C floats */
+/* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= (ceil(M/256) + 64)*C floats */
 int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);
 
 /* inference re-parameterisation of RepConv (model/utils.py:189-215 leaves the 3 branches un-fused): w3 fp32 [Cout][Cin][3][3],

@@ -820,21 +820,39 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
         const int64_t m0 = (int64_t)b * cells + c0;
         __syncthreads();                                          // previous sub-tile fully consumed (and mulv visible)
         const int run = ncell * attrs, nq = (run + 3) >> 2;
-        for (int i = threadIdx.x; i < na * nq; i += 256) {
-            const int a = i / nq, q = i - a * nq;
-            const int e0 = q * 4;
-            const float* src = dout + (((int64_t)b * na + a) * cells + c0) * attrs + e0;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (e0 + 3 < run) { const f4u w = *reinterpret_cast<const f4u*>(src); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
-            else for (int k = 0; e0 + k < run; k++) v[k] = src[k];
-            int cell = (int)((float)e0 * rattrs);
-            if (cell * attrs > e0) cell--;
-            if ((cell + 1) * attrs <= e0) cell++;
-            int at = e0 - cell * attrs;
+        // four 16-byte loads of a thread are requested before the first one is scattered: with one load per loop trip every trip paid its
+        // own memory round trip, and the few workgroups of the small scales (40 at 8 images x 25^2) made that the launch time
+        for (int i0 = threadIdx.x; i0 < na * nq; i0 += 256 * 4) {
+            float v[4][4];
+            int aa[4], ee[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (e0 + k < run) hl[cell * LD + a * attrs + at] = v[k];
-                if (++at == attrs) { at = 0; cell++; }
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 256;
+                aa[u] = -1;
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[u][k] = 0.f;
+                if (i >= na * nq) continue;
+                const int a = i / nq, q = i - a * nq;
+                const int e0 = q * 4;
+                aa[u] = a;
+                ee[u] = e0;
+                const float* src = dout + (((int64_t)b * na + a) * cells + c0) * attrs + e0;
+                if (e0 + 3 < run) { const f4u w = *reinterpret_cast<const f4u*>(src); v[u][0] = w.x; v[u][1] = w.y; v[u][2] = w.z; v[u][3] = w.w; }
+                else for (int k = 0; e0 + k < run; k++) v[u][k] = src[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (aa[u] < 0) continue;
+                const int e0 = ee[u];
+                int cell = (int)((float)e0 * rattrs);
+                if (cell * attrs > e0) cell--;
+                if ((cell + 1) * attrs <= e0) cell++;
+                int at = e0 - cell * attrs;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (e0 + k < run) hl[cell * LD + aa[u] * attrs + at] = v[u][k];
+                    if (++at == attrs) { at = 0; cell++; }
+                }
             }
         }
         __syncthreads();
@@ -856,20 +874,33 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
         for (int j = 0; j < MAXQ; j++) {
             const int c4 = c4l + j * 128;
             if (c4 >= c4n) break;
-            for (int cell = cl; cell < ncell; cell += 2) {
-                const float* t = hl + cell * LD + c4 * 4;
-                float pv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (mul) {
-                    const float* pp = pre + (m0 + cell) * ldp + c4 * 4;
-                    if (pre4 && c4 * 4 + 3 < C) { const float4 w = *reinterpret_cast<const float4*>(pp); pv[0] = w.x; pv[1] = w.y; pv[2] = w.z; pv[3] = w.w; }
-                    else for (int k = 0; k < 4 && c4 * 4 + k < C; k++) pv[k] = pp[k];
+            // cells in groups of 8 per thread: the `pre` rows of a group are requested together (same reason as above), the sums stay in
+            // ascending cell order
+            for (int cg = cl; cg < ncell; cg += 16) {
+                float pv[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pv[u][k] = 0.f;
+                    const int cell = cg + 2 * u;
+                    if (mul && cell < ncell) {
+                        const float* pp = pre + (m0 + cell) * ldp + c4 * 4;
+                        if (pre4 && c4 * 4 + 3 < C) { const float4 w = *reinterpret_cast<const float4*>(pp); pv[u][0] = w.x; pv[u][1] = w.y; pv[u][2] = w.z; pv[u][3] = w.w; }
+                        else for (int k = 0; k < 4 && c4 * 4 + k < C; k++) pv[u][k] = pp[k];
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (c4 * 4 + k < C) {
-                        const float d = t[k];
-                        sb[j][k] += bf2f(f2bf(d * mulv[c4 * 4 + k]));      // bias gradient = column sum of the bf16 operand the wgrad GEMM reads
-                        sm[j][k] += d * pv[k];
+                for (int u = 0; u < 8; u++) {
+                    const int cell = cg + 2 * u;
+                    if (cell >= ncell) continue;
+                    const float* t = hl + cell * LD + c4 * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (c4 * 4 + k < C) {
+                            const float d = t[k];
+                            sb[j][k] += bf2f(f2bf(d * mulv[c4 * 4 + k]));      // bias gradient = column sum of the bf16 operand the wgrad GEMM reads
+                            sm[j][k] += d * pv[u][k];
+                        }
                     }
                 }
             }
@@ -943,10 +974,20 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = 0.f;
         if (rl < nrl && cc < c8)
-            for (int64_t m = r0 + rl; m < r1; m += nrl) {
-                const V8 v = ld8(x + m * ldx + (cc << 3));
+            for (int64_t m = r0 + rl; m < r1; m += (int64_t)nrl * 4) {          // four rows requested before the first is added (order of the sums unchanged)
+                V8 v[4];
 #pragma unroll
-                for (int k = 0; k < 8; k++) s[k] += v.v[k];
+                for (int u = 0; u < 4; u++) {
+                    const int64_t mm = m + (int64_t)u * nrl;
+                    if (mm < r1) v[u] = ld8(x + mm * ldx + (cc << 3));
+                    else
+#pragma unroll
+                        for (int k = 0; k < 8; k++) v[u].v[k] = 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) s[k] += v[u].v[k];
             }
         __syncthreads();
 #pragma unroll
@@ -1313,10 +1354,12 @@ extern "C" int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int
 {
     if (!x || !out || !scratch || (C & 7) || (ldx & 7) || Cvalid > C) return RY_ERR_ARG;
     if (M == 0) return RY_OK;
-    const int rpb = 1024;
+    const int rpb = 256;                                       // rows per workgroup (1024 left 78 workgroups for 8 images x 100^2: a latency-bound launch)
     const int nblk = (int)ry_cdiv(M, rpb);
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, M, C, rpb, scratch);
-    hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, scratch, nblk, C, Cvalid, out);
+    int rows = nblk;                                           // one thread per column walked every partial row serially: fold to 64 rows first
+    const float* part = fold_rows(scratch, rows, C, scratch + (int64_t)nblk * C, stream);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)ry_cdiv(C, 256)), dim3(256), 0, stream, part, rows, C, Cvalid, out);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -1000,7 +1000,7 @@ class Graph:
             dpre = torch.zeros((M, coutp), dtype=BF16, device=self.adev)       # pad columns stay zero
             self.keep.append(dpre)
             nblk = x.N * ((x.H * x.W + 127) // 128)
-            scratch = self.f32(max((nblk + 64) * 2 * cout, ((M + 1023) // 1024) * max(coutp, x.C)))
+            scratch = self.f32(max((nblk + 64) * 2 * cout, ((M + 255) // 256 + 64) * max(coutp, x.C)))
 
             class _G:                      # geometry shim so dpre can be used as a gathered operand
                 N, H, W, ld = x.N, x.H, x.W, coutp
