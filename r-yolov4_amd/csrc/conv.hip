@@ -39,8 +39,12 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 // 1x1 stride-1 data gradient (the launcher checks it; requires ID and the LDS-DMA ring).  Row m of the GEMM IS input pixel m, so the tile
 // needs no (image, row, column) decomposition, no tap table in LDS (and not the workgroup barrier behind it), no bounds tests and no
 // per-stage scalar tap lookups: on an 8-32 step K loop that prologue was as long as the loop (tools/gemm_phases.py).
-template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0, bool ID = false, bool T1 = false>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p)
+// NST: ring depth override (0 = RY_STAGES, 2 for 64-channel stages).  A workgroup ALONE on its CU (grids of <= 256 tiles: the low-resolution
+// layers at 8 images, batch-1 inference) is latency-bound on a 3-stage ring — ~1.5 stages in flight per ~1.3 us round trip to L2 / Infinity
+// Cache = 1600 cycles per K step — where three co-resident workgroups keep 4.5 in flight; with the LDS to itself it takes a 6-deep ring
+// (4-deep for <= 512 tiles, two per CU).
+template <int BM, int BN, int WM, int WN, int PIPE, int KB = 32, int EP = 0, bool ID = false, bool T1 = false, int NST = 0>
+__global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const ConvGemmParams p)
 {
     static_assert(!T1 || (ID && PIPE == 1), "T1 is an identity-grid LDS-DMA instantiation");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     constexpr int WTM = BM / WM, WTN = BN / WN;               // rows x cols of one wave's output block
     constexpr int EP_LD = WTN + 8;                            // staging row stride (bf16), 16-byte aligned, breaks bank aliasing
     static_assert(KB == 32 || (KB == 64 && PIPE == 1), "64-channel stages exist for the flat LDS-DMA ring only");
-    constexpr int NSTG = KB == 64 ? 2 : RY_STAGES;             // 64-channel stages are twice as large: 2-deep ring, same LDS
+    constexpr int NSTG = NST ? NST : (KB == 64 ? 2 : RY_STAGES);   // 64-channel stages are twice as large: 2-deep ring, same LDS
     constexpr int MAINLOOP_ELEMS = (PIPE ? NSTG : 2) * (BM + BN) * KB, EPI_ELEMS = 4 * WTM * EP_LD;
     constexpr int TAPTAB = 64;                                // 32 ints after the tiles: per-tap (dh, dw, widx) for the DMA loop
     __shared__ __attribute__((aligned(16))) bf16_t smem[(MAINLOOP_ELEMS > EPI_ELEMS ? MAINLOOP_ELEMS : EPI_ELEMS) + TAPTAB];
@@ -322,7 +326,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         for (int k = 0; k < nk; k++) {
             // stages allowed to stay in flight while stage k is consumed
             const int pend = min(NSTG - 2, nk - 1 - k);
-            if (NSTG >= 4 && pend >= 2) wait_inflight(std::integral_constant<int, 2>{});
+            if (NSTG >= 6 && pend >= 4) wait_inflight(std::integral_constant<int, 4>{});
+            else if (NSTG >= 5 && pend == 3) wait_inflight(std::integral_constant<int, 3>{});
+            else if (NSTG >= 4 && pend == 2) wait_inflight(std::integral_constant<int, 2>{});
             else if (NSTG >= 3 && pend == 1) wait_inflight(std::integral_constant<int, 1>{});
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                     // stage k visible to all waves; stage k-1 fully consumed
@@ -1151,6 +1157,30 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 
+// deep-ring instantiations of the 128 x 128 tile for grids that leave a workgroup alone (or in a pair) on its CU
+template <int NST>
+static int launch_gemm_deep(const ConvGemmParams& p, hipStream_t stream)
+{
+    const int64_t M = (int64_t)p.NB * p.OH * p.OW;
+    const dim3 grid((unsigned)(ry_cdiv(M, 128) * ry_cdiv(p.Nout, 128)), 1, 1);
+    const bool t1 = gemm_is_t1(p), acc = p.epi == EPI_ACCUM;
+    if (t1 && acc) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, 1, 32, 1, true, true, NST>), grid, dim3(256), 0, stream, p);
+    else if (t1) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, 1, 32, 0, true, true, NST>), grid, dim3(256), 0, stream, p);
+    else if (acc) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, 1, 32, 1, true, false, NST>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, 1, 32, 0, true, false, NST>), grid, dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
+}
+static int gemm_deep_stages(const ConvGemmParams& p)
+{
+    static const int mode = getenv("RYOLO_GEMM_DEEP") ? atoi(getenv("RYOLO_GEMM_DEEP")) : 1;     // 0 off; 1 by grid size; 4 / 6 force that depth on every eligible launch (tests)
+    if (!mode || (p.pipe & 0xff) != 1 || !gemm_ident(p) || p.nbstat || p.Nout <= 64 || (p.pipe & 0x800)) return 0;
+    if (mode == 4 || mode == 6) return mode;
+    const int64_t tiles = ry_cdiv((int64_t)p.NB * p.OH * p.OW, 128) * ry_cdiv(p.Nout, 128);
+    const int nk = p.cls[0].ntaps * (p.Cin / BK);
+    if (nk < 12) return 0;
+    return tiles <= 256 ? 6 : (tiles <= 512 ? 4 : 0);
+}
+
 // rows of one generic-kernel tile for these parameters: the SAME decision ryolo_conv_gemm's dispatch makes (statistics rows = M tiles)
 static bool gemm_k64(const ConvGemmParams& p) { return (p.Cin % 64 == 0) && p.cls[0].ntaps > 1 && p.Cin <= 256 && !(p.pipe & 0x100); }
 static bool gemm_wide_n64(const ConvGemmParams& p)
@@ -1277,6 +1307,7 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         // <= 64 output columns: 256 x 64 tiles (each wave 64 x 64: 8 MFMAs per K step; the 128 x 64 tile gives a wave 64 x 32 = 4 MFMAs per
         // step around the same barrier / DMA issue) when the grid still fills the chip; RYOLO_GEMM_N64 = 0 restores 128 x 64 (A/B)
         if (gemm_wide_n64(p)) return launch_gemm<256, 64, 4, 1, 1>(p, stream);
+        if (const int deep = gemm_deep_stages(p)) return deep == 6 ? launch_gemm_deep<6>(p, stream) : launch_gemm_deep<4>(p, stream);
         if (p.Nout <= 64 || (p.pipe & 0x800)) return k64 ? launch_gemm<128, 64, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 64, 2, 2, 1>(p, stream);   // 0x800: A/B, 64-wide N tiles everywhere
         return k64 ? launch_gemm<128, 128, 2, 2, 1, 64>(p, stream) : launch_gemm<128, 128, 2, 2, 1>(p, stream);
     }

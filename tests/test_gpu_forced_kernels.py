@@ -51,3 +51,18 @@ def test_block_and_network_parity_with_persistent_1x1_kernel_forced():
                        timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("depth", ["4", "6"])
+def test_block_and_network_parity_with_deep_ring_forced(depth):
+    """RYOLO_GEMM_DEEP=4 / 6: the deep-ring instantiations of the generic 128 x 128 tile (by default chosen for grids of <= 512 / <= 256
+    tiles) on every eligible launch of the block / network / per-node parity tests."""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    env = dict(os.environ, RYOLO_GEMM_DEEP=depth)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py",
+                        "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
