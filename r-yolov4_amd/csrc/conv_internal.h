@@ -207,6 +207,7 @@ struct Ws1Geom {
     int nk;                    // 32-channel K steps
     int gridN, wgn;            // 128-channel n tiles; workgroups per n tile (grid = gridN * wgn <= CUs, one workgroup per CU)
     int stats_rows;            // partial-statistics rows = waves per n tile (one row per wave for the whole launch)
+    int s2d;                   // 1: the space-to-depth data-gradient instantiation (2 x 2 taps, depth-to-space store)
     unsigned lds_bytes;
 };
 bool ws1_geometry(const ConvGemmParams& p, Ws1Geom& g);

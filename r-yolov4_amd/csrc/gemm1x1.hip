@@ -24,8 +24,21 @@
 
 template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams p, const int nk, const int gridN, const int wgn)
+// S2D instantiations: the space-to-depth form of a stride-2 3x3 data gradient with 32 input channels (ConvGemmParams.s2d_cin == 32: ONE
+// stride-1 GEMM over the dY grid, 2 x 2 taps, Nout = 4 parity blocks x 32 channels — the second layer of every backbone, the slowest launch of
+// the step on the generic kernel: 8-16 K steps that re-fetch a 64 KiB weight tile per 128 pixels).  K step k is (tap, 32-channel chunk):
+// a row's source is its pixel shifted by the tap (zero page outside the image), and quarter j of the epilogue IS parity block (ph, pw) = (j >> 1,
+// j & 1): row (img, a, b) of the tile goes to pixel (2a + ph, 2b + pw) of the full-resolution gradient, 64 bytes each.
+struct WsTaps {
+    int koff[8];               // K step -> element offset of its source relative to the row's own pixel: (dh * IW + dw) * ldA + chunk * 32
+    int wkoff[8];              // K step -> element offset inside a weight row: widx * Cin + chunk * 32
+    int ktap[8];               // K step -> tap (bit of the row's validity mask)
+    int dh[4], dw[4], ntaps;
+    unsigned m_img, s_img, m_row, s_row;       // exact n / (OH * OW) and n / OW for n < 2^31 as (mulhi(n, m) >> s); m == 0: divisor 1
+};
+
+template <int EPI, bool S2D = false>
+__global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams p, const int nk, const int gridN, const int wgn, const WsTaps tk)
 {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile indices, ring addresses and DMA destinations stay in SGPRs
@@ -43,7 +56,7 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
         const bool ok = n0 + r < p.Nout;
         const bf16_t* src = p.W + (int64_t)(n0 + r) * wrow + (((lane & 3) ^ swz) << 3);
         for (int c = 0; c < nk; c++)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(ok ? src + c * 32 : p.zeros), (lds_void_t*)(smem + c * (WS_BN * 32) + wave * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(ok ? src + (S2D ? tk.wkoff[c] : c * 32) : p.zeros), (lds_void_t*)(smem + c * (WS_BN * 32) + wave * 512), 16, 0, 0);
     }
     bf16_t* ring = smem + nk * (WS_BN * 32) + wave * WS_RING;
     const bf16_t* abase = p.A + (int64_t)(lane >> 2) * p.ldA + (((lane & 3) ^ swz) << 3);
@@ -72,17 +85,42 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
     const int64_t tstride = (int64_t)wgn * WS_WAVES;
     const bool full_n = n0 + WS_BN <= p.Nout;
     int64_t t = (int64_t)slot * WS_WAVES + wave;
-    auto issue = [&](const bf16_t* tp_, int rows_, int k, int sl, int q) {
-        const bf16_t* src = q * 16 + (lane >> 2) < rows_ ? tp_ + q * qoff + k * 32 : p.zeros;
+    // S2D: (image, row, column) of the lane's four rows of tile t_ (row = 16 q + lane / 4 — the DMA rows and the store rows of a lane are the
+    // same four): validity of every tap as bit (8 q + tap), and the output pixel index (img * OHf + 2 a) * OWf + 2 b
+    auto row_info = [&](int64_t t_, unsigned& vmask, int64_t* pix) {
+        vmask = 0;
+        const int HW = p.OH * p.OW;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t m = t_ * WS_TM + q * 16 + (lane >> 2);
+            const unsigned mm = (unsigned)(m < M ? m : 0);
+            const unsigned img = tk.m_img ? __umulhi(mm, tk.m_img) >> tk.s_img : mm;
+            const unsigned rem = mm - img * (unsigned)HW;
+            const unsigned a = tk.m_row ? __umulhi(rem, tk.m_row) >> tk.s_row : rem;
+            const unsigned b = rem - a * (unsigned)p.OW;
+            if (m < M) {
+#pragma unroll
+                for (int tp_ = 0; tp_ < 4; tp_++)
+                    if (tp_ < tk.ntaps && (unsigned)((int)a + tk.dh[tp_]) < (unsigned)p.IH && (unsigned)((int)b + tk.dw[tp_]) < (unsigned)p.IW) vmask |= 1u << (8 * q + tp_);
+            }
+            if (pix) pix[q] = ((int64_t)img * p.OHf + 2 * a) * p.OWf + 2 * b;
+        }
+    };
+    auto issue = [&](const bf16_t* tp_, int rows_, unsigned vm_, int k, int sl, int q) {
+        const bf16_t* src;
+        if constexpr (S2D) src = (vm_ >> (8 * q + tk.ktap[k])) & 1 ? tp_ + q * qoff + tk.koff[k] : p.zeros;
+        else src = q * 16 + (lane >> 2) < rows_ ? tp_ + q * qoff + k * 32 : p.zeros;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ring + sl * (WS_TM * 32) + q * 512), 16, 0, 0);
     };
     if (t < tiles) {
         const bf16_t* tp = abase + t * WS_TM * p.ldA;
         int rows_left = (int)(M - t * WS_TM < WS_TM ? M - t * WS_TM : WS_TM);
+        unsigned vmask = 0, vmask_next = 0;
+        if constexpr (S2D) row_info(t, vmask, nullptr);
 #pragma unroll
-        for (int q = 0; q < 4; q++) issue(tp, rows_left, 0, 0, q);
+        for (int q = 0; q < 4; q++) issue(tp, rows_left, vmask, 0, 0, q);
 #pragma unroll
-        for (int q = 0; q < 4; q++) issue(tp, rows_left, 1, 1, q);
+        for (int q = 0; q < 4; q++) issue(tp, rows_left, vmask, 1, 1, q);
         int cur = 0;                                               // slot of the stage consumed next
         bool first = true;
         while (true) {
@@ -90,6 +128,7 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
             const bool has_next = tn < tiles;
             const bf16_t* tpn = abase + tn * WS_TM * p.ldA;
             const int rows_next = has_next ? (int)(M - tn * WS_TM < WS_TM ? M - tn * WS_TM : WS_TM) : 0;
+            if constexpr (S2D) { if (has_next) row_info(tn, vmask_next, nullptr); }
             f32x16 acc[2][4];
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -117,6 +156,7 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                 const bool here = k + 2 < nk, more = here || has_next;
                 const bf16_t* ip = here ? tp : tpn;
                 const int irows = here ? rows_left : rows_next, ik = here ? k + 2 : k + 2 - nk;
+                const unsigned ivm = here ? vmask : vmask_next;
                 const int isl = cur == 0 ? 2 : cur - 1;             // (cur + 2) % 3
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
@@ -125,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
                     if ((q & 3) == 3) {                             // four DMA pieces in the MFMA shadow
                         __builtin_amdgcn_sched_barrier(0);
-                        if (more) issue(ip, irows, ik, isl, q >> 2);
+                        if (more) issue(ip, irows, ivm, ik, isl, q >> 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -135,6 +175,8 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
             // at chunk c ^ ((r >> 1) & 3) (8-byte writes of a lane quad and the 16-byte row reads both spread over the banks) ---------------
             bf16_t* stage = ring + (cur == 0 ? 2 : cur - 1) * (WS_TM * 32);
             const int64_t m0 = t * WS_TM;
+            int64_t pix[4] = {0, 0, 0, 0};
+            if constexpr (S2D) { unsigned unused; row_info(t, unused, pix); }
             const int rc = lane & 3, rr = lane >> 2;                // store phase: 16-byte chunk rc of rows rr + 16 it
             const int rsw = (rc ^ ((lane >> 3) & 3)) * 8;
             const int wsw = (l31 >> 1) & 3;
@@ -160,17 +202,27 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                         *reinterpret_cast<uint2*>(stage + (i * 32 + l31) * 32 + ((g4 ^ wsw) << 3) + 4 * h) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     }
                 // (same-wave LDS hand-off: the wave's own ds_write -> ds_read ordering)
-                const int n = n0 + j * 32 + rc * 8;
+                const int n = S2D ? rc * 8 : n0 + j * 32 + rc * 8;       // S2D: channel inside parity block j
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (m0 + rr) * p.ldC + n;
+                bf16_t* os[4];                                            // S2D: the four rows' pixels of parity block j
+                if constexpr (S2D) {
+#pragma unroll
+                    for (int it = 0; it < 4; it++) os[it] = reinterpret_cast<bf16_t*>(p.out) + (pix[it] + (int64_t)(j >> 1) * p.OWf + (j & 1)) * p.ldC + n;
+                }
+                auto dst = [&](int it) -> bf16_t* {
+                    if constexpr (S2D) return os[it];
+                    else return o + (int64_t)it * 16 * p.ldC;
+                };
+                const bool n_ok = S2D || n < p.Nout;
                 uint4 v[4];
 #pragma unroll
                 for (int it = 0; it < 4; it++) v[it] = *reinterpret_cast<const uint4*>(stage + (it * 16 + rr) * 32 + rsw);
                 if (rows_left == WS_TM) {                           // wave-uniform: every tile but the last of the tensor
-                    if (n < p.Nout) {
+                    if (n_ok) {
                         if constexpr (accum) {
                             uint4 oldv[4];
 #pragma unroll
-                            for (int it = 0; it < 4; it++) oldv[it] = *reinterpret_cast<const uint4*>(o + (int64_t)it * 16 * p.ldC);
+                            for (int it = 0; it < 4; it++) oldv[it] = *reinterpret_cast<const uint4*>(dst(it));
 #pragma unroll
                             for (int it = 0; it < 4; it++) {
                                 const unsigned* a = reinterpret_cast<const unsigned*>(&v[it]);
@@ -184,14 +236,15 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                             }
                         }
 #pragma unroll
-                        for (int it = 0; it < 4; it++) *reinterpret_cast<uint4*>(o + (int64_t)it * 16 * p.ldC) = v[it];
+                        for (int it = 0; it < 4; it++) *reinterpret_cast<uint4*>(dst(it)) = v[it];
                     }
                 } else {                                            // the tensor's last tile (also this wave's last): row masks
+#pragma unroll
                     for (int it = 0; it < 4; it++) {
-                        if (it * 16 + rr >= rows_left || n >= p.Nout) continue;
+                        if (it * 16 + rr >= rows_left || !n_ok) continue;
                         uint4 w = v[it];
                         if constexpr (accum) {
-                            const uint4 old = *reinterpret_cast<const uint4*>(o + (int64_t)it * 16 * p.ldC);
+                            const uint4 old = *reinterpret_cast<const uint4*>(dst(it));
                             const unsigned* a = reinterpret_cast<const unsigned*>(&w);
                             const unsigned* b = reinterpret_cast<const unsigned*>(&old);
                             unsigned x[4];
@@ -201,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                                                 __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(b[e] & 0xffff0000u));
                             w = make_uint4(x[0], x[1], x[2], x[3]);
                         }
-                        *reinterpret_cast<uint4*>(o + (int64_t)it * 16 * p.ldC) = w;
+                        *reinterpret_cast<uint4*>(dst(it)) = w;
                     }
                 }
                 if constexpr (stats) {
@@ -228,6 +281,7 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
             t = tn;
             tp = tpn;
             rows_left = rows_next;
+            vmask = vmask_next;
         }
     }
     if constexpr (stats) {
@@ -264,7 +318,40 @@ static int ws_mode()
     return m;
 }
 
+static bool ws1_geometry_1x1(const ConvGemmParams& p, Ws1Geom& g);
+// the space-to-depth data gradient of a 32-input-channel stride-2 layer (see WsTaps): RYOLO_GEMM_WS_S2D = 0 keeps it on the generic kernel
+static bool ws1_s2d_eligible(const ConvGemmParams& p)
+{
+    static const bool on = !(getenv("RYOLO_GEMM_WS_S2D") && atoi(getenv("RYOLO_GEMM_WS_S2D")) == 0);
+    if (!on || p.s2d_cin != 32 || p.Nout != 128 || p.nclasses != 1 || p.oh_mul != 2 || p.ow_mul != 2 || p.cls[0].oh_add || p.cls[0].ow_add) return false;
+    const int nt = p.cls[0].ntaps;
+    if (nt < 1 || nt > 4 || p.Cin % 32 || nt * (p.Cin / 32) > 8 || nt * (p.Cin / 32) < 2) return false;
+    if (p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW || p.OHf != 2 * p.OH || p.OWf != 2 * p.OW) return false;
+    if (p.pool_idx || p.nbstat || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.ldA % 8 || p.ldC % 8) return false;
+    if ((int64_t)p.NB * p.OH * p.OW >= (1ll << 31) || (int64_t)(p.IW + 1) * p.ldA >= (1ll << 30)) return false;
+    return true;
+}
+
 bool ws1_geometry(const ConvGemmParams& p, Ws1Geom& g)
+{
+    g.ok = 0;
+    g.s2d = 0;
+    if ((p.pipe & 0xff) == 1 && p.zeros && ws1_s2d_eligible(p)) {
+        const int64_t tiles = ry_cdiv((int64_t)p.NB * p.OH * p.OW, WS_TM);
+        static const int cus = getenv("RYOLO_GEMM_WS_WGS") ? atoi(getenv("RYOLO_GEMM_WS_WGS")) : 256;
+        g.nk = p.cls[0].ntaps * (p.Cin / 32);
+        g.gridN = 1;
+        g.wgn = (int)(tiles < (int64_t)cus * WS_WAVES ? ry_cdiv(tiles, WS_WAVES) : cus);
+        g.lds_bytes = (unsigned)((g.nk * WS_BN * 32 + WS_WAVES * WS_RING) * sizeof(bf16_t));
+        g.stats_rows = g.wgn * WS_WAVES;
+        g.s2d = 1;
+        g.ok = 1;
+        return true;
+    }
+    return ws1_geometry_1x1(p, g);
+}
+
+static bool ws1_geometry_1x1(const ConvGemmParams& p, Ws1Geom& g)
 {
     g.ok = 0;
     const int mode = ws_mode();
@@ -293,18 +380,41 @@ bool ws1_geometry(const ConvGemmParams& p, Ws1Geom& g)
 
 int ws1_launch(const ConvGemmParams& p, const Ws1Geom& g, hipStream_t stream)
 {
-    static RyLdsAttr attr[4];
+    static RyLdsAttr attr[6];
+    WsTaps tk = {};
+    if (g.s2d) {
+        const TapClass& tc = p.cls[0];
+        const int cch = p.Cin / 32;
+        tk.ntaps = tc.ntaps;
+        for (int t = 0; t < tc.ntaps; t++) { tk.dh[t] = tc.dh[t]; tk.dw[t] = tc.dw[t]; }
+        for (int k = 0; k < g.nk; k++) {
+            const int t = k / cch, c = k - t * cch;
+            tk.koff[k] = (tc.dh[t] * p.IW + tc.dw[t]) * p.ldA + c * 32;
+            tk.wkoff[k] = tc.widx[t] * p.Cin + c * 32;
+            tk.ktap[k] = t;
+        }
+        auto magic = [](unsigned d, unsigned& m, unsigned& sh) {     // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (m == 0: d == 1)
+            if (d < 2) { m = 0; sh = 0; return; }
+            unsigned l = 0;
+            while ((1ull << l) < d) l++;
+            m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+            sh = l - 1;
+        };
+        magic((unsigned)(p.OH * p.OW), tk.m_img, tk.s_img);
+        magic((unsigned)p.OW, tk.m_row, tk.s_row);
+    }
     auto go = [&](auto kern, RyLdsAttr& at) -> int {
         if (int rc = ry_max_dynamic_lds(at, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-        hipLaunchKernelGGL(kern, dim3(g.gridN * g.wgn), dim3(512), g.lds_bytes, stream, p, g.nk, g.gridN, g.wgn);
+        hipLaunchKernelGGL(kern, dim3(g.gridN * g.wgn), dim3(512), g.lds_bytes, stream, p, g.nk, g.gridN, g.wgn, tk);
         RY_CHECK_LAUNCH();
         return RY_OK;
     };
+    if (g.s2d) return p.epi == EPI_ACCUM ? go(&gemm1x1_ws_kernel<EPI_ACCUM, true>, attr[5]) : go(&gemm1x1_ws_kernel<EPI_RAW, true>, attr[4]);
     switch (p.epi) {
-    case EPI_RAW: return go(&gemm1x1_ws_kernel<EPI_RAW>, attr[0]);
-    case EPI_STATS: return go(&gemm1x1_ws_kernel<EPI_STATS>, attr[1]);
-    case EPI_AFFINE_ACT: return go(&gemm1x1_ws_kernel<EPI_AFFINE_ACT>, attr[2]);
-    case EPI_ACCUM: return go(&gemm1x1_ws_kernel<EPI_ACCUM>, attr[3]);
+    case EPI_RAW: return go(&gemm1x1_ws_kernel<EPI_RAW, false>, attr[0]);
+    case EPI_STATS: return go(&gemm1x1_ws_kernel<EPI_STATS, false>, attr[1]);
+    case EPI_AFFINE_ACT: return go(&gemm1x1_ws_kernel<EPI_AFFINE_ACT, false>, attr[2]);
+    case EPI_ACCUM: return go(&gemm1x1_ws_kernel<EPI_ACCUM, false>, attr[3]);
     }
     return RY_ERR_ARG;
 }

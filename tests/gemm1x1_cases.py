@@ -96,3 +96,68 @@ def test_repeatable_bits():
     y1, s1 = _run(17 * 1000, 256, 256, epi=1, seed=3)
     y2, s2 = _run(17 * 1000, 256, 256, epi=1, seed=3)
     assert torch.equal(y1, y2) and torch.equal(s1, s2)
+
+
+def _run_s2d(NB, OH, OW, Cout, epi, ld_extra=0, seed=0):
+    """The space-to-depth instantiation: data gradient of Conv2d(32, Cout, 3, stride 2, pad 1) as ONE stride-1 GEMM over the dY grid
+    (ryolo_pack_s2d weights, 2 x 2 taps, depth-to-space store), against torch autograd in fp32 on the same bf16 operands."""
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S
+    hip.lib()
+    S.check_layouts()
+    dev = "cuda:0"
+    Cin = 32
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev)
+    wp = torch.zeros(4 * Cin, 4, Cout, dtype=torch.bfloat16, device=dev)
+    hip.call("ryolo_pack_s2d", w.data_ptr(), Cout, Cin, wp.data_ptr(), hip.stream())
+    M = NB * OH * OW
+    ldA, ldC = Cout + ld_extra, Cin + ld_extra
+    dyfull = torch.randn(M, ldA, generator=g).to(torch.bfloat16).to(dev)
+    dxfull = (torch.randn(NB * 4 * OH * OW, ldC, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dx0 = dxfull.clone()
+    zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+    p = S.ConvGemmParams()
+    p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = dyfull.data_ptr(), NB, OH, OW, Cout, ldA
+    p.W, p.Nout, p.wtaps = wp.data_ptr(), 4 * Cin, 4
+    p.OH, p.OW, p.sh, p.sw = OH, OW, 1, 1
+    p.oh_mul, p.ow_mul, p.OHf, p.OWf = 2, 2, 2 * OH, 2 * OW
+    p.nclasses = 1
+    tc = p.cls[0]
+    tc.ntaps = 4
+    for t, (da, db) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        tc.dh[t], tc.dw[t], tc.widx[t] = da, db, 2 * da + db
+    p.epi, p.out, p.ldC = epi, dxfull.data_ptr(), ldC
+    p.zeros, p.pipe, p.s2d_cin = zeros.data_ptr(), 0x201, Cin
+    rows, kern = S.I(), S.I()
+    hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+    assert kern.value & 0xff == 2, f"not routed to the persistent kernel (kernel {kern.value:#x})"
+    hip.call("ryolo_conv_gemm", p, hip.stream())
+    torch.cuda.synchronize()
+    x = torch.zeros(NB, Cin, 2 * OH, 2 * OW, device=dev, requires_grad=True)
+    wq = w.to(torch.bfloat16).float()                                          # the packed image holds bf16-rounded weights
+    y = torch.nn.functional.conv2d(x, wq, stride=2, padding=1)
+    y.backward(dyfull[:, :Cout].float().view(NB, OH, OW, Cout).permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+    got = dxfull[:, :Cin].float()
+    if epi == S.EPI_ACCUM:
+        ref = ref.to(torch.bfloat16).float() + dx0[:, :Cin].float()
+    err = (got - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 2e-2
+    assert bool((err <= tol).all()), f"max err {float(err.max())} at {int(err.argmax())}"
+    assert float((got - ref).norm() / ref.norm()) < 4e-3
+    if ld_extra:
+        assert torch.equal(dxfull[:, Cin:], dx0[:, Cin:]), "wrote outside its channel slice"
+    return dxfull
+
+
+@pytest.mark.parametrize("epi", [0, 4])
+@pytest.mark.parametrize("geom", [(2, 32, 32, 64), (3, 25, 19, 64), (1, 7, 5, 64), (2, 40, 40, 32), (5, 16, 48, 64)])
+def test_space_to_depth_data_gradient(geom, epi):
+    _run_s2d(*geom, epi=epi, seed=epi + 1)
+
+
+def test_space_to_depth_channel_slices_and_repeatability():
+    a = _run_s2d(2, 20, 24, 64, epi=0, ld_extra=32, seed=5)
+    b = _run_s2d(2, 20, 24, 64, epi=0, ld_extra=32, seed=5)
+    assert torch.equal(a, b)
