@@ -208,6 +208,7 @@ struct Ws1Geom {
     int gridN, wgn;            // 128-channel n tiles; workgroups per n tile (grid = gridN * wgn <= CUs, one workgroup per CU)
     int stats_rows;            // partial-statistics rows = waves per n tile (one row per wave for the whole launch)
     int s2d;                   // 1: the space-to-depth data-gradient instantiation (2 x 2 taps, depth-to-space store)
+    int pool;                  // 1: the instantiation that adds a MaxPool2d(2, 2) gradient in its store (ConvGemmParams.pool_idx)
     unsigned lds_bytes;
 };
 bool ws1_geometry(const ConvGemmParams& p, Ws1Geom& g);

@@ -37,7 +37,11 @@ struct WsTaps {
     unsigned m_img, s_img, m_row, s_row;       // exact n / (OH * OW) and n / OW for n < 2^31 as (mulhi(n, m) >> s); m == 0: divisor 1
 };
 
-template <int EPI, bool S2D = false>
+// POOL instantiations: pointwise data gradients that also carry the gradient of a MaxPool2d(2, 2) of the same tensor (ConvGemmParams.pool_idx,
+// MaxConv blocks): out[(h, w), n] += pool_dz[(h / 2, w / 2), n] where the argmax offset of that window equals (h & 1) * 2 + (w & 1) — the arithmetic
+// of the generic kernel's store loop (round the GEMM value to bf16, add, round; then the accumulate epilogue).  On the generic kernel these launches
+// lose the identity-grid fast path (814 us for 128 -> 256 @200^2 against ~500 for the plain layer).
+template <int EPI, bool S2D = false, bool POOL = false>
 __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams p, const int nk, const int gridN, const int wgn, const WsTaps tk)
 {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -177,6 +181,34 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
             const int64_t m0 = t * WS_TM;
             int64_t pix[4] = {0, 0, 0, 0};
             if constexpr (S2D) { unsigned unused; row_info(t, unused, pix); }
+            int64_t pool_pp[4] = {0, 0, 0, 0};                      // POOL: pooled pixel and window offset of the lane's four rows
+            unsigned pool_want[4] = {0, 0, 0, 0};
+            if constexpr (POOL) {
+                const int HW = p.OH * p.OW;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int64_t m = t * WS_TM + q * 16 + (lane >> 2);
+                    const unsigned mm = (unsigned)(m < M ? m : 0);
+                    const unsigned img = tk.m_img ? __umulhi(mm, tk.m_img) >> tk.s_img : mm;
+                    const unsigned rem = mm - img * (unsigned)HW;
+                    const unsigned a = tk.m_row ? __umulhi(rem, tk.m_row) >> tk.s_row : rem;
+                    const unsigned b = rem - a * (unsigned)p.OW;
+                    pool_pp[q] = ((int64_t)img * (p.OH >> 1) + (a >> 1)) * (p.OW >> 1) + (b >> 1);
+                    pool_want[q] = (a & 1) * 2 + (b & 1);
+                }
+            }
+            auto pool_add = [&](uint4& v_, const unsigned long long packed, const uint4& gz, const unsigned want) {
+                const unsigned* a = reinterpret_cast<const unsigned*>(&v_);
+                const unsigned* b = reinterpret_cast<const unsigned*>(&gz);
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float g0 = ((packed >> (16 * e)) & 0xff) == want ? __uint_as_float(b[e] << 16) : 0.f;
+                    const float g1 = ((packed >> (16 * e + 8)) & 0xff) == want ? __uint_as_float(b[e] & 0xffff0000u) : 0.f;
+                    w[e] = pack_bf2(__uint_as_float(a[e] << 16) + g0, __uint_as_float(a[e] & 0xffff0000u) + g1);
+                }
+                v_ = make_uint4(w[0], w[1], w[2], w[3]);
+            };
             const int rc = lane & 3, rr = lane >> 2;                // store phase: 16-byte chunk rc of rows rr + 16 it
             const int rsw = (rc ^ ((lane >> 3) & 3)) * 8;
             const int wsw = (l31 >> 1) & 3;
@@ -219,6 +251,17 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                 for (int it = 0; it < 4; it++) v[it] = *reinterpret_cast<const uint4*>(stage + (it * 16 + rr) * 32 + rsw);
                 if (rows_left == WS_TM) {                           // wave-uniform: every tile but the last of the tensor
                     if (n_ok) {
+                        if constexpr (POOL) {
+                            unsigned long long pk[4];
+                            uint4 gz[4];
+#pragma unroll
+                            for (int it = 0; it < 4; it++) {
+                                pk[it] = *reinterpret_cast<const unsigned long long*>(p.pool_idx + pool_pp[it] * p.pool_ldi + n);
+                                gz[it] = *reinterpret_cast<const uint4*>(p.pool_dz + pool_pp[it] * p.pool_ld + n);
+                            }
+#pragma unroll
+                            for (int it = 0; it < 4; it++) pool_add(v[it], pk[it], gz[it], pool_want[it]);
+                        }
                         if constexpr (accum) {
                             uint4 oldv[4];
 #pragma unroll
@@ -243,6 +286,9 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
                     for (int it = 0; it < 4; it++) {
                         if (it * 16 + rr >= rows_left || !n_ok) continue;
                         uint4 w = v[it];
+                        if constexpr (POOL)
+                            pool_add(w, *reinterpret_cast<const unsigned long long*>(p.pool_idx + pool_pp[it] * p.pool_ldi + n),
+                                     *reinterpret_cast<const uint4*>(p.pool_dz + pool_pp[it] * p.pool_ld + n), pool_want[it]);
                         if constexpr (accum) {
                             const uint4 old = *reinterpret_cast<const uint4*>(dst(it));
                             const unsigned* a = reinterpret_cast<const unsigned*>(&w);
@@ -354,11 +400,18 @@ bool ws1_geometry(const ConvGemmParams& p, Ws1Geom& g)
 static bool ws1_geometry_1x1(const ConvGemmParams& p, Ws1Geom& g)
 {
     g.ok = 0;
-    const int mode = ws_mode();
+    g.pool = 0;
+    // pointwise data gradients with a fused MaxPool gradient run here by default (RYOLO_GEMM_WS_POOL = 0: generic kernel); plain ones by RYOLO_GEMM_WS
+    static const bool pool_on = !(getenv("RYOLO_GEMM_WS_POOL") && atoi(getenv("RYOLO_GEMM_WS_POOL")) == 0);
+    const bool pool = p.pool_idx != nullptr;
+    if (pool && (!pool_on || !p.pool_dz || p.pool_ld % 8 || p.pool_ldi % 8 || (p.OH & 1) || (p.OW & 1) || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) ||
+                 (int64_t)p.NB * p.OH * p.OW >= (1ll << 31)))
+        return false;
+    const int mode = pool ? (ws_mode() == 2 ? 2 : 1) : ws_mode();
     if (!mode || (p.pipe & 0xff) != 1 || !p.zeros) return false;
     if (p.nclasses != 1 || p.cls[0].ntaps != 1 || p.cls[0].dh[0] || p.cls[0].dw[0] || p.cls[0].widx[0] || p.cls[0].oh_add || p.cls[0].ow_add) return false;
     if (p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW || p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW) return false;
-    if (p.pool_idx || p.s2d_cin || p.nbstat) return false;
+    if (p.s2d_cin || p.nbstat) return false;
     if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT && p.epi != EPI_ACCUM) return false;
     if (p.Cin % 32 || p.Cin > 256 || p.Cin < 64 || p.Nout % 8 || p.ldA % 8 || p.ldC % 8) return false;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
@@ -374,14 +427,26 @@ static bool ws1_geometry_1x1(const ConvGemmParams& p, Ws1Geom& g)
     } else if (mode != 2 && tiles < 6ll * g.wgn * WS_WAVES) return false;      // < 6 tiles per wave: the tail quantisation costs more than persistence buys
     g.lds_bytes = (unsigned)((g.nk * WS_BN * 32 + WS_WAVES * WS_RING) * sizeof(bf16_t));
     g.stats_rows = g.wgn * WS_WAVES;
+    g.pool = pool ? 1 : 0;
     g.ok = 1;
     return true;
 }
 
 int ws1_launch(const ConvGemmParams& p, const Ws1Geom& g, hipStream_t stream)
 {
-    static RyLdsAttr attr[6];
+    static RyLdsAttr attr[8];
     WsTaps tk = {};
+    auto magic = [](unsigned d, unsigned& m, unsigned& sh) {         // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (m == 0: d == 1)
+        if (d < 2) { m = 0; sh = 0; return; }
+        unsigned l = 0;
+        while ((1ull << l) < d) l++;
+        m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+        sh = l - 1;
+    };
+    if (g.s2d || g.pool) {
+        magic((unsigned)(p.OH * p.OW), tk.m_img, tk.s_img);
+        magic((unsigned)p.OW, tk.m_row, tk.s_row);
+    }
     if (g.s2d) {
         const TapClass& tc = p.cls[0];
         const int cch = p.Cin / 32;
@@ -393,15 +458,6 @@ int ws1_launch(const ConvGemmParams& p, const Ws1Geom& g, hipStream_t stream)
             tk.wkoff[k] = tc.widx[t] * p.Cin + c * 32;
             tk.ktap[k] = t;
         }
-        auto magic = [](unsigned d, unsigned& m, unsigned& sh) {     // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (m == 0: d == 1)
-            if (d < 2) { m = 0; sh = 0; return; }
-            unsigned l = 0;
-            while ((1ull << l) < d) l++;
-            m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
-            sh = l - 1;
-        };
-        magic((unsigned)(p.OH * p.OW), tk.m_img, tk.s_img);
-        magic((unsigned)p.OW, tk.m_row, tk.s_row);
     }
     auto go = [&](auto kern, RyLdsAttr& at) -> int {
         if (int rc = ry_max_dynamic_lds(at, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
@@ -409,6 +465,7 @@ int ws1_launch(const ConvGemmParams& p, const Ws1Geom& g, hipStream_t stream)
         RY_CHECK_LAUNCH();
         return RY_OK;
     };
+    if (g.pool) return p.epi == EPI_ACCUM ? go(&gemm1x1_ws_kernel<EPI_ACCUM, false, true>, attr[7]) : go(&gemm1x1_ws_kernel<EPI_RAW, false, true>, attr[6]);
     if (g.s2d) return p.epi == EPI_ACCUM ? go(&gemm1x1_ws_kernel<EPI_ACCUM, true>, attr[5]) : go(&gemm1x1_ws_kernel<EPI_RAW, true>, attr[4]);
     switch (p.epi) {
     case EPI_RAW: return go(&gemm1x1_ws_kernel<EPI_RAW, false>, attr[0]);

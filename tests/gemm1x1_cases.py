@@ -161,3 +161,57 @@ def test_space_to_depth_channel_slices_and_repeatability():
     a = _run_s2d(2, 20, 24, 64, epi=0, ld_extra=32, seed=5)
     b = _run_s2d(2, 20, 24, 64, epi=0, ld_extra=32, seed=5)
     assert torch.equal(a, b)
+
+
+def _run_pool(NB, H, W, Cin, Cout, epi, seed=0):
+    """The MaxPool-gradient instantiation: out[(h, w), n] = bf16(x @ w^T) + pool_dz[(h / 2, w / 2), n] where pool_idx == (h & 1) * 2 + (w & 1)
+    (then the accumulate epilogue), against the same arithmetic in torch."""
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S
+    hip.lib()
+    S.check_layouts()
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    M = NB * H * W
+    x = torch.randn(M, Cin, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Cout, Cin, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    y = (torch.randn(M, Cout, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    y0 = y.clone()
+    pidx = torch.randint(0, 4, (NB, H // 2, W // 2, Cout), generator=g, dtype=torch.uint8).to(dev)
+    pdz = torch.randn(NB, H // 2, W // 2, Cout, generator=g).to(torch.bfloat16).to(dev)
+    zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+    p = S.ConvGemmParams()
+    p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = x.data_ptr(), NB, H, W, Cin, Cin
+    p.W, p.Nout, p.wtaps = w.data_ptr(), Cout, 1
+    p.OH, p.OW, p.sh, p.sw = H, W, 1, 1
+    p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, H, W
+    p.nclasses = 1
+    p.cls[0].ntaps = 1
+    p.epi, p.out, p.ldC = epi, y.data_ptr(), Cout
+    p.zeros, p.pipe = zeros.data_ptr(), 0x201
+    p.pool_idx, p.pool_dz, p.pool_ldi, p.pool_ld = pidx.data_ptr(), pdz.data_ptr(), Cout, Cout
+    rows, kern = S.I(), S.I()
+    hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+    assert kern.value & 0xff == 2, f"not routed to the persistent kernel (kernel {kern.value:#x})"
+    hip.call("ryolo_conv_gemm", p, hip.stream())
+    torch.cuda.synchronize()
+    ref = (x.float() @ w.float().t()).to(torch.bfloat16).float().view(NB, H, W, Cout)
+    hh = torch.arange(H, device=dev).view(1, H, 1, 1)
+    ww = torch.arange(W, device=dev).view(1, 1, W, 1)
+    want = ((hh & 1) * 2 + (ww & 1)).to(torch.uint8)
+    up_idx = pidx.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    up_dz = pdz.float().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    ref = (ref + torch.where(up_idx == want, up_dz, torch.zeros_like(up_dz))).to(torch.bfloat16).float().view(M, Cout)
+    if epi == S.EPI_ACCUM:
+        ref = ref + y0.float()
+    got = y.float()
+    err = (got - ref).abs()
+    tol = 2.0 ** -6 * ref.abs() + 3e-2           # one more bf16 rounding than the plain store
+    assert bool((err <= tol).all()), f"max err {float(err.max())} at {int(err.argmax())}"
+    assert float((got - ref).norm() / ref.norm()) < 6e-3
+
+
+@pytest.mark.parametrize("epi", [0, 4])
+@pytest.mark.parametrize("geom", [(2, 20, 20, 128, 256), (3, 10, 14, 256, 128), (1, 6, 6, 64, 136), (2, 50, 50, 128, 256)])
+def test_maxpool_gradient_in_the_store(geom, epi):
+    _run_pool(*geom, epi=epi, seed=epi + 2)
