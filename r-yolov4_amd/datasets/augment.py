@@ -34,19 +34,175 @@ _I, _L, _P = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
 
 
 class ImagePool:
-    """uint8 HWC (BGR) images of different sizes packed into one device buffer (what cv2.imread leaves per file)."""
+    """Decoded uint8 HWC (BGR) images of different sizes (what cv2.imread leaves per file) resident in HBM, filled ON DEMAND and bounded
+    by a byte budget — the role of the reference's 8 DataLoader workers re-reading files from disk (lib/load.py:19).
 
-    def __init__(self, images, device):
-        self.shapes = [tuple(im.shape[:2]) for im in images]
-        sizes = [h * w * 3 for h, w in self.shapes]
-        self.offsets = [0]
-        for s in sizes[:-1]:
-            self.offsets.append(self.offsets[-1] + ((s + 15) // 16) * 16)
-        total = self.offsets[-1] + sizes[-1] if sizes else 0
-        host = torch.zeros(max(total, 1), dtype=torch.uint8)
-        for im, o, s in zip(images, self.offsets, sizes):
-            host[o:o + s] = torch.as_tensor(np.ascontiguousarray(im)).reshape(-1)
-        self.buf = host.to(device)
+    Memory is a list of equally sized SLABS (one torch uint8 tensor each); an image is bump-allocated into the current slab and addressed
+    by its 64-bit byte offset from slab 0's base pointer (`buf`), which is what the table-driven kernels take (ryolo_resize_hsv_batch /
+    ryolo_paste_rects: base + int64 offset; later slabs have offsets beyond — or below — slab 0).  With `budget_bytes` the pool holds at
+    most budget // slab slabs; when they are full the LEAST RECENTLY USED slab that the batch being assembled does not need is dropped as a
+    whole (its images leave the index) and refilled — LRU at slab granularity: no per-image free list, no fragmentation.  A dropped
+    image is decoded again when it is next asked for.  Reuse of a slab is ordered by the stream: the upload that overwrites it is enqueued
+    on the same stream as the kernels that read it before.
+
+    Host side: a decoded image is copied once into a PINNED staging tensor (torch's caching host allocator: the block is recycled only
+    after the asynchronous copy that reads it has completed) and uploaded with a non-blocking copy; missing images of a batch are decoded
+    by a thread pool (`workers`), so the host never holds more than the images in flight.
+
+    ImagePool(images, device) — the round-2/3 form — is the eager special case: every image is uploaded at construction, no budget."""
+
+    def __init__(self, images=None, device=None, *, count=None, decode=None, shapes=None, budget_bytes=None, slab_bytes=None, workers=8):
+        self.device = torch.device(device)
+        if images is not None:
+            images = list(images)
+            count, shapes = len(images), [tuple(im.shape[:2]) for im in images]
+            decode = images.__getitem__
+        self.count, self._decode, self.workers = int(count), decode, max(1, int(workers))
+        self._shapes = {} if shapes is None else {i: tuple(s) for i, s in enumerate(shapes)}
+        self.budget_bytes = None if budget_bytes is None else int(budget_bytes)
+        if slab_bytes is None:
+            slab_bytes = 1 << 30
+            if self.budget_bytes is not None:
+                slab_bytes = min(slab_bytes, max(self.budget_bytes // 4, 1 << 20))
+            if images is not None:                                  # eager pools are small (tests, fixtures): one slab of their own size
+                slab_bytes = max(sum(((h * w * 3 + 15) // 16) * 16 for h, w in shapes), 16)
+        self.slab_bytes = int(slab_bytes)
+        self.max_slabs = None if self.budget_bytes is None else max(1, self.budget_bytes // self.slab_bytes)
+        self._slabs, self._members, self._fill, self._touched = [], [], [], []     # per slab: tensor, image ids, bump pointer, LRU tick
+        self._where = {}                                                            # image id -> (slab, offset inside the slab)
+        self._tick, self._cur = 0, -1
+        self._executor = None
+        self.stats = {"decoded": 0, "uploaded_bytes": 0, "evicted_slabs": 0, "hits": 0}
+        if images is not None:
+            self.ensure(range(self.count))
+
+    # ---- what the kernels see
+    @property
+    def buf(self):
+        if not self._slabs:
+            self._new_slab()
+        return self._slabs[0]
+
+    @property
+    def shapes(self):
+        return _ShapeView(self)
+
+    @property
+    def offsets(self):
+        return _OffsetView(self)
+
+    def shape(self, i):
+        """(h, w) of image i without needing its pixels resident (known from the constructor or remembered from the first decode)."""
+        if i not in self._shapes:
+            self.ensure([i])
+        return self._shapes[i]
+
+    def offset(self, i):
+        """Byte offset of RESIDENT image i relative to `buf` (call ensure() for the batch first)."""
+        k, off = self._where[i]
+        return self._slabs[k].data_ptr() - self.buf.data_ptr() + off
+
+    def resident_bytes(self):
+        return len(self._slabs) * self.slab_bytes
+
+    # ---- residency
+    def _new_slab(self):
+        self._slabs.append(torch.empty(self.slab_bytes, dtype=torch.uint8, device=self.device))
+        self._members.append([])
+        self._fill.append(0)
+        self._touched.append(self._tick)
+        return len(self._slabs) - 1
+
+    def _slab_for(self, nbytes, pinned):
+        if nbytes > self.slab_bytes:
+            raise RuntimeError(f"ImagePool: one image needs {nbytes} bytes, a slab holds {self.slab_bytes} — raise slab_bytes / the budget")
+        if self._cur >= 0 and self._fill[self._cur] + nbytes <= self.slab_bytes:
+            return self._cur
+        if self.max_slabs is None or len(self._slabs) < self.max_slabs:
+            self._cur = self._new_slab()
+            return self._cur
+        victims = [k for k in range(len(self._slabs)) if k not in pinned]
+        if not victims:
+            raise RuntimeError(f"ImagePool: the images of ONE batch do not fit the budget ({self.budget_bytes} bytes = {self.max_slabs} slabs "
+                               f"of {self.slab_bytes}); raise budget_bytes or lower the batch size")
+        k = min(victims, key=lambda v: self._touched[v])
+        for i in self._members[k]:
+            del self._where[i]
+        self._members[k], self._fill[k] = [], 0
+        self.stats["evicted_slabs"] += 1
+        self._cur = k
+        return k
+
+    def ensure(self, indices):
+        """Make every image of `indices` resident (decode + upload the missing ones on the current stream); the slabs holding them are
+        protected from eviction for the duration of this call, i.e. one call = one batch."""
+        self._tick += 1
+        need = list(dict.fromkeys(int(i) for i in indices))
+        pinned = set()
+        missing = []
+        for i in need:
+            w = self._where.get(i)
+            if w is None:
+                missing.append(i)
+            else:
+                pinned.add(w[0])
+                self._touched[w[0]] = self._tick
+                self.stats["hits"] += 1
+        if not missing:
+            return
+        if len(missing) > 1 and self.workers > 1:
+            if self._executor is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._executor = ThreadPoolExecutor(self.workers)
+            decoded = self._executor.map(self._decode_one, missing)
+        else:
+            decoded = map(self._decode_one, missing)
+        for i, img in zip(missing, decoded):
+            nbytes = img.shape[0] * img.shape[1] * 3
+            k = self._slab_for(((nbytes + 15) // 16) * 16, pinned)
+            pinned.add(k)
+            off = self._fill[k]
+            if self.device.type == "cuda":
+                stage = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+                stage.numpy()[:] = img.reshape(-1)
+                self._slabs[k][off:off + nbytes].copy_(stage, non_blocking=True)
+            else:
+                self._slabs[k][off:off + nbytes] = torch.from_numpy(np.ascontiguousarray(img).reshape(-1))
+            self._fill[k] = off + ((nbytes + 15) // 16) * 16
+            self._members[k].append(i)
+            self._where[i] = (k, off)
+            self._touched[k] = self._tick
+            self.stats["decoded"] += 1
+            self.stats["uploaded_bytes"] += nbytes
+
+    def _decode_one(self, i):
+        img = np.asarray(self._decode(i))
+        if img.ndim == 2:
+            img = img[:, :, None]
+        if img.shape[2] != 3:                                       # base_dataset.py:177-178: grey images are stacked to 3 channels
+            img = np.repeat(img[:, :, :1], 3, axis=2)
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self._shapes[i] = tuple(img.shape[:2])
+        return img
+
+
+class _ShapeView:
+    def __init__(self, pool):
+        self.pool = pool
+
+    def __getitem__(self, i):
+        return self.pool.shape(i)
+
+    def __len__(self):
+        return self.pool.count
+
+
+class _OffsetView:
+    def __init__(self, pool):
+        self.pool = pool
+
+    def __getitem__(self, i):
+        return self.pool.offset(i)
 
 
 # ------------------------------------------------------------------------------------------------ placements (host integers)
@@ -170,7 +326,15 @@ def _check_layouts():
 
 
 def _to_device(arr, dev):
-    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    """A small host table (ctypes array / numpy array) -> device bytes through PINNED memory with a non-blocking copy on the current
+    stream (the pinned block comes from torch's caching host allocator, which recycles it only after the copy has completed)."""
+    raw = np.frombuffer(arr, dtype=np.uint8) if not isinstance(arr, np.ndarray) else np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return torch.from_numpy(raw.copy()).to(dev)
+    stage = torch.empty(max(raw.size, 1), dtype=torch.uint8, pin_memory=True)
+    stage.numpy()[:raw.size] = raw
+    return stage[:max(raw.size, 1)].to(dev, non_blocking=True)
 
 
 def paste(src_buf, rects, ncanvas, CH, CW, fill=114):
@@ -208,7 +372,7 @@ def resize_hsv_batch(pool, items, luts=None):
         maxpix = max(maxpix, nh * nw)
     stage = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
     if items:
-        lt = None if luts is None or not len(luts) else torch.as_tensor(np.ascontiguousarray(luts, dtype=np.uint8)).to(dev)
+        lt = None if luts is None or not len(luts) else _to_device(np.ascontiguousarray(luts, dtype=np.uint8), dev)
         hip.call("ryolo_resize_hsv_batch", hip.ptr(pool.buf), hip.ptr(_to_device(arr, dev)), len(items), maxpix, hip.ptr(lt), hip.ptr(stage),
                  hip.stream())
     return stage, offs
@@ -221,8 +385,8 @@ def label_stage(rows, mats, device):
     n = len(rows)
     out = torch.empty((n, 10), dtype=torch.float32, device=device)
     if n:
-        table = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy()).to(device)
-        mt = None if mats is None or not len(mats) else torch.as_tensor(np.ascontiguousarray(mats, dtype=np.float64).reshape(-1, 9)).to(device)
+        table = _to_device(np.frombuffer(rows.tobytes(), dtype=np.uint8), device)
+        mt = None if mats is None or not len(mats) else _to_device(np.ascontiguousarray(mats, dtype=np.float64).reshape(-1, 9), device).view(torch.float64)
         hip.call("ryolo_label_stage", hip.ptr(table), n, hip.ptr(mt), hip.ptr(out), hip.stream())
     return out
 
@@ -253,7 +417,7 @@ def warp_perspective(imgs, Ms, dsize, border=114):
     hip.require_device(imgs, "warp_perspective")
     B, H, W, _ = imgs.shape
     DW, DH = dsize
-    minv = torch.tensor(np.stack([np.linalg.inv(np.asarray(M, dtype=np.float64)) for M in Ms]).reshape(B, 9), dtype=torch.float64).to(imgs.device)
+    minv = _to_device(np.stack([np.linalg.inv(np.asarray(M, dtype=np.float64)) for M in Ms]).reshape(B, 9), imgs.device).view(torch.float64)
     out = torch.empty((B, DH, DW, 3), dtype=torch.uint8, device=imgs.device)
     hip.call("ryolo_warp_perspective_u8", hip.ptr(imgs.contiguous()), B, H, W, hip.ptr(minv), hip.ptr(out), DH, DW, border, hip.stream())
     return out

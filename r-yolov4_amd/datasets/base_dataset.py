@@ -13,7 +13,14 @@ Returns (imgs [B, 3, S, S] fp32 RGB in [0, 1], targets [n, 7 | 187]) exactly as 
                                                        for a WHOLE BATCH on the device (`assemble_batch`), the random draws made on the
                                                        host in the reference's order.  Subclasses (DOTA_dataset.py, UCASAOD_dataset.py)
                                                        only list files and parse labels, as in the reference.
-Image decode (cv2.imread) stays on the host: `imread` is injectable, the decoded uint8 images live in ONE device buffer (ImagePool).
+Image decode (cv2.imread) stays on the host: `imread` is injectable; decoded uint8 images are kept in HBM by an ImagePool that is filled
+on demand and bounded by `pool_budget_bytes` (LRU over slabs, pinned staging, thread-pool decode: datasets/augment.py).
+
+    ImageDataset                                       base_dataset.py:59-81 (detect.py:12,43): a folder of images -> letterbox -> RGB ->
+                                                       /255, batched on the device (`assemble_batch`, or `__getitems__` under a
+                                                       torch DataLoader as detect.py:44 builds it).
+    DeviceLoader                                       lib/load.py:19's DataLoader: batches assembled on a SIDE stream so that batch k + 1
+                                                       is prepared under training step k.
 """
 import os
 import random as _py_random
@@ -73,6 +80,20 @@ def _default_imread(path):
         raise RuntimeError("ryolov4_amd.datasets: no image decoder (cv2 / PIL) — pass imread=callable(path) -> uint8 HWC BGR")
 
 
+def _default_imsize(path):
+    """(h, w) from the file header when PIL is there (no pixel decode); None = unknown until the image is decoded."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            w, h = im.size
+        return h, w
+    except Exception:
+        return None
+
+
+_POOL_CACHE = {}          # (image file list, device, budget) -> (ImagePool, parsed labels): test.py calls load_data once per evaluation
+
+
 class BaseDataset:
     """Same constructor and subclass contract as the reference's BaseDataset (datasets/base_dataset.py:70-77): subclasses fill
     `img_files` / `label_files` and implement `load_files(label_path) -> (polys float32 [n, 8], labels [n])`.  Differences by design:
@@ -83,14 +104,25 @@ class BaseDataset:
     defaults to exactly those, and every draw is made in the reference's order (base_dataset.py:83-138, lib/augmentations.py:11,25,
     53-61), so the same seeds give the same sample composition (fixture G13: the imported reference's __getitem__ ran)."""
 
-    def __init__(self, hyp, img_size, augment, csl, normalized_labels, device=None, imread=None, rng=None):
+    def __init__(self, hyp, img_size, augment, csl, normalized_labels, device=None, imread=None, rng=None, imsize=None,
+                 pool_budget_bytes=None, pool_slab_bytes=None, decode_workers=8, share_pool=True):
         self.hyp, self.img_size, self.augment, self.csl, self.normalized_labels = hyp, img_size, augment, csl, normalized_labels
         self.mosaic_border = [-img_size // 2, -img_size // 2]
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         self.imread = imread or _default_imread
+        self.imsize = imsize or (_default_imsize if imread is None else (lambda path: None))
         self.rng = rng or (_py_random, np.random)
         self.img_files, self.label_files = [], []
         self._pool = self._labels = None
+        self.pool_budget_bytes, self.pool_slab_bytes, self.decode_workers, self.share_pool = pool_budget_bytes, pool_slab_bytes, decode_workers, share_pool
+
+    def shard(self, rank, world_size):
+        """Data parallel: this rank keeps every world_size-th file (and draws its mosaic partners among them), so the pool of a rank holds
+        its shard only.  Call before the first batch."""
+        if self._pool is not None:
+            raise RuntimeError("BaseDataset.shard: call before the first batch is assembled")
+        self.img_files, self.label_files = self.img_files[rank::world_size], self.label_files[rank::world_size]
+        return self
 
     def __len__(self):
         return len(self.img_files)
@@ -100,34 +132,49 @@ class BaseDataset:
 
     # ------------------------------------------------------------------ cache: decoded images + parsed labels, resident
     def set_arrays(self, images, polys, labels):
-        """Use already decoded images (uint8 HWC BGR, 1- or 3-channel) and parsed labels instead of reading files."""
-        imgs = [self._three_channels(np.asarray(im)) for im in images]
-        self._pool = A.ImagePool(imgs, self.device)
-        self._labels = [(np.asarray(p, dtype=np.float32).reshape(-1, 8), np.asarray(c, dtype=np.float32).reshape(-1)) for p, c in zip(polys, labels)]
+        """Use already decoded images (uint8 HWC BGR, 1- or 3-channel) and parsed labels instead of reading files (the budget applies:
+        with pool_budget_bytes the arrays are re-uploaded on demand like files are re-decoded)."""
+        images = list(images)
+        self._pool = A.ImagePool(count=len(images), decode=images.__getitem__, shapes=[tuple(np.asarray(im).shape[:2]) for im in images],
+                                 device=self.device, budget_bytes=self.pool_budget_bytes, slab_bytes=self.pool_slab_bytes, workers=1)
+        self._labels = {i: (np.asarray(p, dtype=np.float32).reshape(-1, 8), np.asarray(c, dtype=np.float32).reshape(-1))
+                        for i, (p, c) in enumerate(zip(polys, labels))}
         if not self.img_files:
-            self.img_files = [f"<array {i}>" for i in range(len(imgs))]
+            self.img_files = [f"<array {i}>" for i in range(len(images))]
             self.label_files = list(self.img_files)
 
-    @staticmethod
-    def _three_channels(img):
-        if img.ndim == 2:
-            img = img[:, :, None]
-        if img.shape[2] != 3:                                    # base_dataset.py:177-178: grey images are stacked to 3 channels
-            img = np.repeat(img[:, :, :1], 3, axis=2)
-        return np.ascontiguousarray(img, dtype=np.uint8)
-
     def cache(self):
+        """The pool of this dataset's images: nothing is decoded here — images are decoded (thread pool), staged in pinned memory and
+        uploaded when a batch first needs them, and dropped slab-wise (LRU) once pool_budget_bytes is reached.  Image sizes come from the
+        file headers (`imsize`) so that planning a batch does not need pixels.  Datasets over the same files on the same device share
+        one pool (test.py calls load_data for every evaluation)."""
         if self._pool is None:
-            images, polys, labels = [], [], []
-            for ip, lp in zip(self.img_files, self.label_files):
-                images.append(self.imread(ip))
-                lp = lp.rstrip()
-                assert os.path.exists(lp), "Label file {} not found".format(lp)          # base_dataset.py:221
-                p, c = self.load_files(lp)
-                polys.append(p.numpy() if isinstance(p, torch.Tensor) else p)
-                labels.append(c.numpy() if isinstance(c, torch.Tensor) else (c if len(c) else np.zeros(0, np.float32)))
-            self.set_arrays(images, polys, labels)
+            files = self.img_files
+            key = (tuple(files), str(self.device), self.pool_budget_bytes, self.pool_slab_bytes, id(self.imread) if self.imread is not _default_imread else 0)
+            if self.share_pool and key in _POOL_CACHE:
+                self._pool, self._labels = _POOL_CACHE[key]
+                return self._pool
+            shapes = [self.imsize(p) for p in files]
+            imread = self.imread
+            self._pool = A.ImagePool(count=len(files), decode=lambda i: imread(files[i]), shapes=None if any(s is None for s in shapes) else shapes,
+                                     device=self.device, budget_bytes=self.pool_budget_bytes, slab_bytes=self.pool_slab_bytes,
+                                     workers=self.decode_workers)
+            self._labels = {}
+            if self.share_pool:
+                _POOL_CACHE[key] = (self._pool, self._labels)
         return self._pool
+
+    def labels_of(self, index):
+        """(polys float32 [n, 8], classes float32 [n]) of image `index`, parsed on first use."""
+        got = self._labels.get(index)
+        if got is None:
+            lp = self.label_files[index].rstrip()
+            assert os.path.exists(lp), "Label file {} not found".format(lp)          # base_dataset.py:221
+            p, c = self.load_files(lp)
+            p = p.numpy() if isinstance(p, torch.Tensor) else p
+            c = c.numpy() if isinstance(c, torch.Tensor) else (c if len(c) else np.zeros(0, np.float32))
+            got = self._labels[index] = (np.asarray(p, dtype=np.float32).reshape(-1, 8), np.asarray(c, dtype=np.float32).reshape(-1))
+        return got
 
     # ------------------------------------------------------------------ the draws, in the reference's order
     def _load_image_plan(self, index, items, luts):
@@ -207,6 +254,7 @@ class BaseDataset:
             if self.augment and nrd.random() < self.hyp["flipud"]:
                 flags[slot] |= 2
         # ---- pixels -----------------------------------------------------------------------------------------------------------------
+        pool.ensure(it[0] for it in items)                        # decode + upload what is not resident (this batch's slabs are protected)
         stage, offs = A.resize_hsv_batch(pool, items, np.stack(luts) if luts else None)
         final = torch.empty((B, s, s, 3), dtype=torch.uint8, device=dev)
         mos = [c for c in canvases if c["kind"] == "mosaic"]
@@ -244,17 +292,17 @@ class BaseDataset:
                 mats.append(c["M"])
             if c["kind"] == "mosaic":
                 for u, ds_index, hw0, hw in c["uses"]:
-                    polys, cls = self._labels[ds_index]
+                    polys, cls = self.labels_of(ds_index)
                     rows.append(A.label_rows(polys, cls, c["slot"], hw0, hw, u, mat, self.normalized_labels))
             else:
-                polys, cls = self._labels[c["index"]]
+                polys, cls = self.labels_of(c["index"])
                 u = A.Use(c["item"], None, c["pad"], None, None)
                 rows.append(A.label_rows(polys, cls, c["slot"], c["hw0"], c["hw"], u, mat, self.normalized_labels))
         rows = np.concatenate(rows) if rows else np.zeros(0, dtype=A.LABEL_ROW_DTYPE)
         # (mixup appends the second canvas' labels behind the first's: canvases of one sample are adjacent and in that order; samples are
         # in slot order, so the rows are already ordered the way collate_fn's torch.cat orders them)
         targets10 = A.label_stage(rows, np.stack(mats) if mats else None, dev)
-        imgs, targets = finalize_batch(final, targets10, torch.from_numpy(flags), self.csl)
+        imgs, targets = finalize_batch(final, targets10, A._to_device(flags, dev), self.csl)
         return [self.img_files[i] for i in indices], imgs, targets
 
     # ------------------------------------------------------------------ API parity with torch.utils.data.Dataset users
@@ -272,16 +320,87 @@ class BaseDataset:
 
 class DeviceLoader:
     """Iterates a BaseDataset in batches assembled on the device (the role of torch.utils.data.DataLoader(dataset, batch_size, shuffle,
-    num_workers=8, collate_fn=dataset.collate_fn) at lib/load.py:19): yields (paths, imgs, targets)."""
+    num_workers=8, collate_fn=dataset.collate_fn) at lib/load.py:19): yields (paths, imgs, targets).
 
-    def __init__(self, dataset, batch_size, shuffle):
+    Loader in the loop: the batch is assembled on a stream of the loader's own (`side_stream=True`, the default on a HIP device).  The
+    consumer enqueues training step k asynchronously and asks for the next batch: its decode / planning runs on the host and its ~10
+    launches run on the side stream WHILE step k occupies the compute stream; the compute stream only waits for the batch's event.
+    rank / world_size: data parallel — the rank iterates (and pools) its shard of the files (BaseDataset.shard)."""
+
+    def __init__(self, dataset, batch_size, shuffle, side_stream=True, rank=0, world_size=1):
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        if world_size > 1:
+            dataset.shard(rank, world_size)
+        self._side = torch.cuda.Stream(device=dataset.device) if side_stream and dataset.device.type == "cuda" and torch.cuda.is_available() else None
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def assemble(self, indices):
+        if self._side is None:
+            return self.dataset.assemble_batch(indices)
+        main = torch.cuda.current_stream(self.dataset.device)
+        with torch.cuda.stream(self._side):
+            paths, imgs, targets = self.dataset.assemble_batch(indices)
+            done = self._side.record_event()
+        main.wait_event(done)
+        imgs.record_stream(main)
+        targets.record_stream(main)
+        return paths, imgs, targets
 
     def __iter__(self):
         n = len(self.dataset)
         order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
         for a in range(0, n, self.batch_size):
-            yield self.dataset.assemble_batch(order[a:a + self.batch_size])
+            yield self.assemble(order[a:a + self.batch_size])
+
+
+class ImageDataset:
+    """The detect path's dataset (datasets/base_dataset.py:59-81; detect.py:12,43-44): every `*.ext` file of a folder, letterboxed to
+    img_size x img_size on 114-grey (pad_to_square: cv2.resize INTER_LINEAR + copyMakeBorder), BGR -> RGB, float / 255.
+
+    Same constructor, `__len__`, `__getitem__(index) -> (img_path, img [3, S, S])`.  The work is done per BATCH on the device:
+    `assemble_batch(indices)` decodes on the host (imread injectable), uploads the uint8 images through pinned memory and runs three
+    launches — ryolo_resize_hsv_batch (the resize of every image of the batch), ryolo_paste_rects (onto the grey canvases),
+    ryolo_to_tensor.  `__getitems__` makes torch.utils.data.DataLoader(dataset, batch_size, shuffle=False) (detect.py:44) use that batch
+    path; `loader(batch_size)` iterates it without the DataLoader's re-stacking copy."""
+
+    def __init__(self, folder_path, img_size=416, ext="png", device=None, imread=None):
+        import glob
+        self.files = sorted(glob.glob(os.path.join(folder_path, "*.{}".format(ext))))
+        self.img_size = img_size
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self.imread = imread or _default_imread
+
+    def __len__(self):
+        return len(self.files)
+
+    def assemble_batch(self, indices):
+        """-> (paths, imgs [B, 3, S, S] fp32 RGB in [0, 1] on the device)."""
+        s, dev = self.img_size, self.device
+        paths = [self.files[i % len(self.files)] for i in indices]
+        pool = A.ImagePool([np.asarray(self.imread(p)) for p in paths], dev)      # grey -> 3 channels inside the pool
+        items, rects = [], []
+        for k in range(len(paths)):
+            (nw, nh), (top, bottom, left, right), _ = A.pad_to_square_plan(pool.shape(k), (s, s))
+            if (top + nh + bottom, left + nw + right) != (s, s):
+                raise RuntimeError("ImageDataset: letterbox did not produce a square canvas")
+            items.append((k, (nh, nw), A.INTERP_COPY if (nh, nw) == pool.shape(k) else A.INTERP_LINEAR, -1))
+            rects.append((nw, A.Placed(0, 0, left, top, nw, nh), k))
+        stage, offs = A.resize_hsv_batch(pool, items)
+        canv = A.paste(stage, [(offs[k], pitch, r, cv) for k, (pitch, r, cv) in enumerate(rects)], len(paths), s, s, fill=114)
+        imgs = torch.empty((len(paths), 3, s, s), dtype=torch.float32, device=dev)
+        hip.call("ryolo_to_tensor", hip.ptr(canv), len(paths), s, s, None, hip.ptr(imgs), hip.stream())
+        return paths, imgs
+
+    def __getitem__(self, index):
+        paths, imgs = self.assemble_batch([index])
+        return paths[0], imgs[0]
+
+    def __getitems__(self, indices):
+        paths, imgs = self.assemble_batch(list(indices))
+        return [(p, imgs[k]) for k, p in enumerate(paths)]
+
+    def loader(self, batch_size):
+        for a in range(0, len(self.files), batch_size):
+            yield self.assemble_batch(range(a, min(a + batch_size, len(self.files))))

@@ -412,7 +412,11 @@ class Graph:
             if not (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1 or A.N * OH * OW * Nout > self.rt.fuse_bn_max_elems:
                 bstat = None
         if bstat:
+            # the plan is asked again for the launch AS IT WILL RUN: kernel selection depends on nbstat (the persistent 1x1 kernel and the
+            # deep-ring instantiations do not fold statistics), and `part` is sized by the rows of the kernel that really writes it
             p.nbstat = len(bstat)
+            hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+            assert (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1, "BN-statistics fold planned on a kernel family that is masked off"
             for i, (n0, (c0_, C_, y_, co_, act_, holder)) in enumerate(bstat):
                 part = self.f32(rows.value + 64, 2, C_)                      # +64 rows: fold scratch of ryolo_bn_act_bwd
                 b = p.bstat[i]

@@ -55,6 +55,8 @@ class _ComputeLossBase:
         self._ws = None
         self._items = None
         self._last_items = None
+        self._drop_host = self._drop_event = None
+        self._drop_batch = 0
 
     def _params(self, outputs, targets, compute_grad, grads):
         p = S.LossParams()
@@ -99,6 +101,23 @@ class _ComputeLossBase:
         hip.call("ryolo_loss", p, hip.stream())
         return grads, items
 
+    def _check_previous_call(self):
+        """Asynchronous path (sync_items=False): the dropped-row count of the previous call was copied to pinned host memory behind an
+        event; by the next call that event has completed, so reading it does not stall the host.  A collate / shard re-indexing bug
+        therefore raises one step late instead of training quietly on fewer labels.  `flush()` checks the last call explicitly."""
+        ev = self._drop_event
+        if ev is None:
+            return
+        self._drop_event = None
+        ev.synchronize()
+        n = int(self._drop_host[0])
+        if n > 0:
+            raise IndexError("loss: {} target row(s) of the previous call carried an image index outside [0, {}) (targets[:, 0])".format(n, self._drop_batch))
+
+    def flush(self):
+        """Wait for and check the dropped-target count of the last sync_items=False call (end of an epoch / before a checkpoint)."""
+        self._check_previous_call()
+
     def debug_matches(self):
         """Test hook: the (b, a, gj, gi, cls, tidx, cell) records of the last call, per scale, read back from the workspace
         (layout = carve() in csrc/loss.hip)."""
@@ -127,6 +146,13 @@ class _ComputeLossBase:
             loss = items[4:5].clone()
         names = ("reg_loss", "conf_loss", "cls_loss", "theta_loss", "total_loss")
         self.dropped_targets = items[5]                # device scalar: rows whose image index is outside [0, batch)
+        self._check_previous_call()                    # sync_items=False: the PREVIOUS call's count, long finished by now (no stall)
+        if not sync_items:
+            if self._drop_host is None:
+                self._drop_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._drop_host.copy_(items[5:6], non_blocking=True)
+            self._drop_event = torch.cuda.current_stream().record_event()
+            self._drop_batch = outputs[0].shape[0]
         if sync_items:
             vals = items.tolist()                      # the single device->host read of the step
             if vals[5] > 0:

@@ -41,6 +41,9 @@ from detectron2.layers.rotated_boxes import pairwise_iou_rotated   # lib/loss.py
 from model.yolo import Yolo                                    # train.py:14, test.py:10
 from lib.loss import ComputeCSLLoss, ComputeKFIoULoss          # train.py:16, test.py:12
 from lib.general import post_process                           # test.py:11
+from lib.logger import logger                                  # train.py:15, test.py:12 — the CALLER's own module (written by the test below)
+from lib.plot import plot_boxes                                # detect.py:10 — the caller's, importing the HIP lib.general's helpers
+assert logger == "the caller logger" and plot_boxes() == "ryolov4_amd.lib.general"
 from ryolov4_amd.lib.evaluate import get_batch_statistics, calculate_eval_stats
 from ryolov4_amd.synth import CFG, fill_state, synth_batch, synth_nms_boxes
 import oracle
@@ -152,13 +155,20 @@ print("RESULT " + json.dumps(dict(dev_log=dev_log, cpu_log=cpu_log, steps=[dev_s
 '''
 
 
-def test_reference_train_and_test_loops_through_install_dropin():
+def test_reference_train_and_test_loops_through_install_dropin(tmp_path):
     import gc
+    # a caller tree with its OWN lib package beside the hot-path names (install_dropin used to replace the whole package)
+    (tmp_path / "lib").mkdir()
+    (tmp_path / "lib" / "__init__.py").write_text("")
+    (tmp_path / "lib" / "logger.py").write_text("logger = 'the caller logger'\n")
+    (tmp_path / "lib" / "plot.py").write_text("from lib.general import xywh2xyxy, xywha2xyxyxyxy\ndef plot_boxes():\n    return xywha2xyxyxyxy.__module__\n")
+    (tmp_path / "lib" / "general.py").write_text("raise ImportError('shadowed by install_dropin')\n")
     import torch
     gc.collect()
     torch.cuda.empty_cache()
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, '')\n" + SCRIPT], cwd=str(tmp_path), env=env, capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     d = json.loads(line[len("RESULT "):])

@@ -167,6 +167,37 @@ def test_loss_golden(golden_dir, mode, nc):
         assert abs(it2["total_loss"] - items["total_loss"]) < 1e-6 * max(1.0, abs(items["total_loss"]))
 
 
+def test_out_of_range_image_index_raises_also_without_the_per_call_sync(golden_dir):
+    """lib/loss.py:209,385: the reference indexes pi[b, a, gj, gi] with the targets' image column and raises IndexError when it is >= the
+    batch.  sync_items=True reads the dropped-row count with the loss items; sync_items=False (the asynchronous training path) copies it
+    to pinned memory behind an event and raises at the NEXT call or at flush() — never silently."""
+    from ryolov4_amd.lib import loss as L
+
+    class M:
+        pass
+    m = M()
+    m.anchors, m.nc = ref_ops.make_anchors(CFG, "kfiou"), 2
+    g = np.load(os.path.join(golden_dir, "g46_loss.npz"))
+    tag = "kfiou_nc2_c0"
+    outs = [torch.from_numpy(g[f"{tag}_out{i}"].astype(np.float32)).to(DEV) for i in range(3)]
+    good = torch.from_numpy(g[f"{tag}_targets"]).to(DEV)
+    bad = good.clone()
+    bad[0, 0] = outs[0].shape[0] + 3
+    crit = L.ComputeKFIoULoss(m, HYP)
+    with pytest.raises(IndexError):
+        crit(outs, bad)
+    crit = L.ComputeKFIoULoss(m, HYP)
+    crit(outs, good, sync_items=False)
+    crit(outs, bad, sync_items=False)                              # nothing read back yet
+    assert float(crit.dropped_targets) == 1.0
+    with pytest.raises(IndexError):
+        crit(outs, good, sync_items=False)                         # the previous call's count surfaces here
+    crit(outs, bad, sync_items=False)
+    with pytest.raises(IndexError):
+        crit.flush()
+    crit.flush()                                                   # consumed: no second raise
+
+
 @pytest.mark.parametrize("tag", ["csl_nc2", "kfiou_nc2", "kfiou_nc16", "csl_nc16", "csl_nc16_empty"])
 def test_focal_loss_golden(golden_dir, tag):
     """hyp['fl_gamma'] > 0: FocalLoss (lib/loss.py:10-33) around the objectness / class / CSL-angle BCE terms, with non-unit pos_weights —

@@ -101,3 +101,77 @@ def test_device_loader_iterates_batches(tmp_path):
     assert seen == NIMG
     path, img, labels = ds[3]                                   # API parity with Dataset.__getitem__
     assert path == ds.img_files[3] and tuple(img.shape) == (3, 32, 32) and labels.shape[1] == 7
+
+
+@pytest.mark.gpu
+def test_budgeted_pool_is_bit_equal_to_the_unbounded_pool(tmp_path):
+    """an ImagePool whose byte budget is SMALLER than the dataset (slabs dropped LRU, images decoded again on demand)
+    produces the same batches, bit for bit, as the pool that keeps everything — three epochs of mosaic / mixup batches."""
+    from ryolov4_amd.lib.load import load_data
+    hyp = {k: float(v) for k, v in zip(HYP_KEYS, G["dota_mosaic_hyp"])}
+    base, images = _write_tree(tmp_path, "DOTA")
+    total = sum(int(np.prod(im.shape)) for im in images.values())
+    decodes = {"n": 0}
+
+    def imread(p):
+        decodes["n"] += 1
+        return images[p]
+
+    outs = {}
+    for name, kw in (("unbounded", {}), ("budget", dict(pool_budget_bytes=total // 2, pool_slab_bytes=total // 8))):
+        decodes["n"] = 0
+        ds, loader = load_data(base, CLASSES, "DOTA", hyp, False, img_size=32, batch_size=2, augment=True, shuffle=False, imread=imread,
+                               device="cuda:0", share_pool=False, **kw)
+        random.seed(5)
+        np.random.seed(5)
+        got = []
+        for _ in range(3):
+            for paths, imgs, targets in loader:
+                got.append((imgs.cpu(), targets.cpu()))
+        outs[name] = (got, decodes["n"], ds.cache().stats, ds.cache().resident_bytes())
+    (a, na, sa, ra), (b, nb, sb, rb) = outs["unbounded"], outs["budget"]
+    assert len(a) == len(b) == 3 * ((NIMG + 1) // 2)
+    for (ia, ta), (ib, tb) in zip(a, b):
+        assert torch.equal(ia, ib) and torch.equal(ta, tb)
+    assert na == NIMG and sa["evicted_slabs"] == 0                       # everything decoded exactly once
+    assert rb <= total // 2 < total and sb["evicted_slabs"] > 0 and nb > NIMG     # the budget held, slabs were recycled, images re-decoded
+
+
+@pytest.mark.gpu
+def test_pool_budget_too_small_for_one_batch_raises(tmp_path):
+    from ryolov4_amd.datasets import augment as A
+    images = [np.full((16, 16, 3), i, np.uint8) for i in range(8)]
+    pool = A.ImagePool(count=8, decode=images.__getitem__, device="cuda:0", budget_bytes=2048, slab_bytes=1024)
+    pool.ensure([0, 1])
+    with pytest.raises(RuntimeError, match="do not fit the budget"):
+        pool.ensure(range(8))
+    with pytest.raises(RuntimeError, match="one image needs"):
+        A.ImagePool(count=1, decode=lambda i: np.zeros((64, 64, 3), np.uint8), device="cuda:0", budget_bytes=4096, slab_bytes=1024).ensure([0])
+
+
+def test_pool_lru_bookkeeping_on_cpu():
+    """The pool's residency logic without a GPU (device 'cpu' tensors): LRU slab recycling, offsets relative to slab 0, re-decode."""
+    from ryolov4_amd.datasets import augment as A
+    images = [np.full((8, 8, 3), i, np.uint8) for i in range(6)]          # 192 bytes each
+    calls = []
+    pool = A.ImagePool(count=6, decode=lambda i: (calls.append(i), images[i])[1], device="cpu", budget_bytes=3 * 384, slab_bytes=384, workers=1)
+    pool.ensure([0, 1, 2, 3])                                             # two slabs
+    pool.ensure([4, 5])                                                   # third slab
+    assert pool.stats["evicted_slabs"] == 0 and len(pool._slabs) == 3
+    pool.ensure([0])                                                      # touch slab 0: slab 1 (images 2, 3) is now the LRU
+    pool.ensure([2])                                                      # missing? no — still resident
+    assert calls == [0, 1, 2, 3, 4, 5]
+    pool._touched[1] = 0                                                  # make slab 1 the oldest explicitly
+    pool._cur = 2
+    pool._fill[2] = 384
+    big = [np.full((8, 8, 3), 9, np.uint8)]
+    pool._decode = lambda i: big[0] if i == 99 else images[i]
+    pool.count = 100
+    pool.ensure([99])
+    assert pool.stats["evicted_slabs"] == 1 and 2 not in pool._where and 3 not in pool._where and 99 in pool._where
+    base = pool.buf.data_ptr()
+    k, off = pool._where[99]
+    assert pool.offset(99) == pool._slabs[k].data_ptr() - base + off
+    flat = pool._slabs[k][off:off + 192]
+    assert int(flat.min()) == int(flat.max()) == 9
+    assert pool.shape(2) == (8, 8)                                        # shapes survive eviction
