@@ -170,6 +170,12 @@ void ora_pairwise_iou_rotated(const float *b1, int n, const float *b2, int m, fl
             out[(size_t)i * m + j] = ora_single_box_iou_rotated(b1 + 5 * i, b2 + 5 * j);
 }
 
+/* element-wise form (pair k = b1[k] vs b2[k]): the oracle side of the large-scale fuzz (tests/test_iou_fuzz.py) and of L8's diagonal SkewIoU */
+void ora_diag_iou_rotated(const float *b1, const float *b2, int64_t n, float *out)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = ora_single_box_iou_rotated(b1 + 5 * i, b2 + 5 * i);
+}
+
 /* nms_rotated(boxes[N,5] deg, scores[N], thr) -> keep indices into the input, in score-desc order.
  * Sort: score descending, ties by ascending original index (the build's fixed tie-break).
  * Lazy greedy exactly as detectron2's CPU kernel: IoU only against boxes that survive.             */

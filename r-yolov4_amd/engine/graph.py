@@ -235,7 +235,12 @@ class Graph:
             if fam == 2:
                 return ("gemm1x1_ws_kernel", fl, by)
             # the generic kernel's instantiations as rocprofv3 lists them: tile shape, and the 1x1 form (no tap table / tile decomposition)
-            return (f"conv_gemm_kernel<{((kv >> 12) & 15) * 64}x{((kv >> 16) & 15) * 32}{',1x1' if kv & 0x100 else ''}>", fl, by)
+            kind = f"conv_gemm_kernel<{((kv >> 12) & 15) * 64}x{((kv >> 16) & 15) * 32}{',1x1' if kv & 0x100 else ''}>"
+            if kv & 0x100:
+                # the pointwise class holds two regimes: short-K layers are memory streams, K > 256 layers are MFMA-side;
+                # the fourth field lets bench.py report a roofline for each
+                return (kind, fl, by, "K<=256" if p.Cin <= 256 else "K>256")
+            return (kind, fl, by)
         if name == "ryolo_conv_wgrad":
             p = args[0]
             fl = 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin
@@ -337,13 +342,13 @@ class Graph:
                 elif pending is not None:            # first main-stream launch after a join point
                     main.wait_event(pending)
                     pending = None
-            kind, fl, by = self.meta.get((tid, i), (name, 0, 0)) if timer is not None else (name, 0, 0)
+            kind, fl, by, *sub = self.meta.get((tid, i), (name, 0, 0)) if timer is not None else (name, 0, 0)
             if fl:
                 e0, e1 = timer.pair()
                 e0.record(lane_stream if on_side else None)
                 rc = fn(*args, sst if on_side else st)
                 e1.record(lane_stream if on_side else None)
-                timer.note(kind, fl, e0, e1, by)
+                timer.note(kind, fl, e0, e1, by, *sub)
             else:
                 rc = fn(*args, sst if on_side else st)
             if rc != 0:

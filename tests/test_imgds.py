@@ -41,9 +41,9 @@ def test_image_dataset_batches_match_the_reference(tmp_path, size):
     got, paths = [], []
     for p, imgs in ds.loader(BATCH):
         assert imgs.is_cuda and imgs.dtype == torch.float32 and tuple(imgs.shape[1:]) == (3, size, size)
-        u8 = torch.round(imgs * 255)
-        assert torch.equal(u8 / 255, imgs)                                 # exactly uint8 / 255 (base_dataset.py:79)
-        got.append(u8.to(torch.uint8).cpu().numpy())
+        u8 = torch.round(imgs * 255).to(torch.uint8).cpu()
+        assert torch.equal(u8.float() / 255, imgs.cpu())                   # exactly uint8 / 255 (base_dataset.py:79), IEEE division
+        got.append(u8.numpy())
         paths += list(p)
     got = np.concatenate(got, 0)
     assert paths == ds.files and [int(os.path.basename(p)[:3]) for p in paths] == G[f"order_{size}"].tolist()

@@ -14,18 +14,21 @@ from ryolov4_amd.synth import synth_nms_boxes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R2 = math.sqrt(2)
+# Where each known-answer vector comes from.  detectron2 is absent from /root/reference and from this image, so the test names are quoted
+# as recalled from the public tests/layers/test_rotated_boxes.py (class TestRotatedBoxesLayer) — the VALUES are what is asserted, and each one
+# was re-derived by hand / with the independent float64 clips (sh_iou below, tests/iou_fuzz.py):
 KNOWN = [
-    ([0.5, 0.5, 1, 1, 0], [0.25, 0.5, 0.5, 1, 0], 0.5),
-    ([565, 565, 10, 10, 0], [565, 565, 10, 8.3, 0], 0.83),
-    ([1, 1, R2, R2, 45], [1, 1, 2, 2, 0], 0.5),
-    ([1, 1, 2 * R2, 2 * R2, -45], [1, 1, 2, 2, 0], 0.5),
-    ([5, 5, 10, 6, 55], [5, 5, 10, 6, -35], 36 / 84),
-    ([3, 3, 8, 2, -45], [6, 0, 8, 2, -45], 0.0),
-    ([160, 153, 230, 23, -37], [190, 127, 80, 21, -46], 0.0),
-    ([299.5, 417.370422, 600, 364.259186, 27.1828], [299.5, 417.370422, 600, 364.259155, 27.1828], 364.259155 / 364.259186),
-    ([0, 0, 1, 1, 0], [0, 0, 1, 1, 45], (2 * R2 - 2) / (4 - 2 * R2)),
-    ([2563.7446, 1436.7902, 2174.7034, 214.095, 115.1183], [2563.7446, 1436.7902, 2174.7034, 214.095, 115.1183], 1.0),
-    ([296.662, 458.7388, 23.5157, 47.677, 0.08795], [296.662, 458.7388, 23.5157, 47.677, 0.08795], 1.0),
+    ([0.5, 0.5, 1, 1, 0], [0.25, 0.5, 0.5, 1, 0], 0.5),                              # test_iou_half_overlap_cpu/_cuda (also a column of test_iou_0_degree)
+    ([565, 565, 10, 10, 0], [565, 565, 10, 8.3, 0], 0.83),                           # test_iou_precision
+    ([1, 1, R2, R2, 45], [1, 1, 2, 2, 0], 0.5),                                      # test_iou_45_degrees, first box
+    ([1, 1, 2 * R2, 2 * R2, -45], [1, 1, 2, 2, 0], 0.5),                             # test_iou_45_degrees, second box
+    ([5, 5, 10, 6, 55], [5, 5, 10, 6, -35], 36 / 84),                                # test_iou_perpendicular
+    ([3, 3, 8, 2, -45], [6, 0, 8, 2, -45], 0.0),                                     # test_iou_issue1207_simplified (parallel, disjoint)
+    ([160, 153, 230, 23, -37], [190, 127, 80, 21, -46], 0.0),                        # test_iou_issue1207
+    ([299.5, 417.370422, 600, 364.259186, 27.1828], [299.5, 417.370422, 600, 364.259155, 27.1828], 364.259155 / 364.259186),   # test_iou_large_close_boxes
+    ([0, 0, 1, 1, 0], [0, 0, 1, 1, 45], (2 * R2 - 2) / (4 - 2 * R2)),                # not from detectron2: unit square vs itself at 45 deg (regular octagon), analytic
+    ([2563.7446, 1436.7902, 2174.7034, 214.095, 115.1183], [2563.7446, 1436.7902, 2174.7034, 214.095, 115.1183], 1.0),          # test_iou_issue_2167 (identical boxes)
+    ([296.662, 458.7388, 23.5157, 47.677, 0.08795], [296.662, 458.7388, 23.5157, 47.677, 0.08795], 1.0),                        # test_iou_issue_2154 (identical boxes)
 ]
 
 

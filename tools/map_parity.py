@@ -1,16 +1,21 @@
-"""mAP-parity experiment (BASELINE north_star: "... at reference mAP parity"): the HIP path and the fp32 torch-CPU
-oracle are TRAINED on the same rendered rotated-rectangle task with identical initial weights, batches and optimizer, then EVALUATED the
-way test.py:167-222 does (eval forward, post_process conf 0.001 / iou 0.65, get_batch_statistics over IoU 0.5:0.95, ap_per_class).
+"""mAP-parity experiment (BASELINE north_star: "... at reference mAP parity"): the HIP path and the fp32
+torch-CPU oracle are TRAINED on the same rendered rotated-rectangle task with identical initial weights, batches and optimizer, then
+EVALUATED the way test.py:167-222 does (eval forward, post_process conf 0.001 / iou 0.65, get_batch_statistics over IoU 0.5:0.95,
+ap_per_class).
 
-Task: 96 x 96 images with 1-3 filled rotated rectangles on a noisy background, 2 classes told apart by colour, sizes around the
-stride-8 anchors; 32 images, trained for `steps` SGD-nesterov steps (lr 0.01, momentum 0.937, train.py:156) in batches of 16, evaluated
-on the same 32 images (a memorisation task: what a few hundred steps can reach).
+Task (r04 scale): 96 x 96 images with 2-6 filled rotated rectangles on a noisy background, NC = 16 classes told apart by hue, sizes around
+the stride-8 anchors; 512 images / ~2000 labels, trained for `steps` SGD-nesterov steps (lr 0.01, momentum 0.937, train.py:156) in
+batches of 16, evaluated on the same images (a memorisation task: what a few hundred steps can reach).  r03 ran 32 images / 65 labels /
+2 classes, where ONE true positive changing sides moves a class AP by 0.015-0.03; with >= 100 labels per class it moves it by < 0.01
+and the mean over 16 classes by < 1e-3.
 
-Reported (gpurun_out/r03_map_parity.json):
-  hip_trained / oracle_trained     mAP@0.5, mAP@0.5:0.95, P, R of each path's OWN training + evaluation          -> band |d mAP@0.5| stated
-  cross                            the ORACLE-trained weights evaluated by the HIP path (model, post_process, NMS, matching, AP on the
-                                   device): isolates inference + evaluation parity from the chaotic training trajectory -> measured 1e-4 (300 steps) / 0.025 (600 steps): 65 labels, one flipped TP = 0.015-0.03
-usage: python tools/map_parity.py [steps] [ver] [mode]"""
+Reported (gpurun_out/r04_map_parity.json), for `seeds` different initialisations:
+  cross     the ORACLE-trained weights of every seed evaluated by the HIP path (network, post_process, rotated NMS, TP matching, AP on
+            the device) against the oracle path on the same weights: inference + evaluation parity, isolated from the chaotic training
+            trajectory.  Target: max |d mAP@0.5| <= 5e-3.
+  trained   each path's OWN training + evaluation per seed: the two paths' mAP@0.5 ranges over the seeds must overlap (two roundings of
+            one chaotic trajectory are two members of the same family: tests/test_gpu_trajectory.py).
+usage: python tools/map_parity.py [--images 512] [--steps 480] [--seeds 3] [--nc 16] [--ver yolov7] [--mode kfiou]"""
 import json
 import math
 import os
@@ -28,8 +33,14 @@ from ryolov4_amd.lib.loss import ComputeCSLLoss, ComputeKFIoULoss
 from ryolov4_amd.model.yolo import Yolo
 from ryolov4_amd.synth import CFG, HYP
 
-S, NC, NIMG, BATCH = 96, 2, 32, 16
+S, NC, NIMG, BATCH = 96, 16, 512, 16
 DEV = "cuda:0"
+
+
+def class_colour(cls):
+    """16 hues around the colour wheel at two brightness levels (class -> RGB in [0, 1])."""
+    import colorsys
+    return np.array(colorsys.hsv_to_rgb((cls % 8) / 8.0, 0.9, 0.95 if cls < 8 else 0.55), dtype=np.float32)
 
 
 def weights_init_normal(m):                                      # train.py:28-33
@@ -46,7 +57,7 @@ def render(rs, csl):
     img = rs.rand(S, S, 3).astype(np.float32) * 0.25
     ys, xs = np.mgrid[0:S, 0:S].astype(np.float32) + 0.5
     rows = []
-    for _ in range(rs.randint(1, 4)):
+    for _ in range(rs.randint(2, 7)):
         cx, cy = rs.uniform(18, S - 18, size=2)
         long_, short = rs.uniform(22, 34), rs.uniform(10, 16)
         th = rs.uniform(-math.pi / 2, math.pi / 2)
@@ -54,8 +65,7 @@ def render(rs, csl):
         c, s = math.cos(th), math.sin(th)
         u, v = (xs - cx) * c + (ys - cy) * s, -(xs - cx) * s + (ys - cy) * c
         inside = (np.abs(u) <= long_ / 2) & (np.abs(v) <= short / 2)
-        colour = np.array([0.9, 0.5, 0.1] if cls == 0 else [0.1, 0.5, 0.9], dtype=np.float32)
-        img[inside] = colour + rs.rand(int(inside.sum()), 3).astype(np.float32) * 0.1
+        img[inside] = np.clip(class_colour(cls) + (rs.rand(int(inside.sum()), 3).astype(np.float32) - 0.5) * 0.1, 0, 1)
         hx, hy = np.array([c, s]) * long_ / 2, np.array([-s, c]) * short / 2
         ctr = np.array([cx, cy])
         poly = np.concatenate([ctr - hx - hy, ctr + hx - hy, ctr + hx + hy, ctr - hx + hy]) / S
@@ -100,69 +110,85 @@ def evaluate(forward, loss_fn, pp, stats_fn, batches, to_dev, host_ap):
     return dict(images=seen, labels=int(np.sum(nt)), detections=int(len(cat[1])), P=float(mp), R=float(mr), mAP50=float(map50), mAP=float(map_))
 
 
-def main():
-    torch.set_num_threads(min(32, os.cpu_count() or 1))          # torch-CPU oversubscribes on the 256-thread GPU hosts (bench.py's cpu_baseline notes)
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    ver = sys.argv[2] if len(sys.argv) > 2 else "yolov7"
-    mode = sys.argv[3] if len(sys.argv) > 3 else "kfiou"
-    csl = mode == "csl"
-    batches = dataset(csl)
-    torch.manual_seed(42)
-    orc = ref_model.Yolo(NC, CFG, mode, ver)
-    orc.apply(weights_init_normal)
-    sd0 = {k: v.clone() for k, v in orc.state_dict().items()}
-    net = Yolo(NC, CFG, mode, ver)
-    net.load_state_dict(sd0)
-    net.to(DEV)
-    crit = (ComputeCSLLoss if csl else ComputeKFIoULoss)(net, HYP)
-    t0 = time.time()
-    net.train()
-    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.937, nesterov=True)
-    dbatches = [(i.to(DEV), t.to(DEV)) for i, t in batches]
-    hip_curve = []
+def train(model, loss_fn, batches, steps):
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    curve = []
     for it in range(steps):
-        imgs, tg = dbatches[it % len(dbatches)]
-        loss, items = crit(net(imgs, training=True), tg)
+        imgs, tg = batches[it % len(batches)]
+        loss, items = loss_fn(model(imgs, True), tg)
         loss.backward()
         opt.step()
         opt.zero_grad()
-        hip_curve.append(float(items["total_loss"]))
-    t_hip = time.time() - t0
-    t0 = time.time()
-    orc.train()
-    oopt = torch.optim.SGD(orc.parameters(), lr=0.01, momentum=0.937, nesterov=True)
-    orc_curve = []
-    for it in range(steps):
-        imgs, tg = batches[it % len(batches)]
-        loss, items = ref_ops.compute_loss(orc(imgs, True), tg, orc.anchors, NC, mode, HYP)
-        loss.backward()
-        oopt.step()
-        oopt.zero_grad()
-        orc_curve.append(float(items["total_loss"]))
-    t_orc = time.time() - t0
-    net.eval()
-    orc.eval()
-    res = {}
-    res["hip_trained"] = evaluate(lambda x: net(x, training=False), None, post_process, EV.get_batch_statistics, batches, lambda t: t.to(DEV), False)
-    res["oracle_trained"] = evaluate(lambda x: orc(x, False), None, ref_ops.post_process, ref_ops.get_batch_statistics, batches, lambda t: t, True)
-    net2 = Yolo(NC, CFG, mode, ver)
-    net2.load_state_dict(orc.state_dict())
-    net2.to(DEV).eval()
-    res["cross_oracle_weights_on_hip_path"] = evaluate(lambda x: net2(x, training=False), None, post_process, EV.get_batch_statistics, batches,
-                                                       lambda t: t.to(DEV), False)
-    out = dict(task=f"{NIMG} rendered {S}x{S} images, 1-3 rotated rectangles, {NC} classes; {ver} {mode}; {steps} SGD-nesterov steps lr 0.01 batch {BATCH}; "
-                    "evaluated on the training images as test.py:167-222 (conf 0.001, iou 0.65)",
-               loss_first_last=dict(hip=[hip_curve[0], hip_curve[-1]], oracle=[orc_curve[0], orc_curve[-1]]),
-               loss_every_20=dict(hip=[round(v, 4) for v in hip_curve[::20]], oracle=[round(v, 4) for v in orc_curve[::20]]),
-               seconds=dict(hip=round(t_hip, 1), oracle_cpu=round(t_orc, 1)), **res)
-    out["delta_mAP50_trained"] = abs(res["hip_trained"]["mAP50"] - res["oracle_trained"]["mAP50"])
-    out["delta_mAP50_cross"] = abs(res["cross_oracle_weights_on_hip_path"]["mAP50"] - res["oracle_trained"]["mAP50"])
+        curve.append(float(items["total_loss"]))
+    return curve
+
+
+def main():
+    import argparse
+    global NIMG, NC
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--seeds", type=int, default=3)
+    ap.add_argument("--nc", type=int, default=16)
+    ap.add_argument("--ver", default="yolov7")
+    ap.add_argument("--mode", default="kfiou")
+    args = ap.parse_args()
+    NIMG, NC = args.images, args.nc
+    torch.set_num_threads(min(32, os.cpu_count() or 1))          # torch-CPU oversubscribes on the 256-thread GPU hosts (bench.py's cpu_baseline notes)
+    steps, ver, mode = args.steps, args.ver, args.mode
+    csl = mode == "csl"
+    batches = dataset(csl)
+    dbatches = [(i.to(DEV), t.to(DEV)) for i, t in batches]
+    nlabels = int(sum(t.shape[0] for _, t in batches))
+    runs, t_hip, t_orc, t_eval = [], 0.0, 0.0, 0.0
+    for seed in range(args.seeds):
+        torch.manual_seed(42 + seed)
+        orc = ref_model.Yolo(NC, CFG, mode, ver)
+        orc.apply(weights_init_normal)
+        sd0 = {k: v.clone() for k, v in orc.state_dict().items()}
+        net = Yolo(NC, CFG, mode, ver)
+        net.load_state_dict(sd0)
+        net.to(DEV)
+        crit = (ComputeCSLLoss if csl else ComputeKFIoULoss)(net, HYP)
+        t0 = time.time()
+        hip_curve = train(net, lambda o, t: crit(o, t), dbatches, steps)
+        t_hip += time.time() - t0
+        t0 = time.time()
+        orc_curve = train(orc, lambda o, t: ref_ops.compute_loss(o, t, orc.anchors, NC, mode, HYP), batches, steps)
+        t_orc += time.time() - t0
+        net.eval()
+        orc.eval()
+        t0 = time.time()
+        res = {"seed": 42 + seed, "loss_first_last": dict(hip=[hip_curve[0], hip_curve[-1]], oracle=[orc_curve[0], orc_curve[-1]])}
+        res["hip_trained"] = evaluate(lambda x: net(x, training=False), None, post_process, EV.get_batch_statistics, batches, lambda t: t.to(DEV), False)
+        res["oracle_trained"] = evaluate(lambda x: orc(x, False), None, ref_ops.post_process, ref_ops.get_batch_statistics, batches, lambda t: t, True)
+        net2 = Yolo(NC, CFG, mode, ver)
+        net2.load_state_dict(orc.state_dict())
+        net2.to(DEV).eval()
+        res["cross_oracle_weights_on_hip_path"] = evaluate(lambda x: net2(x, training=False), None, post_process, EV.get_batch_statistics, batches,
+                                                           lambda t: t.to(DEV), False)
+        res["delta_mAP50_cross"] = abs(res["cross_oracle_weights_on_hip_path"]["mAP50"] - res["oracle_trained"]["mAP50"])
+        res["delta_mAP_cross"] = abs(res["cross_oracle_weights_on_hip_path"]["mAP"] - res["oracle_trained"]["mAP"])
+        t_eval += time.time() - t0
+        runs.append(res)
+        print(json.dumps(res), flush=True)
+        del net, net2, crit
+    hip50 = [r["hip_trained"]["mAP50"] for r in runs]
+    orc50 = [r["oracle_trained"]["mAP50"] for r in runs]
+    out = dict(task=f"{NIMG} rendered {S}x{S} images, 2-6 rotated rectangles each ({nlabels} labels), {NC} classes; {ver} {mode}; {steps} SGD-nesterov "
+                    f"steps lr 0.01 batch {BATCH}; {args.seeds} seeds; evaluated on the training images as test.py:167-222 (conf 0.001, iou 0.65)",
+               labels=nlabels, runs=runs, seconds=dict(hip_train=round(t_hip, 1), oracle_cpu_train=round(t_orc, 1), evaluations=round(t_eval, 1)),
+               cross_max_delta_mAP50=max(r["delta_mAP50_cross"] for r in runs), cross_max_delta_mAP=max(r["delta_mAP_cross"] for r in runs),
+               trained_mAP50_range=dict(hip=[min(hip50), max(hip50)], oracle=[min(orc50), max(orc50)]),
+               trained_ranges_overlap=bool(max(min(hip50), min(orc50)) <= min(max(hip50), max(orc50))))
     os.makedirs("gpurun_out", exist_ok=True)
-    path = "gpurun_out/r03_map_parity.json"
+    path = "gpurun_out/r04_map_parity.json"
     doc = json.load(open(path)) if os.path.exists(path) else {}
-    doc[f"{ver}_{mode}_{steps}"] = out
+    doc[f"{ver}_{mode}_{NIMG}img_{steps}steps"] = out
     json.dump(doc, open(path, "w"), indent=1)
-    print(json.dumps({k: v for k, v in out.items() if k != "loss_every_20"}))
+    print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
 
 
 if __name__ == "__main__":
