@@ -1255,12 +1255,19 @@ static int gemm_check(const ConvGemmParams& p)
 
 // Which kernel ryolo_conv_gemm will run for these parameters and how many [2][Nout] partial-statistics rows its EPI_STATS
 // epilogue writes (= number of M tiles).  kernel: 0 generic implicit GEMM (conv.hip), 1 3x3 halo-patch kernel (conv3x3.hip,
-// selected by pipe bit 0x200 when the layer is eligible), 2 weight-stationary persistent 1x1 kernel (gemm1x1.hip; rows = waves).
+// selected by pipe bit 0x200 when the layer is eligible), 2 weight-stationary persistent 1x1 kernel (gemm1x1.hip; rows = waves),
+// 3 persistent weight-stationary 3x3 kernel for 64 -> <= 64 channels (conv3x3_ws.hip; rows = workgroups).
 extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, int* kernel)
 {
     if (!pp || !stats_rows) return RY_ERR_ARG;
     const ConvGemmParams& p = *pp;
     if (p.Cin <= 0 || p.Cin % BK || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4) return RY_ERR_ARG;
+    Ws3Geom w3;
+    if ((p.pipe & 0x200) && ws3_geometry(p, w3)) {                 // persistent weight-stationary 3x3 (conv3x3_ws.hip): one statistics row per workgroup
+        *stats_rows = w3.nwg;
+        if (kernel) *kernel = 3;
+        return RY_OK;
+    }
     P3Geom g;
     if ((p.pipe & 0x200) && p3_geometry(p, g)) {
         *stats_rows = (int)g.gm;
@@ -1293,6 +1300,8 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
     if (p.epi == EPI_STATS && (!p.stats || p.nclasses != 1)) return RY_ERR_ARG;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
     if (p.pipe & 0x200) {
+        Ws3Geom w3;
+        if (ws3_geometry(p, w3)) return ws3_launch(p, w3, stream);
         P3Geom g;
         if (p3_geometry(p, g)) return p3_launch(p, g, stream);
     }

@@ -180,6 +180,21 @@ struct P3Geom {
 bool p3_geometry(const ConvGemmParams& p, P3Geom& g);
 int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream);
 
+// ---- persistent weight-stationary 3x3 kernel for 64 -> <= 64 channels (conv3x3_ws.hip): weights in registers, double-buffered whole-K patches,
+// one workgroup per CU walking 2-D tiles
+struct Ws3Geom {
+    int TH, TW, PW;            // tile rows / cols, patch row pitch in pixels (TW + 2)
+    int R, NP;                 // patch rows, 8-row (1 KiB) DMA pieces
+    int tilesW, tilesPerImg;
+    int nwg;                   // persistent workgroups (a multiple of 8) = partial-statistics rows of the EPI_STATS epilogue
+    int64_t ntiles;
+    unsigned patch_bytes, lds_bytes;
+    int tdh[9], tdw[9], twi[9];
+    float rPW, rTW;
+};
+bool ws3_geometry(const ConvGemmParams& p, Ws3Geom& g);
+int ws3_launch(const ConvGemmParams& p, const Ws3Geom& g, hipStream_t stream);
+
 // ---- 3x3 stride-1 weight gradient over a sliding halo ring (conv3x3.hip) ------------------------------------------------
 // K runs over PADDED pixel coordinates (image framed by one zero pixel on every side), so every tap is a constant row
 // offset into one ring of input rows and no per-element masks exist.

@@ -99,6 +99,14 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict
     }
 }
 #define FOLD_S 64
+#define FOLD_DIRECT 4096
+// RYOLO_BN_FOLD_DIRECT (default FOLD_DIRECT = 4096; 256 = the round-3 behaviour): up to how many partial rows the finalize kernels sum without a
+// fold_rows pass in front (A/B knob, read once)
+static int bn_fold_direct()
+{
+    static const int v = [] { const char* e = getenv("RYOLO_BN_FOLD_DIRECT"); int x = e ? atoi(e) : FOLD_DIRECT; return x < 4 * FOLD_S ? 4 * FOLD_S : x; }();
+    return v;
+}
 static inline const float* fold_rows(const float* partial, int& rows, int KC, float* scratch, hipStream_t stream)
 {
     if (rows <= 4 * FOLD_S || !scratch) return partial;
@@ -112,25 +120,66 @@ static inline const float* fold_rows(const float* partial, int& rows, int KC, fl
 // (momentum 0.1, unbiased variance — nn.BatchNorm2d defaults used by model/utils.py:17)
 // ld / c0: the partial rows are [2][ld] wide and this BatchNorm owns channels [c0, c0 + C) of them (sibling convolutions that share
 // one GEMM launch share one statistics buffer; ld == C, c0 == 0 for a stand-alone layer)
+// CH = channels per workgroup: 32 (32 row lanes: short row lists) or 8 (128 row lanes: up to FOLD_DIRECT partial rows are summed HERE, without the
+// fold_rows launch in front — at 8 images per GPU nearly every BatchNorm had 300 ... 2500 partial rows and paid a 5 us launch + a dependent
+// boundary for that pass, forward and backward: ~140 launches per step).  Row lanes sum in double with 4 loads in flight; the lanes of a channel
+// are combined in two fixed-order LDS stages (deterministic).
+template <int CH>
+__device__ __forceinline__ void fold_lanes(double (*red)[1024], double* s, int nq, int cl, int rl)
+{
+    constexpr int NRL = 1024 / CH, G = NRL >= 8 ? 8 : NRL;       // stage 1: G lanes per channel each add NRL / G partials, stage 2: lane 0 adds G
+    for (int q = 0; q < nq; q++) red[q][threadIdx.x] = s[q];
+    __syncthreads();
+    if (rl < G) {
+        for (int q = 0; q < nq; q++) {
+            double t = 0.0;
+#pragma unroll 4
+            for (int k = rl; k < NRL; k += G) t += red[q][k * CH + cl];
+            s[q] = t;
+        }
+    }
+    __syncthreads();
+    if (rl < G)
+        for (int q = 0; q < nq; q++) red[q][rl * CH + cl] = s[q];
+    __syncthreads();
+    if (rl == 0)
+        for (int q = 0; q < nq; q++) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < G; k++) t += red[q][k * CH + cl];
+            s[q] = t;
+        }
+}
+
+template <int CH>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int ld, int c0, int C, double count, float eps,
                                                            float momentum, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ out /*[4][C]*/)
 {
     __shared__ double red[2][1024];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;          // 32 channels x 32 row lanes
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = rl; r < rows; r += 32) {
-            s += (double)partial[((int64_t)r * 2 + 0) * ld + c0 + c];
-            q += (double)partial[((int64_t)r * 2 + 1) * ld + c0 + c];
+    constexpr int NRL = 1024 / CH;
+    const int cl = threadIdx.x % CH, rl = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + cl;
+    double sq[2] = {0.0, 0.0};
+    if (c < C) {
+        const float* base = partial + c0 + c;
+        int r = rl;
+        for (; r + 3 * NRL < rows; r += 4 * NRL) {                 // 8 independent loads in flight
+            float a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { a[k] = base[((int64_t)(r + k * NRL) * 2 + 0) * ld]; b[k] = base[((int64_t)(r + k * NRL) * 2 + 1) * ld]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { sq[0] += (double)a[k]; sq[1] += (double)b[k]; }
         }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = q;
-    __syncthreads();
+        for (; r < rows; r += NRL) {
+            sq[0] += (double)base[((int64_t)r * 2 + 0) * ld];
+            sq[1] += (double)base[((int64_t)r * 2 + 1) * ld];
+        }
+    }
+    fold_lanes<CH>(red, sq, 2, cl, rl);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < 32; k++) { s += red[0][k * 32 + cl]; q += red[1][k * 32 + cl]; }
+        const double s = sq[0], q = sq[1];
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -272,7 +321,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
 
 // backward finalize: sums over blocks (double) -> coefficients + dgamma/dbeta accumulation.
 // sum g*xhat = invstd * (S1 - mean*S0) per branch (formed in double).
-template <int K>
+template <int K, int CH>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count, int frozen,
                                                                const float* __restrict__ co1, const float* __restrict__ co2,
                                                                float* __restrict__ bco /*[K][C]*/, float* __restrict__ dgamma1,
@@ -280,25 +329,34 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                float* __restrict__ dbeta2)
 {
     // K is a template parameter so that both loops unroll: with a runtime K the 32-step LDS fold ran as 96 dependent
-    // ds_read + wait iterations (18 us per launch, 89 launches on the critical path of a step; 4.8 us for the forward twin)
+    // ds_read + wait iterations (18 us per launch, 89 launches on the critical path of a step; 4.8 us for the forward twin).
+    // CH: see bn_finalize_kernel.
     __shared__ double red[K][1024];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    constexpr int NRL = 1024 / CH;
+    const int cl = threadIdx.x % CH, rl = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + cl;
     double s[K];
 #pragma unroll
     for (int q = 0; q < K; q++) s[q] = 0.0;
-    if (c < C)
-        for (int r = rl; r < nblk; r += 32)
+    if (c < C) {
+        int r = rl;
+        for (; r + 3 * NRL < nblk; r += 4 * NRL) {
+            float v[4][K];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int q = 0; q < K; q++) v[k][q] = partial[((int64_t)(r + k * NRL) * K + q) * C + c];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int q = 0; q < K; q++) s[q] += (double)v[k][q];
+        }
+        for (; r < nblk; r += NRL)
 #pragma unroll
             for (int q = 0; q < K; q++) s[q] += (double)partial[((int64_t)r * K + q) * C + c];
-#pragma unroll
-    for (int q = 0; q < K; q++) red[q][threadIdx.x] = s[q];
-    __syncthreads();
+    }
+    fold_lanes<CH>(red, s, K, cl, rl);
     if (rl == 0 && c < C) {
-#pragma unroll
-        for (int k = 1; k < 32; k++)
-#pragma unroll
-            for (int q = 0; q < K; q++) s[q] += red[q][k * 32 + cl];
         const double gx1 = (double)co1[C + c] * (s[1] - (double)co1[c] * s[0]);
         double gx2 = 0.0;
         if constexpr (K == 3) gx2 = (double)co2[C + c] * (s[2] - (double)co2[c] * s[0]);
@@ -1123,13 +1181,18 @@ extern "C" int ryolo_bn_finalize_slice(const float* partial, int rows, int ld, i
                                        hipStream_t stream)
 {
     if (!partial || !gamma || !beta || !coeffs || C <= 0 || rows <= 0 || c0 < 0 || c0 + C > ld) return RY_ERR_ARG;
-    // many rows: folded into a scratch area the caller appends to the partial buffer (rows + FOLD_S rows allocated)
-    if (rows > 4 * FOLD_S) {
+    // very many rows: folded into a scratch area the caller appends to the partial buffer (rows + FOLD_S rows allocated); up to FOLD_DIRECT rows
+    // the finalize kernel's 128 row lanes sum them directly (one launch instead of two)
+    if (rows > bn_fold_direct()) {
         float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * ld;
         partial = fold_rows(partial, rows, 2 * ld, scratch, stream);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ry_cdiv(C, 32)), dim3(1024), 0, stream, partial, rows, ld, c0, C, count, eps,
-                       momentum, gamma, beta, running_mean, running_var, coeffs);
+    if (rows > 4 * FOLD_S)
+        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3((unsigned)ry_cdiv(C, 8)), dim3(1024), 0, stream, partial, rows, ld, c0, C, count, eps,
+                           momentum, gamma, beta, running_mean, running_var, coeffs);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((unsigned)ry_cdiv(C, 32)), dim3(1024), 0, stream, partial, rows, ld, c0, C, count, eps,
+                           momentum, gamma, beta, running_mean, running_var, coeffs);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -1224,13 +1287,14 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     }
 #undef RY_RED
     int frows = nblk;
-    const float* fpart = fold_rows(p.partial, frows, K * p.C, p.partial + (int64_t)nblk * K * p.C, stream);   // caller allocates nblk + 64 rows
-    if (K == 3)
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<3>, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, fpart, frows, p.C,
-                           (double)p.M, frozen, p.co1, p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2);
-    else
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<2>, dim3((unsigned)ry_cdiv(p.C, 32)), dim3(1024), 0, stream, fpart, frows, p.C,
-                           (double)p.M, frozen, p.co1, p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2);
+    const float* fpart = p.partial;
+    if (nblk > bn_fold_direct()) fpart = fold_rows(p.partial, frows, K * p.C, p.partial + (int64_t)nblk * K * p.C, stream);   // caller allocates nblk + 64 rows
+#define RY_FIN(KK, CH)                                                                                                                           \
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<KK, CH>), dim3((unsigned)ry_cdiv(p.C, CH)), dim3(1024), 0, stream, fpart, frows, p.C, (double)p.M, \
+                       frozen, p.co1, p.co2, bco, dgamma1, dbeta1, dgamma2, dbeta2)
+    if (frows > 4 * FOLD_S) { if (K == 3) RY_FIN(3, 8); else RY_FIN(2, 8); }
+    else { if (K == 3) RY_FIN(3, 32); else RY_FIN(2, 32); }
+#undef RY_FIN
     if (p.dy1) {
         const dim3 g(grid_rows(p.M, p.C)), b(256);
 #define RY_APP(ACT)                                                                                                   \

@@ -157,17 +157,12 @@ class ImagePool:
             decoded = self._executor.map(self._decode_one, missing)
         else:
             decoded = map(self._decode_one, missing)
-        for i, img in zip(missing, decoded):
-            nbytes = img.shape[0] * img.shape[1] * 3
+        for i, stage in zip(missing, decoded):
+            nbytes = stage.numel()
             k = self._slab_for(((nbytes + 15) // 16) * 16, pinned)
             pinned.add(k)
             off = self._fill[k]
-            if self.device.type == "cuda":
-                stage = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-                stage.numpy()[:] = img.reshape(-1)
-                self._slabs[k][off:off + nbytes].copy_(stage, non_blocking=True)
-            else:
-                self._slabs[k][off:off + nbytes] = torch.from_numpy(np.ascontiguousarray(img).reshape(-1))
+            self._slabs[k][off:off + nbytes].copy_(stage, non_blocking=self.device.type == "cuda")
             self._fill[k] = off + ((nbytes + 15) // 16) * 16
             self._members[k].append(i)
             self._where[i] = (k, off)
@@ -181,9 +176,11 @@ class ImagePool:
             img = img[:, :, None]
         if img.shape[2] != 3:                                       # base_dataset.py:177-178: grey images are stacked to 3 channels
             img = np.repeat(img[:, :, :1], 3, axis=2)
-        img = np.ascontiguousarray(img, dtype=np.uint8)
         self._shapes[i] = tuple(img.shape[:2])
-        return img
+        # straight into PINNED staging (inside the worker thread: numpy copies release the GIL), so the host holds one copy per image in flight
+        stage = torch.empty(img.shape[0] * img.shape[1] * 3, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+        np.copyto(stage.numpy().reshape(img.shape), img, casting="unsafe")
+        return stage
 
 
 class _ShapeView:

@@ -136,7 +136,7 @@ class BaseDataset:
         with pool_budget_bytes the arrays are re-uploaded on demand like files are re-decoded)."""
         images = list(images)
         self._pool = A.ImagePool(count=len(images), decode=images.__getitem__, shapes=[tuple(np.asarray(im).shape[:2]) for im in images],
-                                 device=self.device, budget_bytes=self.pool_budget_bytes, slab_bytes=self.pool_slab_bytes, workers=1)
+                                 device=self.device, budget_bytes=self.pool_budget_bytes, slab_bytes=self.pool_slab_bytes, workers=self.decode_workers)
         self._labels = {i: (np.asarray(p, dtype=np.float32).reshape(-1, 8), np.asarray(c, dtype=np.float32).reshape(-1))
                         for i, (p, c) in enumerate(zip(polys, labels))}
         if not self.img_files:

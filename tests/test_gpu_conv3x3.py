@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, H, W, Cin, Cout, epi=0, ld_extra=0, mirrored=False, seed=0, act=3):
+def _run(B, H, W, Cin, Cout, epi=0, ld_extra=0, mirrored=False, seed=0, act=3, expect_kernel=1):
     from ryolov4_amd import hip
     from ryolov4_amd.engine import structs as S
     hip.lib()
@@ -46,7 +46,7 @@ def _run(B, H, W, Cin, Cout, epi=0, ld_extra=0, mirrored=False, seed=0, act=3):
     p.scale, p.shift, p.act = co.data_ptr() + 2 * Cout * 4, co.data_ptr() + 3 * Cout * 4, act
     rows, kern = S.I(), S.I()
     hip.call("ryolo_conv_gemm_plan", p, rows, kern)
-    assert kern.value == 1, "layer not routed to the patch kernel"
+    assert kern.value == expect_kernel, f"layer routed to kernel family {kern.value}, expected {expect_kernel}"
     stats = torch.zeros(rows.value, 2, Cout, device=dev)
     p.stats = stats.data_ptr()
     hip.call("ryolo_conv_gemm", p, hip.stream())
@@ -100,3 +100,17 @@ def test_patch_kernel_activations(act):
 def test_patch_kernel_mirrored_taps():
     _run(2, 50, 50, 128, 64, mirrored=True)
     _run(2, 26, 26, 64, 128, mirrored=True, epi=4)
+
+
+# ---- the persistent weight-stationary kernel for 64 -> <= 64 channels (csrc/conv3x3_ws.hip): by default only when every workgroup gets >= 4 tiles
+@pytest.mark.parametrize("epi", [0, 1, 4])
+def test_persistent_64_channel_kernel_multi_tile(epi):
+    """8 x 200 x 200: 1280 tiles of 10 x 25 over 256 persistent workgroups — 5 tiles each, so the double-buffered patch pipeline (request two
+    tiles ahead), the per-tile barrier and the register-accumulated statistics all run in their steady state; raw / statistics / accumulate
+    epilogues, output in a channel slice of a wider buffer."""
+    _run(8, 200, 200, 64, 64, epi=epi, ld_extra=64, seed=10 + epi, expect_kernel=3)
+
+
+def test_persistent_64_channel_kernel_mirrored_taps_and_narrow_output():
+    _run(8, 200, 200, 64, 64, mirrored=True, epi=4, seed=20, expect_kernel=3)          # the data-gradient tap order
+    _run(8, 200, 200, 64, 40, epi=1, seed=21, expect_kernel=3)                          # Cout = 40: zero weight rows, partial column chunks
