@@ -27,9 +27,12 @@
 #include "conv_internal.h"
 #include <type_traits>
 
-#define WS3_STG_LD 40                                          // staging row stride in bf16 (32 channels + 8: 80 bytes, 16-byte aligned)
-#define WS3_STG_BYTES (128 * WS3_STG_LD * 2)                   // one wave's staging block: 128 pixel rows
+#define WS3_STG_BYTES (128 * 64)                               // one wave's staging block: 128 pixel rows x 32 channels (64-byte rows, 16-byte chunks
+                                                               // XOR-swizzled with (row >> 1) & 3)
 #define WS3_WAVES 4
+#define WS3_PF 6                                               // pixel fragments in flight per wave (one wave per SIMD: nobody else hides the LDS latency)
+#define WS3_NU 144                                             // MFMA units per tile and wave: 9 taps x 4 K-steps x 4 pixel blocks
+#define WS3_NPW 12                                             // DMA pieces per wave and tile (pieces past the patch go to a dummy KiB)
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char ws3_lds[];
 
@@ -49,16 +52,17 @@ template <int N> struct Ws3Unroll<N, N> {
 template <int N> __device__ __forceinline__ void ws3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // LDS reads next to LDS-DMA in flight go through inline asm with hand-counted lgkmcnt: for a plain load hipcc's waitcnt pass cannot tell the
 // staging / patch reads from the DMA's LDS writes and drains vmcnt(0) in front of them — i.e. it would wait for the patch requested two tiles
-// ahead right after requesting it (seen in the ISA of the first cut).  LDS operations of a wave return in order; no scalar load may sit
-// between a read and its wait (scalar loads share lgkmcnt and return out of order): the regions below touch registers only.
+// ahead right after requesting it (seen in the ISA of the first cut).  LDS operations of a wave return in order, so "at most N of the
+// operations issued after X are still in flight" means X is done; scalar loads share the counter and return out of order, which can only make
+// such a wait more conservative (X cannot be outstanding while fewer than N + 1 LDS operations are).
+typedef unsigned ws3_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned ws3_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 ws3_rd128(unsigned addr)
 {
     bf16x8 r;
     asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
     return r;
 }
-typedef unsigned ws3_u4 __attribute__((ext_vector_type(4)));
-typedef unsigned ws3_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ws3_u4 ws3_rd128u(unsigned addr)
 {
     ws3_u4 r;
@@ -71,17 +75,70 @@ __device__ __forceinline__ ws3_u2 ws3_rd64u(unsigned addr)
     asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr) : "memory");
     return r;
 }
+// (LDS WRITES too: in front of a plain ds_write hipcc waits for every LDS-DMA in flight — here the pieces of the patch two tiles ahead, requested
+// a few hundred cycles earlier)
+__device__ __forceinline__ void ws3_wr64(unsigned addr, unsigned lo, unsigned hi)
+{
+    const ws3_u2 v = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 template <int N> __device__ __forceinline__ void ws3_wait_lds(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
-template <int N> __device__ __forceinline__ void ws3_wait_lds(ws3_u4& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
-template <int N> __device__ __forceinline__ void ws3_wait_lds(ws3_u2& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+// ... and the registers of EARLIER extra reads that this wait also covers (tied, so that their consumers cannot be scheduled above it)
+template <int N> __device__ __forceinline__ void ws3_wait_lds(bf16x8& f, ws3_u2& a, ws3_u2& b, ws3_u2& c, ws3_u2& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f), "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws3_wait_lds(bf16x8& f, ws3_u4& a, ws3_u4& b, ws3_u4& c, ws3_u4& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f), "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws3_wait_lds(ws3_u2& a, ws3_u2& b, ws3_u2& c, ws3_u2& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws3_wait_lds(ws3_u4& a, ws3_u4& b, ws3_u4& c, ws3_u4& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+// ---- what else rides in the MFMA shadow of a tile's 144 units (the work of the PREVIOUS tile's epilogue and of the patch two tiles ahead) ----
+//   unit 50                     accumulate epilogue: the 8 old 16-byte row segments of THIS tile are requested (consumed a tile later)
+//   units 1, 9, 17, 25          statistics: 4 staged 8-byte reads each, consumed WS3_PF units later
+//   units 33, 41                4 staged 16-byte row segments each, stored to HBM WS3_PF units later
+//   units 56 + 7 i, i = 0..11   DMA piece i of the patch two tiles ahead (LAST among the tile's memory operations: "all but the newest 12
+//                               have completed" is then exactly "the patch of the NEXT tile has landed", whatever the stores did)
+__host__ __device__ constexpr int ws3_extra_reads(int u, bool first, bool stats)
+{
+    if (first) return 0;
+    if (stats && (u == 1 || u == 9 || u == 17 || u == 25)) return 4;
+    if (u == 33 || u == 41) return 4;
+    return 0;
+}
+// LDS operations issued after fragment read v and before unit v waits for it (unit w: wait, consume, extra reads, fragment read w + PF, MFMA)
+__host__ __device__ constexpr int ws3_later(int v, bool first, bool stats)
+{
+    int n = v < WS3_PF - 1 ? WS3_PF - 1 - v : 0;
+    for (int w = (v - WS3_PF + 1 > 0 ? v - WS3_PF + 1 : 0); w < v; w++) n += ws3_extra_reads(w, first, stats) + (w + WS3_PF < WS3_NU ? 1 : 0);
+    return n;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_ws64_kernel(const ConvGemmParams p, const Ws3Geom g)
 {
+    constexpr bool STATS = EPI == EPI_STATS, ACCUM = EPI == EPI_ACCUM;
+    constexpr int PF = WS3_PF, NU = WS3_NU;
+#ifdef WS3_TIMING
+    const unsigned long long TT0 = __builtin_readcyclecounter();
+    unsigned long long t_loop = 0, t_tail = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: uniform branches, scalar LDS bases
     const int wm = wave >> 1, wn = wave & 1;                   // wave = pixel half of the tile (128 pixels) x output-channel half (32)
     const int h = lane >> 5, l31 = lane & 31;
     const int H = p.OH, W = p.OW;
+    const unsigned PB = g.patch_bytes;
+    const unsigned lbase = lds_addr(ws3_lds);
+    const unsigned sbase = lbase + 3u * PB + (unsigned)wave * WS3_STG_BYTES;          // this wave's staging block
+    const unsigned dummy_off = 3u * PB + WS3_WAVES * WS3_STG_BYTES;                  // 1 KiB nobody reads
 
     // ---- my tiles: XCD x owns the contiguous range [x * T8, (x + 1) * T8); its workgroups take them round robin -----------------------------
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -91,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tend = min((xcd + 1) * T8, (int)g.ntiles);
     const int ntl = tbeg < tend ? (tend - tbeg + nloc - 1) / nloc : 0;
 
-    // ---- weights -> registers (A operands: row = output channel nb * 32 + l31, K = 16 input channels of step ks, 8 per lane half) -----------
+    // ---- weights -> registers (A operands: row = output channel wn * 32 + l31, K = 16 input channels of step ks, 8 per lane half) -----------
     bf16x8 wreg[9][4];
     {
         const int co = wn * 32 + l31;
@@ -107,9 +164,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
     }
 
-    // ---- patch DMA: piece j = wave + 4 u covers patch rows 8 j ... 8 j + 7; lane -> (row, 16-byte slot); (patch row, column) are recomputed per
-    //      tile (two multiplications per piece) rather than kept in 12 registers
-    constexpr int MAXU = 12;                                   // <= 48 pieces = 384 patch rows
+    // ---- patch DMA: piece j = wave + 4 u covers patch rows 8 j ... 8 j + 7, lane -> (row, 16-byte slot).  Per piece and lane, once per launch:
+    //      the element offset of its 16 bytes relative to the tile's first pixel, and 5 flag bits — the row belongs to the top / bottom / left /
+    //      right halo, or does not exist; a tile ANDs them with "which of its edges lie on the image border" (dead lanes read the zero page)
+    int d_rel[WS3_NPW];
+    unsigned dfl0 = 0, dfl1 = 0;
+#pragma unroll
+    for (int u = 0; u < WS3_NPW; u++) {
+        const int j = wave + WS3_WAVES * u;
+        const int row = 8 * j + (lane >> 3);
+        const int pr = small_div(row, g.PW, g.rPW), pc = row - pr * g.PW;
+        d_rel[u] = ((pr - 1) * W + (pc - 1)) * p.ldA + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        const unsigned fl = (pr == 0 ? 1u : 0u) | (pr == g.TH + 1 ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc == g.TW + 1 ? 8u : 0u) |
+                            ((j >= g.NP || row >= g.R) ? 16u : 0u);
+        if (u < 6) dfl0 |= fl << (5 * u);
+        else dfl1 |= fl << (5 * (u - 6));
+    }
     // ---- B-operand (pixel) fragment addresses: pixel block b of this wave, tap t -> swizzled LDS byte offset of its patch row (buffer 0) -----
     unsigned aaddr[4][9];
     bool live[4];
@@ -124,173 +194,252 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             aaddr[b][t] = (row << 7) + ((((row >> 1) & 7u) ^ (unsigned)h) << 4);       // K-step ks: ^ (ks << 5)
         }
     }
-    // ---- store side: lane -> 16-byte chunk ch of staged row it * 16 + r0 -----------------------------------------------------------------------
+    unsigned abase_now = 0u;                                   // what the addresses above are currently relative to (LDS address of the patch buffer in use)
+    // ---- store side: lane -> 16-byte chunk ch of staged row it * 16 + r0 (chunk position ^ (row >> 1) & 3) ------------------------------------
     const int ch = lane & 3, r0 = lane >> 2;
     const int ncol = wn * 32 + ch * 8;
     const bool col_ok = ncol < p.Nout;
-    unsigned char* const stg = ws3_lds + 2u * g.patch_bytes + (unsigned)wave * WS3_STG_BYTES;
-    // statistics: lane -> channel quad cq (4 channels), rows rg + 8 k
+    // statistics: lane -> channel quad cq (4 channels = half a chunk), rows rg + 8 k
     const int cq = lane & 7, rg = lane >> 3;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    auto stg_addr16 = [&](int row) { return sbase + (unsigned)(row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)); };
+    auto stg_addr8 = [&](int row) { return sbase + (unsigned)(row * 64 + ((((cq >> 1) ^ ((row >> 1) & 3)) << 4) | ((cq & 1) << 3))); };
 
-    auto tile_origin = [&](int tile, int& pix0, int& oh0, int& ow0) {
+    struct TileAt { int pix0; unsigned em; };                   // first pixel, edges on the image border (flag bits as above; 16 always set)
+    auto tile_at = [&](int tile) {
         const int img = tile / g.tilesPerImg;
         const int rem = tile - img * g.tilesPerImg;
         const int th = rem / g.tilesW;
-        oh0 = th * g.TH;
-        ow0 = (rem - th * g.tilesW) * g.TW;
-        pix0 = (img * H + oh0) * W + ow0;
+        const int oh0 = th * g.TH, ow0 = (rem - th * g.tilesW) * g.TW;
+        TileAt t;
+        t.pix0 = (img * H + oh0) * W + ow0;
+        t.em = 16u | (oh0 == 0 ? 1u : 0u) | (oh0 + g.TH == H ? 2u : 0u) | (ow0 == 0 ? 4u : 0u) | (ow0 + g.TW == W ? 8u : 0u);
+        return t;
     };
-    auto issue_patch = [&](int tile, unsigned buf_off) {
-        int pix0, oh0, ow0;
-        tile_origin(tile, pix0, oh0, ow0);
+    // one DMA piece; have == false (no such tile): every lane reads the zero page into the dummy KiB — the instruction is ALWAYS issued, so the
+    // per-tile count of memory operations is a constant (the end-of-tile wait counts them)
+    auto issue_piece = [&](int u, bool have, const TileAt& t, unsigned buf_off) {
+        const unsigned fl = ((u < 6 ? dfl0 >> (5 * u) : dfl1 >> (5 * (u - 6))) & 31u);
+        const bool dead = (fl & (have ? t.em : 31u)) != 0u;
+        const bf16_t* src = dead ? p.zeros : p.A + ((int64_t)t.pix0 * p.ldA + d_rel[u]);
+        const int j = wave + WS3_WAVES * u;
+        const unsigned dst = (have && j < g.NP) ? buf_off + (unsigned)j * 1024u : dummy_off;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ws3_lds + dst), 16, 0, 0);
+    };
+    // output row segment of staged row `row` of the tile at pix0 (dead rows: pixel 0 of the tile, never stored)
+    auto out_ptr = [&](int pix0, int row, bool& lv) {
+        const int m = wm * 128 + row;
+        const int r = small_div(m, g.TW, g.rTW), c = m - r * g.TW;
+        lv = (m < g.TH * g.TW) & col_ok;
+        return reinterpret_cast<bf16_t*>(p.out) + ((int64_t)pix0 + (lv ? r * W + c : 0)) * p.ldC + (col_ok ? ncol : 0);
+    };
+    auto stat_add = [&](const ws3_u2& w) {
+        const float f0 = __uint_as_float(w.x << 16), f1 = __uint_as_float(w.x & 0xffff0000u);
+        const float f2 = __uint_as_float(w.y << 16), f3 = __uint_as_float(w.y & 0xffff0000u);
+        ssum[0] += f0; ssq[0] += f0 * f0;
+        ssum[1] += f1; ssq[1] += f1 * f1;
+        ssum[2] += f2; ssq[2] += f2 * f2;
+        ssum[3] += f3; ssq[3] += f3 * f3;
+    };
+    auto store_seg = [&](bf16_t* o, bool lv, const ws3_u4& sv, const uint4& old) {
+        uint4 v = make_uint4(sv.x, sv.y, sv.z, sv.w);
+        if (ACCUM) {
+            const unsigned* a = reinterpret_cast<const unsigned*>(&v);
+            const unsigned* bb = reinterpret_cast<const unsigned*>(&old);
+            unsigned w[4];
 #pragma unroll
-        for (int u = 0; u < MAXU; u++) {
-            const int j = wave + WS3_WAVES * u;
-            if (j < g.NP) {                                    // wave-uniform
-                const int row = 8 * j + (lane >> 3);
-                const int pr = small_div(row, g.PW, g.rPW), pc = row - pr * g.PW;
-                const int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
-                // branch-free: every lane forms its address, dead lanes (halo outside the image, rows past the patch) select the zero page
-                const bool ok = (row < g.R) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
-                const int64_t pix = (int64_t)pix0 + (pr - 1) * W + (pc - 1);
-                const unsigned ofs = (unsigned)((pix * p.ldA + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) >> 3);
-                const bf16_t* live_src = p.A + ((int64_t)ofs << 3);
-                const bf16_t* src = ok ? live_src : p.zeros;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ws3_lds + buf_off + (unsigned)j * 1024u), 16, 0, 0);
-            }
+            for (int e = 0; e < 4; e++)
+                w[e] = pack_bf2(__uint_as_float(a[e] << 16) + __uint_as_float(bb[e] << 16),
+                                __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(bb[e] & 0xffff0000u));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        if (lv) *reinterpret_cast<uint4*>(o) = v;
     };
 
-    if (ntl > 0) issue_patch(tbeg, 0u);
-    if (ntl > 1) issue_patch(tbeg + nloc, g.patch_bytes);
-    ws3_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-
-    for (int k = 0; k < ntl; k++) {
-        const unsigned pbuf = (k & 1) ? g.patch_bytes : 0u;
-        // (the buffer offset goes through an opaque VGPR: with a loop-invariant expression hipcc hoists all 72 fragment addresses out of the tile
-        // loop — 72 registers of a kernel that has none to spare; patch_bytes is a multiple of 1024, so (a + p) ^ (ks << 5) == (a ^ (ks << 5)) + p)
-        unsigned pbv = pbuf;
-        asm volatile("" : "+v"(pbv));
-        // accumulate epilogue: the 8 old 16-byte row segments of this lane are requested NOW and consumed after the tile's MFMAs (loading them
-        // in the store phase exposed two HBM round trips per tile: as long as the tile itself)
-        int pix0, oh0, ow0;
-        tile_origin(tbeg + k * nloc, pix0, oh0, ow0);
-        uint4 oldv[8];
-        if (EPI == EPI_ACCUM) {
+    uint4 oldv[8];                                             // accumulate epilogue: old row segments of the tile whose store phase comes next
+    // ---- one tile: 144 MFMAs from patch buffer `bcur`; in their shadow the epilogue of the previous tile (at prev_pix0) and the DMA of the tile
+    //      two ahead (into `bfar`, the buffer the previous tile used) -------------------------------------------------------------------------------
+    auto compute = [&](auto first_tag, unsigned bcur, unsigned bfar, int far_tile, int prev_pix0, int cur_pix0) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // the 36 fragment row addresses follow the patch buffer (one add each per tile; per unit only the K-step XOR is left: patch_bytes is a
+        // multiple of 1024, so (a + p) ^ (ks << 5) == (a ^ (ks << 5)) + p)
+        {
+            const unsigned delta = lbase + bcur - abase_now;
 #pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int m = wm * 128 + it * 16 + r0;
-                const int r = small_div(m, g.TW, g.rTW), c = m - r * g.TW;
-                const bool lv = (m < g.TH * g.TW) & col_ok;
-                oldv[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.out) + ((int64_t)pix0 + (lv ? r * W + c : 0)) * p.ldC +
-                                                            (col_ok ? ncol : 0));
-            }
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int t = 0; t < 9; t++) aaddr[b][t] += delta;
+            abase_now = lbase + bcur;
         }
+        const bool have_far = far_tile >= 0;
+        TileAt far;
+        far.pix0 = 0;
+        far.em = 31u;
         f32x16 acc[4];
 #pragma unroll
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[b][e] = 0.f;
-        // ---- 144 MFMAs over the resident patch: unit u = (tap, K-step, pixel block); the fragment of unit u + PF is read while unit u multiplies --
-        constexpr int NU = 144, PF = 4;
         bf16x8 fr[PF];
-        const unsigned lbase = lds_addr(ws3_lds);
+        ws3_u2 sw[4];
+        ws3_u4 sv[4];
+        bf16_t* optr[4];
+        bool olv[4];
         auto rd = [&](int u) {
             const int t = u >> 4, ks = (u >> 2) & 3, b = u & 3;
-            return ws3_rd128(lbase + ((aaddr[b][t] + pbv) ^ (unsigned)(ks << 5)));
+            return ws3_rd128(ks ? aaddr[b][t] ^ (unsigned)(ks << 5) : aaddr[b][t]);
         };
+#ifdef WS3_TIMING
+        const unsigned long long tc0 = __builtin_readcyclecounter();
+#endif
         auto pre = [&](auto uc) { constexpr int u = decltype(uc)::value; fr[u] = rd(u); };
         Ws3Unroll<0, PF>::run(pre);
         auto unit = [&](auto uc) {
             constexpr int u = decltype(uc)::value;
+            constexpr int later = ws3_later(u, FIRST, STATS);
+            static_assert(later <= 15, "lgkmcnt is a 4-bit counter");
             __builtin_amdgcn_sched_barrier(0);
-            // reads u + 1 ... u + PF - 1 were issued after read u: at most that many may still be in flight
-            constexpr int later = NU - 1 - u < PF - 1 ? NU - 1 - u : PF - 1;
-            ws3_wait_lds<later>(fr[u % PF]);
+            // ---- wait for fragment u (and for the extra reads issued PF units ago, which precede fragment u in the LDS queue) ---------------------
+            constexpr bool use_stats = !FIRST && STATS && (u == 1 + PF || u == 9 + PF || u == 17 + PF || u == 25 + PF);
+            constexpr bool use_store = !FIRST && (u == 33 + PF || u == 41 + PF);
+            if constexpr (use_stats) ws3_wait_lds<later>(fr[u % PF], sw[0], sw[1], sw[2], sw[3]);
+            else if constexpr (use_store) ws3_wait_lds<later>(fr[u % PF], sv[0], sv[1], sv[2], sv[3]);
+            else ws3_wait_lds<later>(fr[u % PF]);
             const bf16x8 cur = fr[u % PF];
+            if constexpr (use_stats) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) stat_add(sw[q]);
+            }
+            if constexpr (use_store) {
+                constexpr int g0 = u == 33 + PF ? 0 : 4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) store_seg(optr[q], olv[q], sv[q], oldv[g0 + q]);
+            }
+            // ---- extra requests of this unit --------------------------------------------------------------------------------------------------
+            if constexpr (ACCUM && u == 50) {
+                // the old values of THIS tile, for the store phase that runs under the NEXT tile's MFMAs (requested most of a tile ahead: loading
+                // them inside that store phase exposed an HBM round trip per tile; the previous tile's were consumed at units 39 / 47)
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    bool lv;
+                    const bf16_t* o = out_ptr(cur_pix0, it * 16 + r0, lv);
+                    oldv[it] = *reinterpret_cast<const uint4*>(o);
+                }
+            }
+            if constexpr (u == 52) {
+                // scalar index arithmetic (two divisions) in the shadow of the MFMAs; branch-free: a join in this stream would make hipcc drain
+                // its counters (no tile two ahead: tile 0's origin with every lane dead)
+                far = tile_at(have_far ? far_tile : 0);
+                far.em = have_far ? far.em : 31u;
+            }
+            if constexpr (!FIRST && STATS && (u == 1 || u == 9 || u == 17 || u == 25)) {
+                constexpr int k4 = (u - 1) / 2;                   // rows rg + 8 (k4 + q): groups 0, 4, 8, 12
+#pragma unroll
+                for (int q = 0; q < 4; q++) sw[q] = ws3_rd64u(stg_addr8(rg + 8 * (k4 + q)));
+            }
+            if constexpr (!FIRST && (u == 33 || u == 41)) {
+                constexpr int g0 = u == 33 ? 0 : 4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    optr[q] = out_ptr(prev_pix0, (g0 + q) * 16 + r0, olv[q]);
+                    sv[q] = ws3_rd128u(stg_addr16((g0 + q) * 16 + r0));
+                }
+            }
+            if constexpr (u >= 56 && (u - 56) % 7 == 0 && (u - 56) / 7 < WS3_NPW) issue_piece((u - 56) / 7, have_far, far, bfar);
             if constexpr (u + PF < NU) fr[u % PF] = rd(u + PF);
             __builtin_amdgcn_sched_barrier(0);
             acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[u >> 4][(u >> 2) & 3], cur, acc[u & 3], 0, 0, 0);
         };
         Ws3Unroll<0, NU>::run(unit);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- accumulators -> the wave's staging block: lane owns pixel (b, l31), channels 8 g4 + 4 h + (0..3) of the wave's 32; dead pixels store zeros --
+#ifdef WS3_TIMING
+        const unsigned long long tc1 = __builtin_readcyclecounter();
+        t_loop += tc1 - tc0;
+#endif
+        // ---- accumulators -> the wave's staging block: lane owns pixel (b, l31), channels 8 g4 + 4 h + (0..3) of the wave's 32; dead pixels store
+        //      zeros.  (The previous tile's staged rows were all read above: same wave, program order.) ------------------------------------------
 #pragma unroll
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 float v0 = acc[b][4 * g4], v1 = acc[b][4 * g4 + 1], v2 = acc[b][4 * g4 + 2], v3 = acc[b][4 * g4 + 3];
                 if (!live[b]) v0 = v1 = v2 = v3 = 0.f;
-                *reinterpret_cast<uint2*>(stg + ((b * 32 + l31) * WS3_STG_LD + 8 * g4 + 4 * h) * 2) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+                const int row = b * 32 + l31;
+                ws3_wr64(sbase + (unsigned)(row * 64 + (((g4 ^ ((row >> 1) & 3)) << 4) | (h << 3))), pack_bf2(v0, v1), pack_bf2(v2, v3));
             }
-        // ---- everyone is done with patch k (its buffer is free) and every piece of patch k + 1 has landed -------------------------------------
-        ws3_wait_vm<0>();
+        // ---- all but this tile's 12 DMA pieces have completed: the NEXT tile's patch (requested one tile ago) has landed; then everyone is done
+        //      with the current buffer -----------------------------------------------------------------------------------------------------------
+        ws3_wait_vm<WS3_NPW>();
         __builtin_amdgcn_s_barrier();
-        // ---- store phase of tile k (wave-local: own ds_write -> ds_read ordering) -----------------------------------------------------------
-        const unsigned sbase = lds_addr(stg);
-        if (EPI == EPI_STATS) {
+#ifdef WS3_TIMING
+        t_tail += __builtin_readcyclecounter() - tc1;
+#endif
+        return far.pix0;                                          // first pixel of the tile two ahead (0 when there is none)
+    };
+
+    // ---- prologue: the first two patches ----------------------------------------------------------------------------------------------------
+    {
+        const TileAt t0 = tile_at(ntl > 0 ? tbeg : 0), t1 = tile_at(ntl > 1 ? tbeg + nloc : 0);
 #pragma unroll
-            for (int k4 = 0; k4 < 16; k4 += 4) {                  // 4 reads in flight
+        for (int u = 0; u < WS3_NPW; u++) issue_piece(u, ntl > 0, t0, 0u);
+#pragma unroll
+        for (int u = 0; u < WS3_NPW; u++) issue_piece(u, ntl > 1, t1, PB);
+    }
+    ws3_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+#ifdef WS3_TIMING
+    const unsigned long long TT1 = __builtin_readcyclecounter();
+#endif
+    unsigned b0 = 0u, b1 = PB, b2 = 2u * PB;                   // buffers of tile k, k + 1, k + 2 (= the one tile k - 1 used)
+    int prev_pix0 = 0, cur_pix0 = ntl > 0 ? tile_at(tbeg).pix0 : 0, next_pix0 = ntl > 1 ? tile_at(tbeg + nloc).pix0 : 0;
+    for (int k = 0; k < ntl; k++) {
+        const int far_tile = k + 2 < ntl ? tbeg + (k + 2) * nloc : -1;
+        const int far_pix0 = k == 0 ? compute(std::true_type{}, b0, b2, far_tile, 0, cur_pix0)
+                                    : compute(std::false_type{}, b0, b2, far_tile, prev_pix0, cur_pix0);
+        prev_pix0 = cur_pix0;
+        cur_pix0 = next_pix0;
+        next_pix0 = far_pix0;
+        const unsigned t = b0;
+        b0 = b1; b1 = b2; b2 = t;
+    }
+    // ---- epilogue of the last tile (nothing left to hide it under) -----------------------------------------------------------------------------
+    if (ntl > 0) {
+        if (STATS) {
+#pragma unroll
+            for (int k4 = 0; k4 < 16; k4 += 4) {
                 ws3_u2 w[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) w[q] = ws3_rd64u(sbase + (unsigned)(((rg + 8 * (k4 + q)) * WS3_STG_LD + cq * 4) * 2));
+                for (int q = 0; q < 4; q++) w[q] = ws3_rd64u(stg_addr8(rg + 8 * (k4 + q)));
+                ws3_wait_lds<0>(w[0], w[1], w[2], w[3]);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (q == 0) ws3_wait_lds<3>(w[q]);
-                    else if (q == 1) ws3_wait_lds<2>(w[q]);
-                    else if (q == 2) ws3_wait_lds<1>(w[q]);
-                    else ws3_wait_lds<0>(w[q]);
-                    const float f0 = __uint_as_float(w[q].x << 16), f1 = __uint_as_float(w[q].x & 0xffff0000u);
-                    const float f2 = __uint_as_float(w[q].y << 16), f3 = __uint_as_float(w[q].y & 0xffff0000u);
-                    ssum[0] += f0; ssq[0] += f0 * f0;
-                    ssum[1] += f1; ssq[1] += f1 * f1;
-                    ssum[2] += f2; ssq[2] += f2 * f2;
-                    ssum[3] += f3; ssq[3] += f3 * f3;
-                }
+                for (int q = 0; q < 4; q++) stat_add(w[q]);
             }
         }
 #pragma unroll
-        for (int g0 = 0; g0 < 8; g0 += 4) {                       // two groups of 4 rows: the loads of an accumulate epilogue are issued together
-            bf16_t* optr[4];
-            ws3_u4 sv[4];
-            bool lvq[4];
+        for (int g0 = 0; g0 < 8; g0 += 4) {
+            bf16_t* o[4];
+            bool lv[4];
+            ws3_u4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int m = wm * 128 + (g0 + q) * 16 + r0;               // tile-local pixel of staged row (g0 + q) * 16 + r0
-                const int r = small_div(m, g.TW, g.rTW), c = m - r * g.TW;
-                lvq[q] = m < g.TH * g.TW && col_ok;
-                optr[q] = reinterpret_cast<bf16_t*>(p.out) + ((int64_t)pix0 + (lvq[q] ? r * W + c : 0)) * p.ldC + (col_ok ? ncol : 0);
+                o[q] = out_ptr(prev_pix0, (g0 + q) * 16 + r0, lv[q]);
+                v[q] = ws3_rd128u(stg_addr16((g0 + q) * 16 + r0));
             }
+            ws3_wait_lds<0>(v[0], v[1], v[2], v[3]);
 #pragma unroll
-            for (int q = 0; q < 4; q++) sv[q] = ws3_rd128u(sbase + (unsigned)((((g0 + q) * 16 + r0) * WS3_STG_LD + ch * 8) * 2));
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (q == 0) ws3_wait_lds<3>(sv[q]);
-                else if (q == 1) ws3_wait_lds<2>(sv[q]);
-                else if (q == 2) ws3_wait_lds<1>(sv[q]);
-                else ws3_wait_lds<0>(sv[q]);
-                uint4 v = make_uint4(sv[q].x, sv[q].y, sv[q].z, sv[q].w);
-                if (EPI == EPI_ACCUM) {
-                    const unsigned* a = reinterpret_cast<const unsigned*>(&v);
-                    const unsigned* bb = reinterpret_cast<const unsigned*>(&oldv[g0 + q]);
-                    unsigned w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        w[e] = pack_bf2(__uint_as_float(a[e] << 16) + __uint_as_float(bb[e] << 16),
-                                        __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(bb[e] & 0xffff0000u));
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                if (lvq[q]) *reinterpret_cast<uint4*>(optr[q]) = v;
-            }
+            for (int q = 0; q < 4; q++) store_seg(o[q], lv[q], v[q], oldv[g0 + q]);       // (old values: requested under the last tile's MFMAs)
         }
-        // ---- the patch two tiles ahead goes into the buffer this tile just released (requested LAST in the iteration: every LDS read above is
-        //      already done, the next ones are the asm reads of the compute loop) ------------------------------------------------------------------
-        if (k + 2 < ntl) issue_patch(tbeg + (k + 2) * nloc, pbuf);
     }
-    if (EPI == EPI_STATS) {
+#ifdef WS3_TIMING
+    if (p.bias && tid == 0) {                                   // tools/bench_conv.py: [prologue, sum of MFMA loops, sum of tile tails, whole kernel], tiles
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + (size_t)blockIdx.x * 4;
+        dbg[0] = TT1 - TT0; dbg[1] = t_loop; dbg[2] = t_tail; dbg[3] = ((__builtin_readcyclecounter() - TT0) << 12) | (unsigned)ntl;
+    }
+#endif
+    if (STATS) {
         // one partial row per workgroup: lanes park their 8 sums in LDS, one thread per channel folds 2 pixel halves x 8 row groups in a fixed order
+        ws3_wait_vm<0>();                                        // (the dummy DMA pieces of the last tiles: nothing may still write LDS)
         __syncthreads();
         float* part = reinterpret_cast<float*>(ws3_lds);         // [wave][rg][2][32]
         float* mine = part + ((wave * 8 + rg) * 2) * 32 + cq * 4;
@@ -368,7 +517,7 @@ bool ws3_geometry(const ConvGemmParams& p, Ws3Geom& g)
     g.NP = (int)ry_cdiv(g.R, 8);
     if (g.NP > 48) return false;
     g.patch_bytes = (unsigned)g.NP * 1024u;
-    g.lds_bytes = 2u * g.patch_bytes + (unsigned)WS3_WAVES * WS3_STG_BYTES;
+    g.lds_bytes = 3u * g.patch_bytes + (unsigned)WS3_WAVES * WS3_STG_BYTES + 1024u;
     if (g.lds_bytes > 160u * 1024u) return false;
     g.tilesW = W / best_tw;
     g.tilesPerImg = (H / best_th) * g.tilesW;

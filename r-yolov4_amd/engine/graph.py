@@ -234,6 +234,8 @@ class Graph:
                 return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl, by)
             if fam == 2:
                 return ("gemm1x1_ws_kernel", fl, by)
+            if fam == 3:
+                return ("conv3x3_ws64_kernel", fl, by)
             # the generic kernel's instantiations as rocprofv3 lists them: tile shape, and the 1x1 form (no tap table / tile decomposition)
             kind = f"conv_gemm_kernel<{((kv >> 12) & 15) * 64}x{((kv >> 16) & 15) * 32}{',1x1' if kv & 0x100 else ''}>"
             if kv & 0x100:

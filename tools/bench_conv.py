@@ -37,7 +37,7 @@ except Exception:                                   # older library (A/B runs th
 stats = torch.zeros(rows.value, 2, Cout, device=dev)
 p.stats = stats.data_ptr()
 dbg = torch.zeros(4 * 70000, dtype=torch.int64, device=dev)
-if os.environ.get('P3_TIMING') or os.environ.get('GEMM_TIMING'): p.bias = dbg.data_ptr()
+if os.environ.get('P3_TIMING') or os.environ.get('GEMM_TIMING') or os.environ.get('WS3_TIMING'): p.bias = dbg.data_ptr()
 st = hip.stream()
 for _ in range(3): hip.call("ryolo_conv_gemm", p, st)
 torch.cuda.synchronize()
@@ -70,3 +70,11 @@ if os.environ.get('P3_TIMING'):
     torch.cuda.synchronize()
     d = dbg.view(-1, 4).cpu().numpy(); d = d[d[:, 0] != 0]
     print("blocks", len(d), "prologue", np.mean(d[:, 1] - d[:, 0]), "loop", np.mean(d[:, 2] - d[:, 1]), "epilogue", np.mean(d[:, 3] - d[:, 2]))
+if os.environ.get('WS3_TIMING'):
+    import numpy as np
+    torch.cuda.synchronize()
+    d = dbg.view(-1, 4).cpu().numpy(); d = d[d[:, 3] != 0]
+    tiles = d[:, 3] & 4095
+    total = d[:, 3] >> 12
+    print("workgroups", len(d), "tiles/wg", tiles.mean(), "kernel cycles", total.mean(), "prologue", d[:, 0].mean(), "MFMA loop per tile", (d[:, 1] / tiles).mean(),
+          "tail per tile", (d[:, 2] / tiles).mean(), "unaccounted per tile", ((total - d[:, 0] - d[:, 1] - d[:, 2]) / tiles).mean())
