@@ -223,6 +223,10 @@ int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, floa
  * hsv: BGR->HSV, lut [3][256] (hue, sat, val), HSV->BGR, in place.  mixup: out = uint8(a*r + b*(1-r)). */
 int ryolo_paste_rects(const uint8_t* pool, const void* rects_dev, int nrect, uint8_t* canvas, int ncanvas, int CH, int CW, int fill,
                       ryolo_stream_t stream);
+/* the same with the rectangles grouped by canvas (first_dev [ncanvas + 1] ints: canvas b owns rects[first[b] .. first[b + 1])): a canvas pixel looks at
+ * its own canvas's <= 9 rectangles instead of the whole batch's table (what BaseDataset.assemble_batch uses: load_mosaic / load_mosaic9 of every sample) */
+int ryolo_paste_rects_grouped(const uint8_t* pool, const void* rects_dev, int nrect, const int* first_dev, uint8_t* canvas, int ncanvas, int CH, int CW,
+                              int fill, ryolo_stream_t stream);
 int ryolo_paste_rect_bytes(int* bytes);
 int ryolo_warp_perspective_u8(const uint8_t* src, int batch, int SH, int SW, const double* Minv, uint8_t* dst, int DH, int DW, int border,
                               ryolo_stream_t stream);

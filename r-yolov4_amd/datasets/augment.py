@@ -37,13 +37,14 @@ class ImagePool:
     """Decoded uint8 HWC (BGR) images of different sizes (what cv2.imread leaves per file) resident in HBM, filled ON DEMAND and bounded
     by a byte budget — the role of the reference's 8 DataLoader workers re-reading files from disk (lib/load.py:19).
 
-    Memory is a list of equally sized SLABS (one torch uint8 tensor each); an image is bump-allocated into the current slab and addressed
-    by its 64-bit byte offset from slab 0's base pointer (`buf`), which is what the table-driven kernels take (ryolo_resize_hsv_batch /
-    ryolo_paste_rects: base + int64 offset; later slabs have offsets beyond — or below — slab 0).  With `budget_bytes` the pool holds at
-    most budget // slab slabs; when they are full the LEAST RECENTLY USED slab that the batch being assembled does not need is dropped as a
-    whole (its images leave the index) and refilled — LRU at slab granularity: no per-image free list, no fragmentation.  A dropped
-    image is decoded again when it is next asked for.  Reuse of a slab is ordered by the stream: the upload that overwrites it is enqueued
-    on the same stream as the kernels that read it before.
+    Memory is a list of SLABS (one torch uint8 tensor each); an image is bump-allocated into the current slab and addressed by its 64-bit
+    byte offset from a small anchor tensor (`buf`), which is what the table-driven kernels take (ryolo_resize_hsv_batch / ryolo_paste_rects:
+    base + int64 offset, positive or negative).  Without a budget slabs are 1 GiB.  With `budget_bytes` a slab holds ONE image by default
+    (`slab_bytes` = the image's size; a mosaic batch touches images all over the dataset, so coarser slabs would all be pinned by the batch
+    being assembled), the sum of slab sizes never exceeds the budget, and when room is needed the LEAST RECENTLY USED slabs that the current
+    batch does not need are dropped (their images leave the index; a dropped slab of sufficient size is reused in place, otherwise its memory
+    goes back to torch's caching allocator).  A dropped image is decoded again when it is next asked for.  Reuse is ordered by the stream:
+    the upload that overwrites a slab is enqueued on the same stream as the kernels that read it before.
 
     Host side: a decoded image is copied once into a PINNED staging tensor (torch's caching host allocator: the block is recycled only
     after the asynchronous copy that reads it has completed) and uploaded with a non-blocking copy; missing images of a batch are decoded
@@ -60,17 +61,15 @@ class ImagePool:
         self.count, self._decode, self.workers = int(count), decode, max(1, int(workers))
         self._shapes = {} if shapes is None else {i: tuple(s) for i, s in enumerate(shapes)}
         self.budget_bytes = None if budget_bytes is None else int(budget_bytes)
-        if slab_bytes is None:
+        if slab_bytes is None and images is not None:               # eager pools are small (tests, fixtures): one slab of their own size
+            slab_bytes = max(sum(((h * w * 3 + 15) // 16) * 16 for h, w in shapes), 16)
+        if slab_bytes is None and self.budget_bytes is None:
             slab_bytes = 1 << 30
-            if self.budget_bytes is not None:
-                slab_bytes = min(slab_bytes, max(self.budget_bytes // 4, 1 << 20))
-            if images is not None:                                  # eager pools are small (tests, fixtures): one slab of their own size
-                slab_bytes = max(sum(((h * w * 3 + 15) // 16) * 16 for h, w in shapes), 16)
-        self.slab_bytes = int(slab_bytes)
-        self.max_slabs = None if self.budget_bytes is None else max(1, self.budget_bytes // self.slab_bytes)
-        self._slabs, self._members, self._fill, self._touched = [], [], [], []     # per slab: tensor, image ids, bump pointer, LRU tick
+        self.slab_bytes = None if slab_bytes is None else int(slab_bytes)     # None (budgeted pools): one image per slab
+        self._anchor = None
+        self._slabs, self._members, self._fill, self._touched = [], [], [], []     # per slab: tensor (None: freed), image ids, bump pointer, LRU tick
         self._where = {}                                                            # image id -> (slab, offset inside the slab)
-        self._tick, self._cur = 0, -1
+        self._tick, self._cur, self._resident = 0, -1, 0
         self._executor = None
         self.stats = {"decoded": 0, "uploaded_bytes": 0, "evicted_slabs": 0, "hits": 0}
         if images is not None:
@@ -79,9 +78,9 @@ class ImagePool:
     # ---- what the kernels see
     @property
     def buf(self):
-        if not self._slabs:
-            self._new_slab()
-        return self._slabs[0]
+        if self._anchor is None:
+            self._anchor = torch.zeros(16, dtype=torch.uint8, device=self.device)
+        return self._anchor
 
     @property
     def shapes(self):
@@ -103,35 +102,38 @@ class ImagePool:
         return self._slabs[k].data_ptr() - self.buf.data_ptr() + off
 
     def resident_bytes(self):
-        return len(self._slabs) * self.slab_bytes
+        return self._resident
 
     # ---- residency
-    def _new_slab(self):
-        self._slabs.append(torch.empty(self.slab_bytes, dtype=torch.uint8, device=self.device))
+    def _slab_for(self, nbytes, pinned):
+        if self._cur >= 0 and self._slabs[self._cur] is not None and self._fill[self._cur] + nbytes <= self._slabs[self._cur].numel():
+            return self._cur
+        want = max(self.slab_bytes or 0, nbytes)
+        if self.budget_bytes is not None:
+            if want > self.budget_bytes:
+                raise RuntimeError(f"ImagePool: one image needs {want} bytes, the budget is {self.budget_bytes}")
+            while self._resident + want > self.budget_bytes:
+                victims = [k for k, t in enumerate(self._slabs) if t is not None and k not in pinned]
+                if not victims:
+                    raise RuntimeError(f"ImagePool: the images of ONE batch do not fit the budget ({self.budget_bytes} bytes, {self._resident} "
+                                       "held by this batch); raise pool_budget_bytes or lower the batch size")
+                k = min(victims, key=lambda v: self._touched[v])
+                for i in self._members[k]:
+                    del self._where[i]
+                self._members[k], self._fill[k] = [], 0
+                self.stats["evicted_slabs"] += 1
+                if self._slabs[k].numel() >= want:                  # reuse in place
+                    self._cur = k
+                    return k
+                self._resident -= self._slabs[k].numel()
+                self._slabs[k] = None                               # back to the caching allocator (stream-ordered reuse)
+        self._slabs.append(torch.empty(want, dtype=torch.uint8, device=self.device))
         self._members.append([])
         self._fill.append(0)
         self._touched.append(self._tick)
-        return len(self._slabs) - 1
-
-    def _slab_for(self, nbytes, pinned):
-        if nbytes > self.slab_bytes:
-            raise RuntimeError(f"ImagePool: one image needs {nbytes} bytes, a slab holds {self.slab_bytes} — raise slab_bytes / the budget")
-        if self._cur >= 0 and self._fill[self._cur] + nbytes <= self.slab_bytes:
-            return self._cur
-        if self.max_slabs is None or len(self._slabs) < self.max_slabs:
-            self._cur = self._new_slab()
-            return self._cur
-        victims = [k for k in range(len(self._slabs)) if k not in pinned]
-        if not victims:
-            raise RuntimeError(f"ImagePool: the images of ONE batch do not fit the budget ({self.budget_bytes} bytes = {self.max_slabs} slabs "
-                               f"of {self.slab_bytes}); raise budget_bytes or lower the batch size")
-        k = min(victims, key=lambda v: self._touched[v])
-        for i in self._members[k]:
-            del self._where[i]
-        self._members[k], self._fill[k] = [], 0
-        self.stats["evicted_slabs"] += 1
-        self._cur = k
-        return k
+        self._resident += want
+        self._cur = len(self._slabs) - 1
+        return self._cur
 
     def ensure(self, indices):
         """Make every image of `indices` resident (decode + upload the missing ones on the current stream); the slabs holding them are
@@ -336,7 +338,8 @@ def _to_device(arr, dev):
 
 def paste(src_buf, rects, ncanvas, CH, CW, fill=114):
     """rects: [(source byte offset, source row pitch in pixels, Placed, canvas index)] in paste order (later rectangles win) ->
-    canvases [ncanvas, CH, CW, 3] uint8, `fill` where nothing was pasted."""
+    canvases [ncanvas, CH, CW, 3] uint8, `fill` where nothing was pasted.  Rectangles listed canvas by canvas (what the batch assembler
+    produces) take the grouped entry point: a pixel then looks at its own canvas's rectangles only."""
     _check_layouts()
     live = [(off, pitch, r, cv) for off, pitch, r, cv in rects if r.w > 0 and r.h > 0]         # empty numpy slices paste nothing
     arr = (_Rect * max(len(live), 1))()
@@ -345,7 +348,13 @@ def paste(src_buf, rects, ncanvas, CH, CW, fill=114):
     dev = src_buf.device
     table = _to_device(arr, dev)
     canvas = torch.empty((ncanvas, CH, CW, 3), dtype=torch.uint8, device=dev)
-    hip.call("ryolo_paste_rects", hip.ptr(src_buf), hip.ptr(table), len(live), hip.ptr(canvas), ncanvas, CH, CW, fill, hip.stream())
+    cvs = [cv for _, _, _, cv in live]
+    if all(a <= b for a, b in zip(cvs, cvs[1:])) and (not cvs or (0 <= cvs[0] and cvs[-1] < ncanvas)):
+        first = np.searchsorted(np.asarray(cvs, dtype=np.int64), np.arange(ncanvas + 1)).astype(np.int32)
+        hip.call("ryolo_paste_rects_grouped", hip.ptr(src_buf), hip.ptr(table), len(live), hip.ptr(_to_device(first, dev)), hip.ptr(canvas), ncanvas, CH, CW,
+                 fill, hip.stream())
+    else:
+        hip.call("ryolo_paste_rects", hip.ptr(src_buf), hip.ptr(table), len(live), hip.ptr(canvas), ncanvas, CH, CW, fill, hip.stream())
     return canvas
 
 

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "ryolo_topk_desc": [_P, _I, _L, _I, _P, _P, _P, _P, _Z, _P],
     "ryolo_argsort_desc": [_P, _L, _P, _P, _Z, _P],
     "ryolo_paste_rects": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "ryolo_paste_rects_grouped": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "ryolo_paste_rect_bytes": [ctypes.POINTER(_I)],
     "ryolo_warp_perspective_u8": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     "ryolo_hsv_gain_u8": [_P, _L, _P, _P],

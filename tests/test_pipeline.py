@@ -105,73 +105,73 @@ def test_device_loader_iterates_batches(tmp_path):
 
 @pytest.mark.gpu
 def test_budgeted_pool_is_bit_equal_to_the_unbounded_pool(tmp_path):
-    """an ImagePool whose byte budget is SMALLER than the dataset (slabs dropped LRU, images decoded again on demand)
-    produces the same batches, bit for bit, as the pool that keeps everything — three epochs of mosaic / mixup batches."""
-    from ryolov4_amd.lib.load import load_data
+    """an ImagePool whose byte budget is SMALLER than the dataset (images dropped LRU, decoded again on demand) produces the
+    same batches, bit for bit, as the pool that keeps everything — two epochs of mosaic / mixup batches over 96 images, budget = 60 % of
+    their decoded size (one batch of 2 mosaic samples with mixup touches at most 36 of them)."""
+    from ryolov4_amd.datasets.DOTA_dataset import DOTADataset
     hyp = {k: float(v) for k, v in zip(HYP_KEYS, G["dota_mosaic_hyp"])}
-    base, images = _write_tree(tmp_path, "DOTA")
-    total = sum(int(np.prod(im.shape)) for im in images.values())
-    decodes = {"n": 0}
-
-    def imread(p):
-        decodes["n"] += 1
-        return images[p]
-
+    rs = np.random.RandomState(8)
+    n = 96
+    images = [rs.randint(0, 256, size=(rs.randint(16, 40), rs.randint(16, 40), 3)).astype(np.uint8) for _ in range(n)]
+    polys = [(rs.rand(3, 1, 2) * [im.shape[1], im.shape[0]] + (rs.rand(3, 4, 2) - 0.5) * 8).reshape(3, 8).astype(np.float32) for im in images]
+    labels = [rs.randint(0, 3, size=3).astype(np.float32) for _ in images]
+    total = sum(int(np.prod(im.shape)) for im in images)
     outs = {}
-    for name, kw in (("unbounded", {}), ("budget", dict(pool_budget_bytes=total // 2, pool_slab_bytes=total // 8))):
-        decodes["n"] = 0
-        ds, loader = load_data(base, CLASSES, "DOTA", hyp, False, img_size=32, batch_size=2, augment=True, shuffle=False, imread=imread,
-                               device="cuda:0", share_pool=False, **kw)
+    for name, kw in (("unbounded", {}), ("budget", dict(pool_budget_bytes=int(total * 0.6)))):
+        ds = DOTADataset(str(tmp_path), CLASSES, hyp, True, 32, False, device="cuda:0", decode_workers=1, **kw)
+        ds.set_arrays(images, polys, labels)
+        from ryolov4_amd.datasets.base_dataset import DeviceLoader
+        loader = DeviceLoader(ds, 2, False)
         random.seed(5)
         np.random.seed(5)
         got = []
-        for _ in range(3):
+        for _ in range(2):
             for paths, imgs, targets in loader:
                 got.append((imgs.cpu(), targets.cpu()))
-        outs[name] = (got, decodes["n"], ds.cache().stats, ds.cache().resident_bytes())
-    (a, na, sa, ra), (b, nb, sb, rb) = outs["unbounded"], outs["budget"]
-    assert len(a) == len(b) == 3 * ((NIMG + 1) // 2)
+        outs[name] = (got, dict(ds.cache().stats), ds.cache().resident_bytes())
+    (a, sa, ra), (b, sb, rb) = outs["unbounded"], outs["budget"]
+    assert len(a) == len(b) == 2 * (n // 2)
     for (ia, ta), (ib, tb) in zip(a, b):
         assert torch.equal(ia, ib) and torch.equal(ta, tb)
-    assert na == NIMG and sa["evicted_slabs"] == 0                       # everything decoded exactly once
-    assert rb <= total // 2 < total and sb["evicted_slabs"] > 0 and nb > NIMG     # the budget held, slabs were recycled, images re-decoded
+    assert sa["decoded"] <= n and sa["evicted_slabs"] == 0              # every image decoded (uploaded) at most once
+    assert rb <= int(total * 0.6) < total and sb["evicted_slabs"] > 0 and sb["decoded"] > n   # the budget held, images were dropped and decoded again
 
 
 @pytest.mark.gpu
 def test_pool_budget_too_small_for_one_batch_raises(tmp_path):
     from ryolov4_amd.datasets import augment as A
     images = [np.full((16, 16, 3), i, np.uint8) for i in range(8)]
-    pool = A.ImagePool(count=8, decode=images.__getitem__, device="cuda:0", budget_bytes=2048, slab_bytes=1024)
+    pool = A.ImagePool(count=8, decode=images.__getitem__, device="cuda:0", budget_bytes=2048)
     pool.ensure([0, 1])
     with pytest.raises(RuntimeError, match="do not fit the budget"):
         pool.ensure(range(8))
     with pytest.raises(RuntimeError, match="one image needs"):
-        A.ImagePool(count=1, decode=lambda i: np.zeros((64, 64, 3), np.uint8), device="cuda:0", budget_bytes=4096, slab_bytes=1024).ensure([0])
+        A.ImagePool(count=1, decode=lambda i: np.zeros((64, 64, 3), np.uint8), device="cuda:0", budget_bytes=4096).ensure([0])
 
 
 def test_pool_lru_bookkeeping_on_cpu():
-    """The pool's residency logic without a GPU (device 'cpu' tensors): LRU slab recycling, offsets relative to slab 0, re-decode."""
+    """The pool's residency logic without a GPU (device 'cpu' tensors): per-image LRU under a budget, offsets relative to the anchor, re-decode,
+    reuse of a dropped slab in place, explicit coarser slabs."""
     from ryolov4_amd.datasets import augment as A
     images = [np.full((8, 8, 3), i, np.uint8) for i in range(6)]          # 192 bytes each
     calls = []
-    pool = A.ImagePool(count=6, decode=lambda i: (calls.append(i), images[i])[1], device="cpu", budget_bytes=3 * 384, slab_bytes=384, workers=1)
-    pool.ensure([0, 1, 2, 3])                                             # two slabs
-    pool.ensure([4, 5])                                                   # third slab
-    assert pool.stats["evicted_slabs"] == 0 and len(pool._slabs) == 3
-    pool.ensure([0])                                                      # touch slab 0: slab 1 (images 2, 3) is now the LRU
-    pool.ensure([2])                                                      # missing? no — still resident
-    assert calls == [0, 1, 2, 3, 4, 5]
-    pool._touched[1] = 0                                                  # make slab 1 the oldest explicitly
-    pool._cur = 2
-    pool._fill[2] = 384
-    big = [np.full((8, 8, 3), 9, np.uint8)]
-    pool._decode = lambda i: big[0] if i == 99 else images[i]
-    pool.count = 100
-    pool.ensure([99])
-    assert pool.stats["evicted_slabs"] == 1 and 2 not in pool._where and 3 not in pool._where and 99 in pool._where
-    base = pool.buf.data_ptr()
-    k, off = pool._where[99]
-    assert pool.offset(99) == pool._slabs[k].data_ptr() - base + off
+    pool = A.ImagePool(count=6, decode=lambda i: (calls.append(i), images[i])[1], device="cpu", budget_bytes=4 * 192, workers=1)
+    pool.ensure([0, 1, 2, 3])
+    assert pool.resident_bytes() == 4 * 192 and pool.stats["evicted_slabs"] == 0
+    pool.ensure([0, 1])                                                   # touch: 2 and 3 are now the least recently used
+    pool.ensure([4, 5])                                                   # drops 2 and 3 (in place: same size)
+    assert pool.stats["evicted_slabs"] == 2 and sorted(pool._where) == [0, 1, 4, 5] and pool.resident_bytes() == 4 * 192
+    pool.ensure([2])                                                      # decoded again; the LRU of {0, 1, 4, 5} goes
+    assert calls == [0, 1, 2, 3, 4, 5, 2] and 2 in pool._where and len(pool._where) == 4
+    k, off = pool._where[2]
+    assert pool.offset(2) == pool._slabs[k].data_ptr() - pool.buf.data_ptr() + off
     flat = pool._slabs[k][off:off + 192]
-    assert int(flat.min()) == int(flat.max()) == 9
-    assert pool.shape(2) == (8, 8)                                        # shapes survive eviction
+    assert int(flat.min()) == int(flat.max()) == 2
+    assert pool.shape(3) == (8, 8)                                        # shapes survive eviction
+    with pytest.raises(RuntimeError, match="do not fit the budget"):
+        pool.ensure([0, 1, 2, 3, 4])
+    # explicit slabs of two images: dropped as a whole
+    pool2 = A.ImagePool(count=6, decode=images.__getitem__, device="cpu", budget_bytes=2 * 384, slab_bytes=384, workers=1)
+    pool2.ensure([0, 1, 2])
+    pool2.ensure([4, 5])                                                  # 4 fills the half-empty slab, 5 needs room: slab {0, 1} is the LRU
+    assert sorted(pool2._where) == [2, 4, 5] and pool2.stats["evicted_slabs"] == 1
