@@ -214,13 +214,15 @@ struct ResizeItem {
     int interp, lut;
 };
 
-__device__ __forceinline__ void hsv_lut_pixel(int& b, int& g, int& r, const uint8_t* __restrict__ lut)
+// divtab (optional, LDS): [0..255] = OpenCV's sdiv_table, [256..511] = hdiv_table180 — the two double-precision divisions per pixel as table
+// reads (what cv::cvtColor's 8-bit BGR2HSV does itself); same integers as the expressions below
+__device__ __forceinline__ void hsv_lut_pixel(int& b, int& g, int& r, const uint8_t* __restrict__ lut, const int* divtab = nullptr)
 {
     int v = max(b, max(g, r)), vmin = min(b, min(g, r));
     const int diff = v - vmin;
     const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    const int sdiv = v ? (int)rint((255 << 12) / (double)v) : 0;
-    const int hdiv = diff ? (int)rint((180 << 12) / (6.0 * diff)) : 0;
+    const int sdiv = divtab ? divtab[v] : (v ? (int)rint((255 << 12) / (double)v) : 0);
+    const int hdiv = divtab ? divtab[256 + diff] : (diff ? (int)rint((180 << 12) / (6.0 * diff)) : 0);
     const int s = (diff * sdiv + (1 << 11)) >> 12;
     int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
     h = (h * hdiv + (1 << 11)) >> 12;
@@ -277,6 +279,13 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
                                                                const uint8_t* __restrict__ luts, uint8_t* __restrict__ stage)
 {
     const ResizeItem it = items[blockIdx.y];
+    __shared__ int divtab[512];
+    if (it.lut >= 0) {                                              // (block-uniform)
+        const int t = threadIdx.x;
+        divtab[t] = t ? (int)rint((255 << 12) / (double)t) : 0;
+        divtab[256 + t] = t ? (int)rint((180 << 12) / (6.0 * t)) : 0;
+        __syncthreads();
+    }
     const int64_t npix = (int64_t)it.NH * it.NW;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const int y = (int)(i / it.NW), x = (int)(i - (int64_t)y * it.NW);
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
             if (ay.has_hi) row(ay.hi, ay.whi);
             for (int c = 0; c < 3; c++) px[c] = min(255, max(0, (int)rintf(acc[c])));
         }
-        if (it.lut >= 0) hsv_lut_pixel(px[0], px[1], px[2], luts + (int64_t)it.lut * 768);
+        if (it.lut >= 0) hsv_lut_pixel(px[0], px[1], px[2], luts + (int64_t)it.lut * 768, divtab);
         uint8_t* d = stage + it.dst_off + i * 3;
         d[0] = (uint8_t)px[0]; d[1] = (uint8_t)px[1]; d[2] = (uint8_t)px[2];
     }
