@@ -83,6 +83,8 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
     "conv_gemm_kernel<128x64>": _gemm_re(128, 64, "false"),
     "conv_gemm_kernel<256x64>": _gemm_re(256, 64),
     "conv_gemm_kernel<256x32>": _gemm_re(256, 32),
+    "gemm256_kernel<256x256>": r"gemm256_kernel<256, ",                                # 8-wave 256-wide pointwise GEMM for long reductions (gemm256.hip)
+    "gemm256_kernel<256x128>": r"gemm256_kernel<128, ",
     "gemm1x1_ws_kernel": r"gemm1x1_ws_kernel<",                                       # weight-stationary persistent 1x1 (gemm1x1.hip, RYOLO_GEMM_WS)
     "conv3x3_patch_kernel<256x128>": r"conv3x3_patch_kernel<128, 2, 2>",
     "conv3x3_patch_kernel<256x64>": r"conv3x3_patch_kernel<64, 4, 1>",

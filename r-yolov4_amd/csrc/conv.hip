@@ -1256,7 +1256,8 @@ static int gemm_check(const ConvGemmParams& p)
 // Which kernel ryolo_conv_gemm will run for these parameters and how many [2][Nout] partial-statistics rows its EPI_STATS
 // epilogue writes (= number of M tiles).  kernel: 0 generic implicit GEMM (conv.hip), 1 3x3 halo-patch kernel (conv3x3.hip,
 // selected by pipe bit 0x200 when the layer is eligible), 2 weight-stationary persistent 1x1 kernel (gemm1x1.hip; rows = waves),
-// 3 persistent weight-stationary 3x3 kernel for 64 -> <= 64 channels (conv3x3_ws.hip; rows = workgroups).
+// 3 persistent weight-stationary 3x3 kernel for 64 -> <= 64 channels (conv3x3_ws.hip; rows = workgroups), 4 the 256-wide pointwise GEMM for long
+// reductions (gemm256.hip; bits 16-19 = tile columns / 32).
 extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, int* kernel)
 {
     if (!pp || !stats_rows) return RY_ERR_ARG;
@@ -1272,6 +1273,12 @@ extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, i
     if ((p.pipe & 0x200) && p3_geometry(p, g)) {
         *stats_rows = (int)g.gm;
         if (kernel) *kernel = 1;
+        return RY_OK;
+    }
+    G256Geom g2;
+    if (g256_geometry(p, g2)) {                                     // 256-wide tiles for long-K pointwise layers (gemm256.hip): one statistics row per pixel tile
+        *stats_rows = (int)g2.gm;
+        if (kernel) *kernel = 4 | ((g2.BN / 32) << 16);
         return RY_OK;
     }
     Ws1Geom wg;
@@ -1307,6 +1314,8 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
     }
     if (p.pipe & 0xff) {
         if (!p.zeros) return RY_ERR_ARG;
+        G256Geom g2;
+        if (g256_geometry(p, g2)) return g256_launch(p, g2, stream);
         Ws1Geom wg;
         if (ws1_geometry(p, wg)) return ws1_launch(p, wg, stream);
         // 64-channel (full 128-byte line) stages: measured +1..5 % on 3x3 layers up to 256 channels, -4..-10 % on 1x1 / 512-channel

@@ -195,6 +195,15 @@ struct Ws3Geom {
 bool ws3_geometry(const ConvGemmParams& p, Ws3Geom& g);
 int ws3_launch(const ConvGemmParams& p, const Ws3Geom& g, hipStream_t stream);
 
+// ---- 256 x 256 (256 x 128) tiled pointwise GEMM for long reductions (gemm256.hip): 8 waves, 64-channel K steps, two 64-KiB LDS-DMA stages
+struct G256Geom {
+    int BN, gn;
+    int64_t gm;                // pixel tiles of 256 = partial-statistics rows of the EPI_STATS epilogue
+    unsigned lds_bytes;
+};
+bool g256_geometry(const ConvGemmParams& p, G256Geom& g);
+int g256_launch(const ConvGemmParams& p, const G256Geom& g, hipStream_t stream);
+
 // ---- 3x3 stride-1 weight gradient over a sliding halo ring (conv3x3.hip) ------------------------------------------------
 // K runs over PADDED pixel coordinates (image framed by one zero pixel on every side), so every tap is a constant row
 // offset into one ring of input rows and no per-element masks exist.

@@ -236,6 +236,8 @@ class Graph:
                 return ("gemm1x1_ws_kernel", fl, by)
             if fam == 3:
                 return ("conv3x3_ws64_kernel", fl, by)
+            if fam == 4:
+                return (f"gemm256_kernel<256x{((kv >> 16) & 15) * 32}>", fl, by, "K<=256" if p.Cin <= 256 else "K>256")
             # the generic kernel's instantiations as rocprofv3 lists them: tile shape, and the 1x1 form (no tap table / tile decomposition)
             kind = f"conv_gemm_kernel<{((kv >> 12) & 15) * 64}x{((kv >> 16) & 15) * 32}{',1x1' if kv & 0x100 else ''}>"
             if kv & 0x100:
