@@ -95,7 +95,7 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
 }
 
 
-PMC_PROFILE = "profiles/r03_pmc_step_traffic.json"        # regenerated by tools/pmc_step.sh whenever a kernel of the step changes
+PMC_PROFILE = "profiles/r04_pmc_step_traffic.json"        # regenerated by tools/pmc_step.sh whenever a kernel of the step changes
 
 
 def source_sha256():
@@ -460,6 +460,8 @@ def main():
         k33 = "conv3x3_patch_kernel<256x128>"
         if k33 in summ:
             res["roofline_3x3"] = roof(k33, summ[k33])
+        if "conv3x3_ws64_kernel" in summ:                       # the 64 -> 64 channel 3x3 layers on the persistent weight-stationary kernel (r04)
+            res["roofline_3x3_ws64"] = roof("conv3x3_ws64_kernel", summ["conv3x3_ws64_kernel"])
         # ... and all 3x3 stride-1 work together (patch kernels fwd + dgrad, ring weight gradient): FLOP-weighted
         k3 = [k for k in summ if k.startswith("conv3x3_")]
         if k3:

@@ -158,7 +158,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned soff = (k & 1) ? STAGE : 0u;
         g256_wait_vm<0>();                                      // my pieces of step k (requested a whole step ago) have landed ...
         __builtin_amdgcn_s_barrier();                           // ... everyone's have, and everyone is done with step k - 1
-        if (k + 1 < nk) issue_stage(k + 1, (k & 1) ? 0u : STAGE);
         unsigned sb = lbase + soff;
         asm volatile("" : "+v"(sb));                            // (opaque: keeps the 4 x NF fragment addresses of a step out of loop-invariant registers)
         bf16x8 fr[2][NF];
@@ -168,7 +167,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < TN; j++) f[4 + j] = g256_rd128(sb + (wa[j] ^ (unsigned)(ks << 5)));
         };
-        rd_set(0, fr[0]);
+        rd_set(0, fr[0]);                                       // first fragments requested BEFORE the next stage's DMA is issued: their LDS latency
+        __builtin_amdgcn_sched_barrier(0);                      // runs under the ~70 address / M0 / DMA instructions below
+        if (k + 1 < nk) issue_stage(k + 1, (k & 1) ? 0u : STAGE);
         auto sub = [&](auto kc) {
             constexpr int ks = decltype(kc)::value;
             __builtin_amdgcn_sched_barrier(0);

@@ -1,19 +1,19 @@
-# End-of-round evidence on ONE GPU box (run from the repo root through gpurun; round 3): PMC step traffic, default bench line, rocprofv3 kernel
-# stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/r03m/
+# End-of-round evidence on ONE GPU box (run from the repo root through gpurun; round 4): PMC step traffic, default bench line, rocprofv3 kernel
+# stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/r04m/
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03m
+O=$R/gpurun_out/r04m
 mkdir -p $O
 cd $R
 # 1. PMC traffic of the step (then the bench line reads it)
-timeout 1500 bash tools/pmc_step.sh r03 > $O/pmc_step.txt 2>&1
-cp gpurun_out/r03_pmc_step_traffic.json profiles/r03_pmc_step_traffic.json
+timeout 1500 bash tools/pmc_step.sh r04 > $O/pmc_step.txt 2>&1
+cp gpurun_out/r04_pmc_step_traffic.json profiles/r04_pmc_step_traffic.json
 # 2. default bench line
 ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
 # 3. rocprofv3 kernel stats, serialized streams, b64 and b8
 cd /tmp; export TMPDIR=/tmp
-RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64 -o run -- python $R/bench.py --no-cpu-baseline --no-b8 --steps 8 > $O/prof_b64.json 2> $O/prof_b64.err
-RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b8 -o run -- python $R/bench.py --no-cpu-baseline --no-b8 --batch 8 --steps 20 > $O/prof_b8.json 2> $O/prof_b8.err
+RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b64 -o run -- python $R/bench.py --no-cpu-baseline --no-loader --no-b8 --steps 8 > $O/prof_b64.json 2> $O/prof_b64.err
+RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b8 -o run -- python $R/bench.py --no-cpu-baseline --no-loader --no-b8 --batch 8 --steps 20 > $O/prof_b8.json 2> $O/prof_b8.err
 cd $R
 # 4. per-launch tables
 B=64 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b64.txt 2>&1
@@ -25,8 +25,8 @@ timeout 600 python tools/bench_infer.py > $O/infer.txt 2>&1; cp gpurun_out/infer
 # that >= 50 k candidates per image reach the top-K / NMS stage
 B=8 SZ=1024 CONF=0.0005 IOU=0.65 timeout 600 python tools/bench_infer.py > $O/infer_1024.txt 2>&1; cp gpurun_out/infer.json $O/infer_1024_b8.json
 # 6. other configs + batch sweep
-for cfg in "yolov4 kfiou 608 2" "yolov7 csl 800 16" "yolov5 kfiou 800 16"; do set -- $cfg; timeout 300 python bench.py --ver $1 --mode $2 --size $3 --nc $4 --no-cpu-baseline --no-b8 --steps 8 > $O/cfg_$1_$2.json 2> $O/cfg_$1_$2.err; done
-for b in 96 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-b8 --no-kernel-timing --steps 8 > $O/batch$b.json 2> $O/batch$b.err; done
+for cfg in "yolov4 kfiou 608 2" "yolov7 csl 800 16" "yolov5 kfiou 800 16"; do set -- $cfg; timeout 300 python bench.py --ver $1 --mode $2 --size $3 --nc $4 --no-cpu-baseline --no-loader --no-b8 --steps 8 > $O/cfg_$1_$2.json 2> $O/cfg_$1_$2.err; done
+for b in 96 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-loader --no-b8 --no-kernel-timing --steps 8 > $O/batch$b.json 2> $O/batch$b.err; done
 # 7. overfit curves
 timeout 600 python tools/overfit_curve.py kfiou 300 > $O/overfit_kfiou.json 2> $O/overfit_kfiou.err
 timeout 600 python tools/overfit_curve.py csl 300 > $O/overfit_csl.json 2> $O/overfit_csl.err
@@ -35,7 +35,8 @@ timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --mast
 BACKEND=nccl timeout 600 python tools/dp_check.py > $O/dp_check_rccl1.txt 2>&1
 # 9. loader feed rate, mAP parity (600 steps), GPU test suite
 timeout 600 python tools/bench_pipeline.py > $O/pipeline.txt 2>&1; cp gpurun_out/pipeline.json $O/pipeline.json
-timeout 1200 python tools/map_parity.py 600 yolov7 kfiou > $O/map_parity.txt 2>&1; cp gpurun_out/r03_map_parity.json $O/map_parity.json
+timeout 300 python tools/bench_loader.py 64 800 10 > $O/loader_diag.txt 2>&1; cp gpurun_out/loader_diag.json $O/loader_diag.json
+# (mAP parity at 512 images / 16 classes / 3 seeds: tools/map_parity.py, 10 min of mostly CPU oracle time — run once per round, not here)
 timeout 1800 python -m pytest tests -m gpu -q --durations=10 > $O/gpu_test_suite.txt 2>&1; tail -n 3 $O/gpu_test_suite.txt
 ls -la $O
 tail -n 3 $O/pmc_step.txt; cat $O/bench_time.txt; tail -n 2 $O/dp_check_gloo2.txt; tail -n 2 $O/dp_check_rccl1.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the end-of-round evidence of tools/collect_evidence.sh (gpurun_out/<tag>m/, merged back by gpurun) into profiles/ under round names.
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/${TAG}m
 P=profiles
 last() { tail -n 1 "$1"; }
@@ -26,8 +26,10 @@ cp $O/overfit_kfiou.json $P/${TAG}_overfit_yolov7_kfiou_b64_800.json
 cp $O/overfit_csl.json $P/${TAG}_overfit_yolov7_csl_b64_800.json
 ( echo "== 2 ranks, gloo, one shared GPU (tools/dp_check.py) =="; cat $O/dp_check_gloo2.txt; echo; echo "== 1 rank, RCCL (BACKEND=nccl tools/dp_check.py) =="; cat $O/dp_check_rccl1.txt ) > $P/${TAG}_dp_check.txt
 cp $O/gpu_test_suite.txt $P/${TAG}_gpu_test_suite.txt
-cp $O/map_parity.json $P/${TAG}_map_parity.json
+[ -f gpurun_out/${TAG}_map_parity.json ] && cp gpurun_out/${TAG}_map_parity.json $P/${TAG}_map_parity.json
+cp $O/loader_diag.json $P/${TAG}_loader_in_the_loop.json
+[ -f gpurun_out/${TAG}_iou_fuzz.json ] && cp gpurun_out/${TAG}_iou_fuzz.json $P/${TAG}_iou_fuzz.json
 cp $O/pipeline.json $P/${TAG}_pipeline_feed_rate.json
-for f in teacher_forced trajectory; do [ -f gpurun_out/${TAG}_$f.json ] && cp gpurun_out/${TAG}_$f.json $P/${TAG}_$f.json; done
+for f in teacher_forced trajectory; do [ -f gpurun_out/r03_$f.json ] && cp gpurun_out/r03_$f.json $P/${TAG}_$f.json; done
 [ -f gpurun_out/r02_parity_e2e.json ] && cp gpurun_out/r02_parity_e2e.json $P/${TAG}_parity_e2e.json
 ls -la $P | grep ${TAG}_
