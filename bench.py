@@ -393,7 +393,7 @@ def main():
             polys.append((c[:, None, :] + d).reshape(nobj, 8).astype(np.float32))
             labels.append(rs.randint(0, args.nc, size=nobj).astype(np.float32))
         total = npool * side * side * 3
-        kw = {} if budget_frac is None else dict(pool_budget_bytes=int(total * budget_frac), pool_slab_bytes=int(total * budget_frac) // 8)
+        kw = {} if budget_frac is None else dict(pool_budget_bytes=int(total * budget_frac))        # (one image per slab: per-image LRU)
         ds = BaseDataset(hyp, args.size, True, args.mode == "csl", False, device=dev, decode_workers=8, **kw)
         ds.set_arrays(images, polys, labels)
         loader = DeviceLoader(ds, batch, shuffle=True)
@@ -472,7 +472,14 @@ def main():
         # the pointwise class by regime: K <= 256 layers are memory streams (HBM roof), K > 256 layers sit on the MFMA side
         split = m["timer"].summary(by_sub=True)
         if split:
-            res["roofline_1x1_split"] = {sub: roof(f"{k} [{sub}]", v) for (k, sub), v in sorted(split.items(), key=lambda kv: kv[0][1])}
+            groups = {}
+            for (k, sub), v in split.items():                       # a regime may be served by several kernels (generic 1x1 instantiation, gemm256)
+                gsub = groups.setdefault(sub, {"seconds": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0, "kernels": {}})
+                for f in ("seconds", "flops", "launches", "bytes"):
+                    gsub[f] += v[f]
+                gsub["kernels"][k] = {"launches_per_step": v["launches"] // steps, "ms_per_step": round(v["seconds"] / steps * 1e3, 3),
+                                      "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)}
+            res["roofline_1x1_split"] = {sub: dict(roof(f"pointwise layers, {sub}", gsub), kernels=gsub["kernels"]) for sub, gsub in sorted(groups.items())}
         res["kernels"] = {kk: {"tflops": round(vv["flops"] / vv["seconds"] / 1e12, 2), "ms_per_step": round(vv["seconds"] / steps * 1e3, 3),
                                "launches_per_step": vv["launches"] // steps} for kk, vv in summ.items()}
         return res

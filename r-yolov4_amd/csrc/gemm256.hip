@@ -327,7 +327,9 @@ bool g256_geometry(const ConvGemmParams& p, G256Geom& g)
     if (g256_mode() < 2) {
         // long reductions only (short-K pointwise layers are memory streams the generic kernel already runs at 4.3 - 5.2 TB/s), and grids of at
         // least ~2.4 rounds of one workgroup per CU (a 256-wide tile on a 1.2-round grid idles half the chip in its second round)
-        if (p.Cin < 512 || g.gm * g.gn < 600) return false;
+        // (and 256-column tiles only: the 256 x 128 form measured 443 TF/s on 512 -> 128 @100^2 against 487 on the generic kernel — half the MFMAs
+        // per barrier for the same pixel stream; it stays reachable with RYOLO_GEMM_256=2 for the tests)
+        if (p.Cin < 512 || g.gm * g.gn < 600 || g.BN != 256) return false;
     }
     g.lds_bytes = 2u * (256u + (unsigned)g.BN) * 128u;
     return true;

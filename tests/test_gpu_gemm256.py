@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_default_dispatch_takes_the_long_k_layers(epi):
     from tests.gemm256_cases import _run
     _run(64 * 50 * 50, 512, 512, epi=epi, ld_extra=64 if epi else 0, seed=epi)          # 512 -> 512 @50^2, batch 64: 1250 tiles
-    _run(64 * 50 * 50, 1024, 128, epi=epi, seed=3 + epi)                                  # 256 x 128 tiles: 625 of them
+    _run(64 * 50 * 50, 1024, 128, epi=epi, seed=3 + epi, expect=0)                        # <= 128 columns: generic kernel by default (256 x 128 tiles only forced)
+    _run(64 * 50 * 50, 1024, 256, epi=epi, seed=9 + epi)                                  # 625 tiles of 256 x 256
     _run(64 * 25 * 25, 2048, 512, epi=epi, seed=6 + epi, expect=0)         # 314 tiles: stays on the generic kernel
 
 
