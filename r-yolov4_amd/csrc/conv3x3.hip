@@ -22,6 +22,7 @@
 //   * epilogues as in conv.hip: raw bf16, training BatchNorm statistics, folded BN + activation (inference), accumulate.
 #include "conv_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define P3_BM 256
 
@@ -31,6 +32,17 @@ template <int K> __device__ __forceinline__ void wait_vm()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
 }
+
+template <int U, int N> struct P3Unroll {
+    template <class F> static __device__ __forceinline__ void run(F& f)
+    {
+        f(std::integral_constant<int, U>{});
+        P3Unroll<U + 1, N>::run(f);
+    }
+};
+template <int N> struct P3Unroll<N, N> {
+    template <class F> static __device__ __forceinline__ void run(F&) {}
+};
 
 template <int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmParams p, const P3Geom g)
@@ -55,7 +67,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     const unsigned patch_bytes = (unsigned)g.P * 1024u;
     const unsigned wring_off = 2u * patch_bytes;
     const unsigned zrow_off = wring_off + 3u * WSLOT;
-    int* const tab = reinterpret_cast<int*>(p3_lds + zrow_off + 64);
 
     // ---- tile origin --------------------------------------------------------------------------------------------------
     int img0 = 0, oh0 = 0, ow0 = 0;
@@ -71,7 +82,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     }
 
     // ---- patch DMA sources -> LDS table ptab[u][tid]: piece (wave + 4u) = patch rows 16*piece ... +15, lane -> (row, slot) ---------
-    // (element offset / 8 into A; ~0u -> zero page).  Kept in LDS, not in 9 VGPRs: the main loop stays rolled and lean.
+    // (element offset / 8 into A; ~0u -> zero page).  Kept in LDS, not in 9 VGPRs; the FIRST chunk's pieces are requested here, entry by
+    // entry, so that the HBM round trip of the patch runs under the rest of the prologue (the address tables below are pure VALU work).
     unsigned* const ptab = reinterpret_cast<unsigned*>(p3_lds + zrow_off + 128);
     // output pixel of tile row m (-1: dead row), one entry per thread: the store loop of the epilogue reads it back instead of redoing the
     // tile -> image index arithmetic for each of its 16 rows per lane (35 VALU instructions per row, a quarter of the store loop)
@@ -105,27 +117,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
             ok = ok && pix >= 0 && pix < M;
         }
         const int sl = (lane & 3) ^ ((j >> 2) & 3);
-        ptab[u * 256 + tid] = ok ? (unsigned)((pix * p.ldA + sl * 8) >> 3) : 0xffffffffu;
+        const unsigned ofs = ok ? (unsigned)((pix * p.ldA + sl * 8) >> 3) : 0xffffffffu;
+        ptab[u * 256 + tid] = ofs;
+        const bf16_t* src = ofs != 0xffffffffu ? p.A + ((int64_t)ofs << 3) : p.zeros;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + pc * 1024), 16, 0, 0);
     }
-    // ---- weight DMA sources --------------------------------------------------------------------------------------------
+    // ---- weight DMA sources; steps 0 and 1 requested now ----------------------------------------------------------------------
     unsigned b_ofs[NPB];                                        // element offset into W (< 2^31: checked on the host), ~0u -> zero page
 #pragma unroll
     for (int u = 0; u < NPB; u++) {
         const int r = (wave + 4 * u) * 16 + (lane >> 2);
         b_ofs[u] = (n0 + r) < p.Nout ? (unsigned)((int64_t)(n0 + r) * p.wtaps * p.Cin + ((lane & 3) ^ ((r >> 2) & 3)) * 8) : 0xffffffffu;
     }
-    // ---- per-tap scalars through LDS (a VMEM kernarg byte load inside the loop would drain vmcnt) + the zero row ----------
-    // (all 27 kernarg dwords are requested before the first LDS write: scalar loads and LDS writes share the lgkmcnt counter, and
-    // "load tap t, write tap t" in one loop made every tap wait for its own kernarg round trip — see conv.hip)
-    int tapv[9];
+    auto issue_w = [&](int w_off, unsigned dst) {
 #pragma unroll
-    for (int t = 0; t < 9; t++) tapv[t] = ((g.tdh[t] + 1) * g.PW + (g.tdw[t] + 1)) | (g.twi[t] << 16);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-        if (tid == t) tab[t] = tapv[t];
-    if (tid >= 64 && tid < 80) reinterpret_cast<unsigned*>(p3_lds + zrow_off)[tid - 64] = 0u;
-    // ---- A fragment rows: patch row of output pixel m (tap (−1,−1)) and the 9-bit validity mask -----------------------------
+        for (int u = 0; u < NPB; u++) {
+            const bf16_t* src = b_ofs[u] != 0xffffffffu ? p.W + b_ofs[u] + w_off : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + dst + (wave + 4 * u) * 1024), 16, 0, 0);
+        }
+    };
+    issue_w(g.twi[0] * p.Cin, wring_off);
+    issue_w(g.twi[1] * p.Cin, wring_off + WSLOT);
+    // ---- A fragment addresses.  atab[i][t]: byte offset INSIDE a patch buffer of the 16-byte fragment piece (16-channel half 0; half 1: ^ 32)
+    // that output pixel (i, lane & 31) reads for tap t — patch row base(m) + (dh+1)*PW + (dw+1), bank swizzle applied; a tap that falls on
+    // padding (or, for flat runs, wraps into the neighbouring row / image) points at the buffer's LAST row instead, which every chunk's DMA
+    // fills from the zero page (the host sizes P so that 16 P > R).  36 registers, computed once: a tap step starts with its LDS reads — the
+    // round-3 loop recomputed these addresses behind the barrier of every step (tap scalar from LDS -> wait -> 24 VALU -> first read).
     int run_oh = 0, run_ow = 0;
     const float rH = 1.0f / (float)H;
     if (g.mode != 1) {
@@ -133,23 +150,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
         run_oh = rem / W;
         run_ow = rem - run_oh * W;
     }
-    int abase[TM];
-    unsigned amask[TM];
+    const unsigned zrel = (unsigned)(g.P * 16 - 1) << 6;
+    // tap scalars first, all of them (kernarg dwords: one batch of s_loads, one wait — read inside the loops below they came back one at a time,
+    // 41 waits of a scalar-memory round trip each in the first cut of this table)
+    int toff[9], tbit[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        toff[t] = (g.tdh[t] + 1) * g.PW + (g.tdw[t] + 1);
+        tbit[t] = (g.tdh[t] + 1) * 3 + (g.tdw[t] + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned atab[TM][9];
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int mrow = wm * WTM + i * 32 + (lane & 31);
         bool live;
-        int oh, ow;
+        int oh, ow, abase;
         if (g.mode == 1) {
             const int r = small_div(mrow, g.TW, g.rTW), c = mrow - r * g.TW;
             live = mrow < g.TH * g.TW;
             oh = oh0 + r;
             ow = ow0 + c;
-            abase[i] = live ? r * g.PW + c : 0;
+            abase = live ? r * g.PW + c : 0;
         } else {
             const int64_t pp = p0 + mrow;
             live = pp < M;
-            // (oh, ow) of a flat pixel index: the run starts at (roh, row_) — computed once per workgroup with scalar math below
+            // (oh, ow) of a flat pixel index: the run starts at (run_oh, run_ow) — computed once per workgroup with scalar math above
             int o = run_ow + mrow, orow = run_oh;
             const int wraps = small_div(o, W, g.rPW);               // PW == W for flat runs
             o -= wraps * W;
@@ -157,17 +183,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
             orow -= small_div(orow, H, rH) * H;                      // next image(s): row index modulo H
             oh = orow;
             ow = o;
-            abase[i] = mrow;
+            abase = mrow;
         }
-        // tap t reads input (oh + dh, ow + dw): 3 row bits x 3 column bits, combined per tap from scalar (dh, dw)
-        const unsigned rowok = ((oh >= 1) ? 1u : 0u) | 2u | ((oh + 1 < H) ? 4u : 0u);
+        // tap (dh, dw) reads input (oh + dh, ow + dw): bit 3*(dh+1) + (dw+1) of m9 says whether that pixel exists (branch-free selects below:
+        // hipcc turned `ok ? address : zero row` into 36 divergent branches)
         const unsigned colok = ((ow >= 1) ? 1u : 0u) | 2u | ((ow + 1 < W) ? 4u : 0u);
-        unsigned vm = 0;
+        unsigned m9 = (colok << 3) | ((oh >= 1) ? colok : 0u) | ((oh + 1 < H) ? (colok << 6) : 0u);
+        if (!live) m9 = 0u;
 #pragma unroll
-        for (int t = 0; t < 9; t++)
-            vm |= ((rowok >> (g.tdh[t] + 1)) & (colok >> (g.tdw[t] + 1)) & 1u) << t;
-        if (!live) vm = 0;
-        amask[i] = vm;
+        for (int t = 0; t < 9; t++) {
+            const unsigned keep = 0u - ((m9 >> tbit[t]) & 1u);          // all ones / zero
+            const unsigned prow = (unsigned)(abase + toff[t]);
+            const unsigned a = (prow << 6) | ((((prow >> 2) & 3u) ^ (unsigned)h) << 4);
+            atab[i][t] = (a & keep) | (zrel & ~keep);
+        }
     }
     unsigned fb[TN];                                            // B fragment byte offset inside a ring slot for ks = 0 (ks = 1: ^ 32)
 #pragma unroll
@@ -175,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
         const int r = wn * WTN + j * 32 + (lane & 31);
         fb[j] = (unsigned)(r * 64 + ((h ^ ((r >> 2) & 3)) << 4));
     }
-    __syncthreads();
+    // (no workgroup barrier here: ptab is read back by the thread that wrote it, rowpix only in the epilogue, and a __syncthreads would drain
+    // the prologue's DMA — the first tap step waits for exactly what it needs)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -187,100 +217,100 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 
     const int cchunks = p.Cin >> 5;
     const int nsteps = cchunks * 9;
-    auto issue_patch = [&](int u, int cc, unsigned buf_off) {
-        const unsigned ofs = ptab[u * 256 + tid];
-        const int pc = min(wave + 4 * u, g.P - 1);
-        const bf16_t* src = ofs != 0xffffffffu ? p.A + ((int64_t)ofs << 3) + cc * 32 : p.zeros;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + buf_off + pc * 1024), 16, 0, 0);
-    };
-    auto issue_w = [&](int t, int cc, int slot) {
-        const int wi = __builtin_amdgcn_readfirstlane(tab[t]) >> 16;
-        const int off = wi * p.Cin + cc * 32;
-#pragma unroll
-        for (int u = 0; u < NPB; u++) {
-            const bf16_t* src = b_ofs[u] != 0xffffffffu ? p.W + b_ofs[u] + off : p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + wring_off + slot * WSLOT + (wave + 4 * u) * 1024), 16, 0, 0);
-        }
-    };
-    // prologue: the whole patch of chunk 0, weights of steps 0 and 1
-    for (int u = 0; u < g.TP; u++) issue_patch(u, 0, 0u);
-    issue_w(0, 0, 0);
-    issue_w(1, 0, 1);
-
 #ifdef P3_TIMING
     const unsigned long long T1 = __builtin_readcyclecounter();
 #endif
+    // Fragments of the COMING step that may be read before its barrier: its weights landed one barrier earlier (see the waits below) and
+    // the patch of a chunk is complete two steps before the chunk starts (TP <= 7), so a step begins with its first MFMAs' operands already in
+    // flight instead of barrier -> ds_read -> LDS latency -> first MFMA.
+    constexpr int PF = 2;
+    bf16x8 bnext[TN], anext[PF];
+    auto pre_issue = [&](auto tcst, unsigned buf) {
+        constexpr int t = decltype(tcst)::value;
+#pragma unroll
+        for (int j = 0; j < TN; j++) bnext[j] = *reinterpret_cast<const bf16x8*>(p3_lds + wring_off + (t % 3) * WSLOT + fb[j]);
+#pragma unroll
+        for (int u = 0; u < PF; u++) anext[u] = *reinterpret_cast<const bf16x8*>(p3_lds + (atab[u][t] + buf));
+    };
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                              // chunk 0 of the patch, weights of steps 0 and 1: landed, visible
+    pre_issue(std::integral_constant<int, 0>{}, 0u);
     int s = 0;
     for (int cc = 0; cc < cchunks; cc++) {
         const bool more = cc + 1 < cchunks;
         const unsigned pbuf = (cc & 1) ? patch_bytes : 0u;
         const unsigned nbuf = (cc & 1) ? 0u : patch_bytes;
-        int slot = 0;                                          // ring slot of step (cc, t) = t % 3 (9 taps per chunk)
-        for (int t = 0; t < 9; t++, s++) {
-            // DMA instructions this wave issued AFTER the ones step s depends on may stay in flight:
-            //   step s-1 issued [its patch piece (if any)] + [weights of step s+1]; a new chunk (t == 0) needs every patch piece
+        // the 9 tap steps of a chunk are unrolled by hand (template recursion): tap index, ring slot and the atab column are compile-time
+        auto step = [&](auto tcst) {
+            constexpr int t = decltype(tcst)::value;
+            constexpr int slot = t % 3;                        // ring slot of step (cc, t) (9 taps per chunk)
+            // Barrier of step s.  Behind it: (a) every wave's DMA pieces of step s+1's weights have landed (each wave waits for its own:
+            // they were requested in the FIRST units of step s-1, a step ago), so step s+1's fragments may be read any time after this
+            // barrier; (b) every wave has finished reading step s-1's ring slot, which this step's weight requests overwrite.
+            // The patch piece of step s-1 — requested last, streamed from HBM — may stay in flight (vmcnt counts in order).
             const bool prev_piece = t != 0 && (t - 1) < g.TP && more;
-            if (s + 1 >= nsteps) wait_vm<0>();
-            else if (prev_piece) wait_vm<NPB + 1>();
-            else wait_vm<NPB>();
-            __builtin_amdgcn_s_barrier();               // step s operands visible to every wave; step s-1 fully consumed
+            if (prev_piece) wait_vm<1>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
             const bool do_patch = more && t < g.TP;
             const bool do_w = s + 2 < nsteps;
-            const int t2 = t + 2 >= 9 ? t - 7 : t + 2;
-            const int w_off = (__builtin_amdgcn_readfirstlane(tab[t2]) >> 16) * p.Cin + (cc + (t + 2 >= 9 ? 1 : 0)) * 32;
-            const unsigned w_dst = wring_off + (slot == 0 ? 2 : slot - 1) * WSLOT;       // slot of step s + 2
-            const int toff = __builtin_amdgcn_readfirstlane(tab[t]) & 0xffff;
-            unsigned aaddr[TM];
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const unsigned prow = (unsigned)(abase[i] + toff);
-                const unsigned a = pbuf + (prow << 6) + ((((prow >> 2) & 3u) ^ (unsigned)h) << 4);
-                aaddr[i] = (amask[i] >> t) & 1u ? a : zrow_off;
-            }
+            constexpr int t2 = (t + 2) % 9;
+            const int w_off = g.twi[t2] * p.Cin + (cc + (t + 2 >= 9 ? 1 : 0)) * 32;
+            const unsigned w_dst = wring_off + ((slot + 2) % 3) * WSLOT;                  // slot of step s + 2
             const unsigned wb = wring_off + slot * WSLOT;
+            // this step's patch piece: its source offset is read together with the first fragments (one lgkmcnt wait covers both)
+            const int pu = min(t, g.TP - 1);
+            const unsigned pofs = ptab[pu * 256 + tid];
+            const int ppc = min(wave + 4 * pu, g.P - 1);
             // Software pipeline over the 2*TM "units" (16-channel half ks, A fragment i): the A fragment of unit u+PF is read while
             // unit u's TN MFMAs run; B fragments of a half are read one unit before its first use.  (All-reads-first exposes the
             // LDS latency once per step; hipcc's own schedule funnels every A fragment through one register quad and waits on each.)
-            // The step's DMA instructions (1 patch piece + NPB weight pieces per wave) are spread between the units: an LDS-DMA
+            // The step's DMA instructions (NPB weight pieces, then 1 patch piece per wave) follow the first units: an LDS-DMA
             // issue costs 100-185 cycles next to ds_reads but hides in the shadow of the matrix pipe (guide's price table).
             // Operands are swapped (A = weights, B = pixels): the accumulator holds the TRANSPOSED tile, so a lane owns 4
             // consecutive channels of one pixel — 8-byte packed stores in the epilogue.
-            constexpr int NU = 2 * TM, PF = 2, NIT = NPB + 1;
+            constexpr int NU = 2 * TM, NIT = NPB + 1;
+            static_assert(NU >= NIT + 1 && NU - 2 >= TM, "DMA items and the pre-issue point fit in the unit sequence");
             bf16x8 af[NU], bfr[2][TN];
-            auto read_a = [&](int u) { return *reinterpret_cast<const bf16x8*>(p3_lds + (aaddr[u % TM] ^ (unsigned)((u / TM) << 5))); };
-            auto read_b = [&](int ks) {
+            auto read_a = [&](int u) { return *reinterpret_cast<const bf16x8*>(p3_lds + ((atab[u % TM][t] ^ (unsigned)((u / TM) << 5)) + pbuf)); };
 #pragma unroll
-                for (int j = 0; j < TN; j++) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(p3_lds + wb + (fb[j] ^ (unsigned)(ks << 5)));
-            };
-            read_b(0);
+            for (int j = 0; j < TN; j++) bfr[0][j] = bnext[j];
 #pragma unroll
-            for (int u = 0; u < PF; u++) af[u] = read_a(u);
+            for (int u = 0; u < PF; u++) af[u] = anext[u];
 #pragma unroll
             for (int u = 0; u < NU; u++) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (u + PF == TM) read_b(1);                              // one unit before the second half starts... (PF units ahead)
+                if (u + PF == TM) {
+#pragma unroll
+                    for (int j = 0; j < TN; j++) bfr[1][j] = *reinterpret_cast<const bf16x8*>(p3_lds + wb + (fb[j] ^ 32u));
+                }
                 if (u + PF < NU) af[u + PF] = read_a(u + PF);
+                if (u == NU - 2) {                                       // bfr[0], af[0], af[1] are dead: the coming step's first fragments
+                    if constexpr (t + 1 < 9) pre_issue(std::integral_constant<int, t + 1>{}, pbuf);
+                    else pre_issue(std::integral_constant<int, 0>{}, nbuf);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < TN; j++)
                     acc[u % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u / TM][j], af[u], acc[u % TM][j], 0, 0, 0);
-                // DMA item k after unit (k + 1) * NU / (NIT + 1) - 1
-#pragma unroll
-                for (int item = 0; item < NIT; item++)
-                    if (u == (item + 1) * NU / (NIT + 1) - 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (item == 0) {
-                            if (do_patch) issue_patch(t, cc + 1, nbuf);
-                        } else if (do_w) {
-                            const int uu = item - 1;
-                            const bf16_t* src = b_ofs[uu] != 0xffffffffu ? p.W + b_ofs[uu] + w_off : p.zeros;
-                            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + w_dst + (wave + 4 * uu) * 1024), 16, 0, 0);
+                // DMA item k after unit k: weights first, the patch piece last
+                if (u < NIT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u < NPB) {
+                        if (do_w) {
+                            const bf16_t* src = b_ofs[u] != 0xffffffffu ? p.W + b_ofs[u] + w_off : p.zeros;
+                            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + w_dst + (wave + 4 * u) * 1024), 16, 0, 0);
                         }
+                    } else if (do_patch) {
+                        const bf16_t* src = pofs != 0xffffffffu ? p.A + ((int64_t)pofs << 3) + (cc + 1) * 32 : p.zeros;
+                        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(p3_lds + nbuf + ppc * 1024), 16, 0, 0);
                     }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            slot = slot == 2 ? 0 : slot + 1;
-        }
+            s++;
+        };
+        P3Unroll<0, 9>::run(step);
     }
 #ifdef P3_TIMING
     const unsigned long long T2 = __builtin_readcyclecounter();
@@ -451,7 +481,7 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
     const unsigned budget = 80u * 1024u;                          // two workgroups per CU
     // flat runs: no tile waste; the patch carries one image row of halo on both sides
     const int Rrun = P3_BM + 2 * W + 2;
-    const int Prun = (int)ry_cdiv(Rrun, 16);
+    const int Prun = (int)ry_cdiv(Rrun + 1, 16);                   // 16 P > R: the last row of a patch buffer is the kernel's zero row
     int best_th = 0, best_tw = 0;
     for (int tw = 1; tw <= W && tw <= P3_BM; tw++) {
         if (W % tw) continue;
@@ -462,7 +492,7 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
         }
     }
     const int R2 = (best_th + 2) * (best_tw + 2);
-    const int P2 = (int)ry_cdiv(R2, 16);
+    const int P2 = (int)ry_cdiv(R2 + 1, 16);
     const bool ok2 = best_th * best_tw >= 224 && P2 <= 36 && p3_lds_bytes(P2, g.BN) <= budget;
     const bool okr = Prun <= 36 && p3_lds_bytes(Prun, g.BN) <= budget;
     if (!ok2 && !okr) return false;
@@ -481,6 +511,7 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
         g.gm = ry_cdiv(M, P3_BM);
     }
     g.TP = (int)ry_cdiv(g.P, 4);
+    if (g.TP > 7) { g.mode = 0; return false; }                   // the kernel reads a chunk's first fragments one barrier early: its last piece is requested by tap step 6
     for (int t = 0; t < 9; t++) { g.tdh[t] = tc.dh[t]; g.tdw[t] = tc.dw[t]; g.twi[t] = tc.widx[t]; }
     g.rPW = 1.0f / (float)g.PW;
     g.rTW = g.TW ? 1.0f / (float)g.TW : 0.f;
