@@ -555,6 +555,9 @@ int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 //   * 3-stage dY ring + sliding X ring, counted vmcnt, one barrier per step; split-K slabs + the deterministic reduce of
 //     conv.hip; XCD-aware order keeps the tiles that share a pixel range on one L2.
 #define W3_NS 3
+#ifndef W3_PF
+#define W3_PF 6                                                  // fragments read ahead of the MFMA stream in conv3x3_wgrad64_kernel (A/B: -DW3_PF=4)
+#endif
 
 // CO64: layers with <= 64 output channels.  Two waves cover the channels (32 each) and the wave PAIRS split every K step into
 // its two 16-pixel halves, each pair accumulating into its own split-K slab (the deterministic reduce adds them), so all four
@@ -804,7 +807,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradParams
 // to cover the HBM latency): CO64 2 x 8 KiB + the 1024-row ring = 80 KiB; 128 channels 2 x 16 KiB + a 512-row ring = 64 KiB: two workgroups
 // per CU.  Ring rows live = 2 halos + this step + the next + alignment slack (<= 1015 for a 400-pixel map).
 // Measured (kernel + reduce, batch 64): 64->64 @400^2 1822 -> 1092 us, @200^2 503 -> 317; the training step 746 -> 777 img/s.
-template <bool CO64>
+// Round 4: the loop above spent ~400 VALU instructions per step on fragment addresses ((row & ring mask) per read, twice per fragment) and on
+// copying read results into operand quads — for 36 MFMAs; it ran at 49 % of the matrix rate, bound by VALU issue (cycle stamps: 4725 per step).
+// Now the taps are walked ROW BY ROW: the three taps of a kernel row read ring rows r - 1, r, r + 1, and the second transposed read of a fragment
+// sits 4 rows further, so ONE wrapped address per (kernel row, 16-pixel half) serves six reads through ds_read's immediate offset.  An
+// immediate cannot wrap: the ring is followed by a copy of its first 16 rows (the piece that lands on ring row 0 is requested twice) when the
+// LDS budget has the 1 KiB (g.mirror); otherwise every read wraps its own address (2 VALU instructions instead of 3 + 2 copies).
+template <bool CO64, bool MIRROR>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradParams p, const W3Geom g)
 {
     constexpr int DYS = CO64 ? 8192 : 16384;                       // one dY stage: [2 | 4 quarters][64 px][64 B]
@@ -812,6 +821,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradPara
     constexpr int NH = CO64 ? 1 : 2;                               // 32-pixel halves a wave multiplies per step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cow = CO64 ? (wave & 1) : wave, kh = CO64 ? (wave >> 1) : 0;
+#ifdef W3_TIMING
+    const unsigned long long T0 = __builtin_readcyclecounter();
+#endif
     const int t_id = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = t_id % g.gx, bc = (t_id / g.gx) % g.gc, bz = t_id / (g.gx * g.gc);
     const int i0 = bx * 128, ci0 = bc * 32;
@@ -822,8 +834,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradPara
     const int H = p.OH, W = p.OW, PWp = g.PWp, HPp = g.HPp;
     const int HALO = PWp + 1;
     const unsigned rmask = (unsigned)g.RX - 1u;
-    unsigned char* const dyst = p3_lds;
-    unsigned char* const xring = p3_lds + 2 * DYS;
+    // LDS: [ring RX x 64 B][mirror 1 KiB if MIRROR][dY stage 0][dY stage 1] — the ring first, so that a wrapped byte offset IS the address
+    unsigned char* const xring = p3_lds;
+    unsigned char* const dyst = p3_lds + (unsigned)g.RX * 64u + (MIRROR ? 1024u : 0u);
     const int prow_l = lane >> 2, slot = lane & 3;
     const int kend32 = (int)kend, Mp32 = (int)g.Mp;
     const unsigned per = (unsigned)(HPp * PWp);
@@ -836,104 +849,199 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const WgradPara
         ok = uq < (unsigned)limit && (ihp - 1u) < (unsigned)H && (iwp - 1u) < (unsigned)W;
         return (int)((img * (unsigned)H + ihp - 1u) * (unsigned)W + iwp - 1u);
     };
-    // dY: a wave stages the 16-row pieces of ITS quarter that it will read itself: CO64 rows 32 kh + 16 u + prow_l, else rows 16 u + prow_l
-    int dq[NDY];
-#pragma unroll
-    for (int u = 0; u < NDY; u++) dq[u] = (int)kbeg + 32 * kh + 16 * u + prow_l;
-    const bool d_chan_ok = (i0 + 32 * cow + slot * 8) < p.CoutPad;
-    const bf16_t* const dy_base = p.dY + i0 + 32 * cow + slot * 8;
+    // DMA requests of a wave per step: ONE 16-row piece of the 64 new ring rows (lane -> row lane >> 2, 16-byte slot lane & 3) and the dY rows
+    // of ITS quarter that it reads itself, RPW = 64 (CO64: 32) rows x 32 channels.  The dY stage is SLOT-MAJOR — [4 slots of 8 channels][RPW
+    // rows][16 B] — so that a lane owns one pixel row (lane % RPW) and instruction u moves slot u (CO64: 2 u + lane / 32) of all rows: ONE
+    // padded-pixel decomposition per lane and step serves all NDY instructions.  (Row-major stages took one per instruction: with the ring
+    // piece five `locate`s per step — two mulhi, three mullo, a 64-bit mad each, quarter-rate — and the step ran 3590 cycles with them, 2395
+    // without.)  The pointers of the NEXT request are formed inside the MFMA stream (prep_*), the block behind the barrier is NDY + 1 DMAs.
+    constexpr int RPW = CO64 ? 32 : 64, SPI = 64 / RPW;              // rows per wave, slots per instruction
+    const int drow = lane % RPW, dsub = lane / RPW;
+    const bf16_t* const dy_base = p.dY + i0 + 32 * cow;
     const bf16_t* const x_base = p.X + ci0 + slot * 8;
-    auto issue_dy = [&](int stage) {
-#pragma unroll
-        for (int u = 0; u < NDY; u++) {
-            bool ok;
-            const int pix = locate(dq[u], kend32, ok);
-            const bf16_t* src = (ok && d_chan_ok) ? dy_base + (int64_t)pix * p.ldY : p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + cow * 4096 + (32 * kh + 16 * u) * 64), 16, 0, 0);
-            dq[u] += 64;
-        }
-    };
-    // X ring: every wave stages 16 of the 64 rows of an iteration, in the prologue (rows of step 0 with both halos) and in the loop
-    // (rows that step s + 1 adds)
     const int x0 = (int)(((kbeg - HALO) >> 6) << 6);                 // aligned down to 64 (arithmetic shift: also for negatives)
     const int pro_iters = ((int)kbeg + 64 + HALO + 16 - x0 + 63) >> 6;
-    int xq = x0 + 16 * wave + prow_l;
-    auto issue_x = [&]() {
+    int xq = x0 + 16 * wave + prow_l;                                 // this lane's ring row of the next request
+    int dq = (int)kbeg + 32 * kh + drow;                              // this lane's dY pixel of the next request
+    const bf16_t *xsrc, *dsrc;                                        // nullptr: padding / out of range -> the zero page
+    auto prep_x = [&]() {
         bool ok;
         const int pix = locate(xq, Mp32, ok);
-        const bf16_t* src = ok ? x_base + (int64_t)pix * p.ldX : p.zeros;
-        const unsigned row0 = (unsigned)(xq - prow_l) & rmask;
+        xsrc = ok ? x_base + (int64_t)pix * p.ldX : nullptr;
+    };
+    auto prep_dy = [&]() {
+        bool ok;
+        const int pix = locate(dq, kend32, ok);
+        dsrc = ok ? dy_base + (int64_t)pix * p.ldY : nullptr;
+    };
+    auto issue_x = [&]() {
+        const bf16_t* src = xsrc ? xsrc : p.zeros;
+        const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane(xq - prow_l) & rmask;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring + row0 * 64), 16, 0, 0);
+        if (MIRROR && row0 == 0u)                                    // wave-uniform: once per lap of the ring
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring + (unsigned)g.RX * 64u), 16, 0, 0);
         xq += 64;
     };
-    for (int it = 0; it < pro_iters; it++) issue_x();
+    auto issue_dy1 = [&](int stage, int u) {
+        const int sl = u * SPI + dsub;                                // 8-channel slot this lane moves
+        const bf16_t* src = (dsrc && (i0 + 32 * cow + sl * 8) < p.CoutPad) ? dsrc + sl * 8 : p.zeros;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + cow * 4096 + kh * 2048 + u * 1024), 16, 0, 0);
+        if (u == NDY - 1) dq += 64;
+    };
+    auto issue_dy = [&](int stage) {
+#pragma unroll
+        for (int u = 0; u < NDY; u++) issue_dy1(stage, u);
+    };
+    for (int it = 0; it < pro_iters; it++) { prep_x(); issue_x(); }   // rows of step 0 with both halos
+    prep_dy();
     issue_dy(0);
+    prep_x();                                                         // the request of step 0 (operands of step 1)
+    prep_dy();
 
     const int s16 = lane & 15, grp = lane >> 4;
     const int fr_row = (grp >> 1) * 8 + (s16 >> 2);
     const int fr_col = (16 * (grp & 1) + 4 * (s16 & 3)) * 2;
-    f32x16 acc[9];
+    f32x16 acc[9];                                                   // acc[3 * (dh + 1) + (dw + 1)]
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
     const unsigned kb32 = (unsigned)(int)kbeg;
     const unsigned xr_a = lds_addr(xring) + (unsigned)fr_col;
+    const unsigned lane_b = (unsigned)(fr_row * 64);                  // this lane's row inside a fragment, in ring bytes
+    const unsigned bmask = ((unsigned)g.RX << 6) - 1u;
+#ifdef W3_TIMING
+    const unsigned long long T1 = __builtin_readcyclecounter();
+#endif
+#ifdef W3_TIMING
+    unsigned long long t_wait = 0, t_bar = 0;
+#endif
     for (int s = 0; s < nk; s++) {
+#ifdef W3_TIMING
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
         wait_vm<0>();                                                 // everything this wave issued one step ago has landed
+#ifdef W3_TIMING
+        const unsigned long long tw1 = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();                                 // ... and everybody else's; step s - 1 fully consumed
-        if (s + 1 < nk) {
-            issue_x();
-            issue_dy((s + 1) & 1);
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            const int half = CO64 ? kh : hh;
-            const unsigned char* da = dyst + (s & 1) * DYS + cow * 4096 + (32 * half) * 64;
-            const unsigned q0 = kb32 + 64u * (unsigned)s + 32u * (unsigned)half;
-            const unsigned da_a = lds_addr(da) + (unsigned)(fr_row * 64 + fr_col);
-            auto read_a = [&](int ks) { return lds_tr16x2(da_a + (unsigned)(ks * 16 * 64), 256u); };
-            auto read_b = [&](int i) {
-                const int ks = i / 9, t = i % 9;
-                const unsigned qq = q0 + (unsigned)(g.toff[t] + ks * 16 + fr_row);
-                const ry_s16x4 lo = lds_tr16(xr_a + (qq & rmask) * 64u), hi = lds_tr16(xr_a + ((qq + 4u) & rmask) * 64u);
-                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            };
-            // the 18-MFMA schedule of conv3x3_wgrad_kernel<false>: a0, b0..b3, a1, then b(i + 4) in front of MFMA i (counted lgkmcnt)
-            constexpr int PF = 4;
-            bf16x8 af[2], bq[18];
-            af[0] = read_a(0);
-#pragma unroll
-            for (int i = 0; i < PF; i++) bq[i] = read_b(i);
-            af[1] = read_a(1);
-#pragma unroll
-            for (int i = 0; i < 18; i++) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (i + PF < 18) bq[i + PF] = read_b(i + PF);
-                if (i < 4) lds_wait2<10>(af[0], bq[i]);
-                else if (i < 14) lds_wait2<8>(af[1], bq[i]);
-                else if (i == 14) lds_wait<6>(bq[i]);
-                else if (i == 15) lds_wait<4>(bq[i]);
-                else if (i == 16) lds_wait<2>(bq[i]);
-                else lds_wait<0>(bq[i]);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i / 9], bq[i], acc[i % 9], 0, 0, 0);
+#ifdef W3_TIMING
+        t_wait += tw1 - tw0;
+        t_bar += __builtin_readcyclecounter() - tw1;
+#endif
+        const bool more = s + 1 < nk;                                 // this step requests the operands of the next one
+        // ONE fragment stream per step over its NH 32-pixel halves: fragment I = 18 hh + 9 ks + 3 (dh + 1) + (dw + 1) reads ring row
+        // q0(hh) + 16 ks + dh * PWp + dw + fr_row (+ 4 for its second read); A fragment k = 2 hh + ks (16 pixels of dY) is read right in front of
+        // B fragment 9 k.  Reads run W3_PF fragments ahead of the MFMAs, across the halves (the round-3 loop restarted its pipeline per half).
+        constexpr int NF = 18 * NH, PF = W3_PF;
+        const unsigned qs = kb32 + 64u * (unsigned)s + (CO64 ? 32u * (unsigned)kh : 0u);
+        // dY fragment (slot-major stage): channel fr_col / 2 = 8 * slot + c, row fr_row (+ 4 for the second read)
+        const unsigned da_s = lds_addr(dyst + (s & 1) * DYS + cow * 4096 + kh * 2048) + (unsigned)((fr_col >> 4) * (RPW * 16) + fr_row * 16 + (fr_col & 15));
+        ry_s16x4 al[2 * NH], ah[2 * NH], bl[NF], bh[NF];
+        unsigned gaddr[NF / 3];                                       // MIRROR: wrapped address of the dw = -1 fragment of a (half, ks, dh) group
+        auto read_b = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int hh = I / 18, i = I % 18, ks = i / 9, dhi = (i % 9) / 3, dwi = i % 3;
+            if constexpr (i % 9 == 0) {                               // A fragment 2 hh + ks first
+                constexpr unsigned ao = (unsigned)((32 * hh + 16 * ks) * 16);
+                al[I / 9] = lds_tr16_off<ao>(da_s);
+                ah[I / 9] = lds_tr16_off<ao + 64>(da_s);
             }
+            if constexpr (MIRROR) {
+                if constexpr (dwi == 0) {
+                    const unsigned sb = (qs + (unsigned)(32 * hh + 16 * ks + (dhi - 1) * PWp - 1)) << 6;     // scalar
+                    gaddr[I / 3] = xr_a + ((lane_b + sb) & bmask);
+                }
+                bl[I] = lds_tr16_off<dwi * 64>(gaddr[I / 3]);
+                bh[I] = lds_tr16_off<dwi * 64 + 256>(gaddr[I / 3]);
+            } else {
+                const unsigned sb = (qs + (unsigned)(32 * hh + 16 * ks + (dhi - 1) * PWp - 1 + dwi)) << 6;      // scalar
+                bl[I] = lds_tr16(xr_a + ((lane_b + sb) & bmask));
+                bh[I] = lds_tr16(xr_a + ((lane_b + sb + 256u) & bmask));
+            }
+        };
+        P3Unroll<0, PF>::run(read_b);
+        bf16x8 af[2 * NH];
+        auto mma = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
-        }
+#if !defined(W3_ABL) || W3_ABL != 2
+            if constexpr (I + PF < NF) read_b(std::integral_constant<int, I + PF>{});
+#else
+            if constexpr (I + PF < NF) { bl[I + PF] = bl[(I + PF) % PF]; bh[I + PF] = bh[(I + PF) % PF]; if constexpr ((I + PF) % 9 == 0) { al[(I + PF) / 9] = al[0]; ah[(I + PF) / 9] = ah[0]; } }
+#endif
+            // LDS returns in order: "at most N later reads in flight" = fragment I has landed, and with it everything read before it (its A
+            // fragment included: tied to the wait only at its first use — tying it again would re-define it and cost two copies per MFMA).
+            // N = 2 per B fragment read after I, + 2 if an A fragment was read among them.
+            constexpr int ahead = (I + PF < NF ? I + PF : NF - 1);
+            constexpr int N = 2 * (ahead - I) + ((ahead / 9 > I / 9) ? 2 : 0);
+            static_assert(N <= 15, "lgkmcnt is a 4-bit counter");
+#if defined(W3_ABL) && W3_ABL == 2
+            constexpr int NW = I < PF ? N : 0;
+            if constexpr (I % 9 == 0) { lds_wait_h2<NW>(al[I / 9], ah[I / 9], bl[I], bh[I]); af[I / 9] = join_halves(al[I / 9], ah[I / 9]); }
+            else lds_wait_h<NW>(bl[I], bh[I]);
+#else
+            if constexpr (I % 9 == 0) { lds_wait_h2<N>(al[I / 9], ah[I / 9], bl[I], bh[I]); af[I / 9] = join_halves(al[I / 9], ah[I / 9]); }
+            else lds_wait_h<N>(bl[I], bh[I]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(W3_ABL) && W3_ABL == 3
+            if constexpr (I < 9) acc[I % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[I / 9], join_halves(bl[I], bh[I]), acc[I % 9], 0, 0, 0);
+            else asm volatile("" :: "v"(bl[I]), "v"(bh[I]));
+#else
+            acc[I % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[I / 9], join_halves(bl[I], bh[I]), acc[I % 9], 0, 0, 0);
+#endif
+            // source pointers of the next step's request, right behind an MFMA
+            // The step's NDY + 1 DMA instructions follow MFMAs 0, 2, 4, ... (a DMA issue stalls the wave for ~100+ cycles; issued as one block
+            // behind the barrier the five of them cost a third of the step — 3590 cycles against 2395 without — behind an MFMA they wait in
+            // its shadow), then the pointers of the next request are formed behind MFMAs in the second half of the stream.
+            if constexpr (I % 2 == 0 && I / 2 <= NDY) {
+                __builtin_amdgcn_sched_barrier(0);
+#if defined(W3_ABL) && W3_ABL == 1
+                if (false) {
+#elif defined(W3_ABL) && W3_ABL == 4
+                if (more) { xsrc = nullptr; dsrc = nullptr;                  // every request from the zero page
+#elif defined(W3_ABL) && W3_ABL == 5
+                if (more && I == 0) {                                        // ring rows only
+#elif defined(W3_ABL) && W3_ABL == 6
+                if (more && I != 0) {                                        // dY only
+#else
+                if (more) {
+#endif
+                    if constexpr (I == 0) issue_x();
+                    else issue_dy1((s + 1) & 1, I / 2 - 1);
+                }
+            }
+            if constexpr (I == NF / 2 + 1 || I == NF / 2 + 5) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (I == NF / 2 + 1) prep_x();
+                else prep_dy();
+            }
+        };
+        P3Unroll<0, NF>::run(mma);
+        __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef W3_TIMING
+    const unsigned long long T2 = __builtin_readcyclecounter();
+#endif
     // split-K partial tile -> workspace (CO64: two slabs per K range, one per pixel half, summed by the deterministic reduce)
     const int NK = 9 * p.Cin;
     float* part = p.partial + ((int64_t)bz * (CO64 ? 2 : 1) + kh) * p.Cout * NK;
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-        const int kc = t * p.Cin + ci0 + (lane & 31);
+    for (int j = 0; j < 9; j++) {
+        const int kc = g.tap_of[j] * p.Cin + ci0 + (lane & 31);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int co = i0 + 32 * cow + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[t][e];
+            if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[j][e];
         }
     }
+#ifdef W3_TIMING
+    if (tid == 0) {   // debug build only: timestamps into the tail of the slab workspace (tools/bench_wgrad.py reads them)
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.partial + (size_t)g.slabs * p.Cout * NK) + (size_t)blockIdx.x * 4;
+        dbg[0] = t_wait; dbg[1] = T2 - T1; dbg[2] = t_bar; dbg[3] = nk;              // (wave 0's DMA wait and barrier wait, summed over the steps)
+    }
+#endif
 }
 
 bool w3_geometry(const WgradParams& p, W3Geom& g)
@@ -982,6 +1090,7 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.kchunk = ry_cdiv(ry_cdiv(g.Mp, sk), kstep) * kstep;
     g.splitk = (int)ry_cdiv(g.Mp, g.kchunk);
     for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
+    for (int t = 0; t < 9; t++) g.tap_of[(p.dh[t] + 1) * 3 + p.dw[t] + 1] = t;
     auto magic = [](unsigned d, unsigned& m, unsigned& sh) {         // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (d >= 3 here: padded sizes)
         unsigned l = 0;
         while ((1ull << l) < d) l++;
@@ -991,6 +1100,9 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     magic((unsigned)(g.HPp * g.PWp), g.m_img, g.s_img);
     magic((unsigned)g.PWp, g.m_row, g.s_row);
     g.lds_bytes = (g.step64 ? 2u * (g.co64 ? 8192u : 16384u) : W3_NS * (g.co64 ? 4096u : 8192u)) + (unsigned)g.RX * 64u;
+    static const int w3_mirror = getenv("RYOLO_W3_MIRROR") ? atoi(getenv("RYOLO_W3_MIRROR")) : 1;      // A/B knob
+    g.mirror = (g.step64 && w3_mirror && g.lds_bytes + 1024u <= 80u * 1024u) ? 1 : 0;
+    if (g.mirror) g.lds_bytes += 1024u;
     g.slabs = g.splitk * (g.co64 ? 2 : 1);
     g.ok = 1;
     return true;
@@ -998,17 +1110,23 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
 
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream)
 {
-    static RyLdsAttr attr_f, attr_t, attr_64f, attr_64t;
+    static RyLdsAttr attr_f, attr_t, attr_64f, attr_64t, attr_64fm, attr_64tm;
     if (ry_max_dynamic_lds(attr_f, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<false>), 160 * 1024) ||
         ry_max_dynamic_lds(attr_t, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<true>), 160 * 1024) ||
-        ry_max_dynamic_lds(attr_64f, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<false>), 160 * 1024) ||
-        ry_max_dynamic_lds(attr_64t, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<true>), 160 * 1024))
+        ry_max_dynamic_lds(attr_64f, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<false, false>), 160 * 1024) ||
+        ry_max_dynamic_lds(attr_64t, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<true, false>), 160 * 1024) ||
+        ry_max_dynamic_lds(attr_64fm, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<false, true>), 160 * 1024) ||
+        ry_max_dynamic_lds(attr_64tm, reinterpret_cast<const void*>(&conv3x3_wgrad64_kernel<true, true>), 160 * 1024))
         return RY_ERR_LAUNCH;
     const dim3 grid((unsigned)((int64_t)g.gx * g.gc * g.splitk));
-    if (g.step64 && g.co64)
-        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<true>), grid, dim3(256), g.lds_bytes, stream, p, g);
+    if (g.step64 && g.co64 && g.mirror)
+        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<true, true>), grid, dim3(256), g.lds_bytes, stream, p, g);
+    else if (g.step64 && g.co64)
+        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<true, false>), grid, dim3(256), g.lds_bytes, stream, p, g);
+    else if (g.step64 && g.mirror)
+        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<false, true>), grid, dim3(256), g.lds_bytes, stream, p, g);
     else if (g.step64)
-        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<false>), grid, dim3(256), g.lds_bytes, stream, p, g);
+        hipLaunchKernelGGL((conv3x3_wgrad64_kernel<false, false>), grid, dim3(256), g.lds_bytes, stream, p, g);
     else if (g.co64)
         hipLaunchKernelGGL((conv3x3_wgrad_kernel<true>), grid, dim3(256), g.lds_bytes, stream, p, g);
     else

@@ -62,6 +62,23 @@ __device__ __forceinline__ bf16x8 lds_tr16x2(unsigned addr, unsigned second)
     const ry_s16x4 lo = lds_tr16(addr), hi = lds_tr16(addr + second);
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+// the same read with a compile-time byte offset (ds_read's 16-bit immediate): one address register serves several rows
+template <int OFF> __device__ __forceinline__ ry_s16x4 lds_tr16_off(unsigned addr)
+{
+    ry_s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+// waits tied to the two 64-bit HALVES of fragments: the halves are joined into the MFMA operand after the wait
+template <int N> __device__ __forceinline__ void lds_wait_h(ry_s16x4& a, ry_s16x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_wait_h2(ry_s16x4& a, ry_s16x4& b, ry_s16x4& c, ry_s16x4& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+__device__ __forceinline__ bf16x8 join_halves(ry_s16x4 lo, ry_s16x4 hi)
+{
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 template <int N> __device__ __forceinline__ void lds_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 template <int N> __device__ __forceinline__ void lds_wait2(bf16x8& f, bf16x8& g) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(g) : "n"(N)); }
 
@@ -217,6 +234,8 @@ struct W3Geom {
     int step64;                // 1: 64-pixel K steps (conv3x3_wgrad64_kernel), 0: 32-pixel steps
     int64_t kchunk;            // padded pixels per split (multiple of 32)
     int toff[9];               // dh * PWp + dw per tap (caller's tap order)
+    int tap_of[9];             // caller's tap index of the tap (dh, dw) at 3 * (dh + 1) + (dw + 1) (the 64-pixel kernels walk the taps row by row)
+    int mirror;                // 1: the ring is followed by a copy of its first 16 rows (conv3x3_wgrad64_kernel: immediate row offsets never wrap)
     unsigned lds_bytes;
     // exact n / d for 0 <= n < 2^31 as (mulhi(n, m) >> s): d = HPp * PWp (padded pixels per image) and d = PWp (padded row length) —
     // the DMA address generation decomposes a padded pixel index without loops or branches

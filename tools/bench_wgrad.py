@@ -54,4 +54,4 @@ if os.environ.get("W3_TIMING"):
     torch.cuda.synchronize()
     d = work[ws.value:].view(torch.int64).view(-1, 4).cpu().numpy()
     d = d[d[:, 3] != 0]
-    print("blocks", len(d), "steps", d[:, 3].mean(), "prologue", d[:, 0].mean(), "loop", d[:, 1].mean(), "per-step", (d[:, 1] / d[:, 3]).mean(), "epilogue", d[:, 2].mean())
+    print("blocks", len(d), "steps", d[:, 3].mean(), "loop per step", (d[:, 1] / d[:, 3]).mean(), "DMA wait per step (wave 0)", (d[:, 0] / d[:, 3]).mean(), "barrier wait per step", (d[:, 2] / d[:, 3]).mean())
