@@ -44,7 +44,9 @@ template <int N> struct P3Unroll<N, N> {
     template <class F> static __device__ __forceinline__ void run(F&) {}
 };
 
-template <int BN, int WM, int WN>
+// EPI / BS (BatchNorm-backward sums folded into the store loop) are template parameters: with the epilogue selected by run-time branches the
+// one kernel body carried every variant (17 k instructions behind the loop) and the training epilogues ran 10-13 k cycles per workgroup.
+template <int BN, int WM, int WN, int EPI, bool BS>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmParams p, const P3Geom g)
 {
     constexpr int BM = P3_BM, TM = BM / WM / 32, TN = BN / WN / 32, WTM = BM / WM, WTN = BN / WN;
@@ -316,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     const unsigned long long T2 = __builtin_readcyclecounter();
 #endif
     __syncthreads();                                           // operand tiles dead: LDS is reused for the output staging
+#ifdef P3_TIMING
+    unsigned long long te[6] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0};    // sync | stage writes | statistics | store loop (both halves summed)
+#endif
 
     // ---- epilogue.  acc[i][j] is the transposed 32x32 tile: column = lane & 31 = pixel i*32 + (lane & 31), row = channel
     // j*32 + (e & 3) + 8*(e >> 2) + 4*(lane >> 5): 4 consecutive channels per lane per register quad -> one 8-byte LDS store
@@ -329,7 +334,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     const int cq = lane & 15, rg = lane >> 4;                  // statistics: 4 channels x every 4th row per lane
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     BsLane bsl;
-    if (p.nbstat) bs_lane_init(p, ncol, bsl);
+    if constexpr (BS) bs_lane_init(p, ncol, bsl);
+    // accumulate epilogue: the old values of the WHOLE tile are requested here, in front of the staging writes — one memory round trip per
+    // workgroup, most of it under the staging of the first half (requested per group of 4 rows inside the store loop it was four round trips:
+    // 12 k of the epilogue's 13.8 k cycles)
+    constexpr int NITA = 64 / RPI;
+    uint4 oldall[TM / 2][NITA];
+    if constexpr (EPI == EPI_ACCUM) {
+        const int ncol_a = ncol < p.Nout ? ncol : 0;
+#pragma unroll
+        for (int half = 0; half < TM / 2; half++)
+#pragma unroll
+            for (int it = 0; it < NITA; it++) {
+                const int pi = rowpix[wm * WTM + half * 64 + it * RPI + r0];
+                const int64_t pix = (pi >= 0 && ncol < p.Nout) ? (int64_t)pi : 0;      // dead rows read (and discard) pixel 0 of their own columns
+                oldall[half][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.out) + pix * p.ldC + ncol_a);
+            }
+    }
 #pragma unroll
     for (int half = 0; half < TM / 2; half++) {
 #pragma unroll
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                     float v[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) v[q] = acc[i][j][4 * g4 + q];
-                    if (p.epi == EPI_AFFINE_ACT) {
+                    if constexpr (EPI == EPI_AFFINE_ACT) {
                         const int n = n0 + wn * WTN + c0;
                         if (n < p.Nout) {
                             const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
@@ -357,8 +378,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                     const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     *reinterpret_cast<uint2*>(stage + (ii * 32 + (lane & 31)) * EP_LD + c0) = w;
                 }
+#ifdef P3_TIMING
+        { const unsigned long long t = __builtin_readcyclecounter(); te[1] += t - (half ? te[5] : te[0]); te[4] = t; }
+#endif
         // (same-wave LDS hand-off: the wave's own ds_write -> ds_read ordering is enough, no workgroup barrier)
-        if (p.epi == EPI_STATS) {
+        if constexpr (EPI == EPI_STATS) {
             // BatchNorm batch statistics of the values actually stored (bf16-rounded); dead rows hold exact zeros
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -371,13 +395,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                 ssum[3] += f3; ssq[3] += f3 * f3;
             }
         }
+#ifdef P3_TIMING
+        { const unsigned long long t = __builtin_readcyclecounter(); te[2] += t - te[4]; te[4] = t; }
+#endif
         // Store loop in two phases: every global load of the half (the old value of an accumulate epilogue, the BatchNorm input of a
         // bstat lane) is issued before the first one is used.  With the loads inside one loop next to `continue` branches each of the
         // 8 iterations paid its own memory round trip: +24 us on a 77 us launch for EPI_ACCUM, +40 us more with bstat (128->128 @50^2).
         constexpr int NIT = 64 / RPI, GRP = 4;                          // 4 iterations in flight: more would cost a resident workgroup (VGPRs)
         static_assert(NIT % GRP == 0, "store loop grouping");
-        const bool accum = p.epi == EPI_ACCUM, bs_on = p.nbstat && bsl.y;
-        const int ncol_s = ncol < p.Nout ? ncol : 0;
+        constexpr bool accum = EPI == EPI_ACCUM;
+        const bool bs_on = BS && bsl.y;
 #pragma unroll
         for (int g0 = 0; g0 < NIT; g0 += GRP) {
             int64_t pixv[GRP];
@@ -391,10 +418,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                 lv[k] = live;
                 pixv[k] = live ? (int64_t)pi : 0;                        // dead rows read (and discard) pixel 0 of their own columns
             }
-            if (accum) {
+            if constexpr (accum) {
 #pragma unroll
-                for (int k = 0; k < GRP; k++)
-                    oldv[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.out) + pixv[k] * p.ldC + ncol_s);
+                for (int k = 0; k < GRP; k++) oldv[k] = oldall[half][g0 + k];
             }
             if (bs_on) {
 #pragma unroll
@@ -420,9 +446,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                 if (bs_on) bs_lane_row(bsl, yv[k], v);
             }
         }
+#ifdef P3_TIMING
+        { const unsigned long long t = __builtin_readcyclecounter(); te[3] += t - te[4]; te[5] = t; }
+#endif
     }
-    if (p.nbstat) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(p3_lds), wave, r0, ch, tid, n0, mb);
-    if (p.epi == EPI_STATS) {
+#ifdef P3_TIMING
+    const unsigned long long T3 = __builtin_readcyclecounter();
+#endif
+    if constexpr (BS) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(p3_lds), wave, r0, ch, tid, n0, mb);
+    if constexpr (EPI == EPI_STATS) {
         // every lane parks its 8 partial sums in LDS, one thread per column folds the 4 row groups x WM waves
         // (a shuffle tree here is 16 dependent ds_bpermute round trips, ~2 k cycles)
         __syncthreads();
@@ -451,6 +483,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     if (p.bias && tid == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + (size_t)blockIdx.x * 4;
         dbg[0] = T0; dbg[1] = T1; dbg[2] = T2; dbg[3] = __builtin_readcyclecounter();
+        unsigned long long* d2 = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + (size_t)(4 * 35000) + (size_t)blockIdx.x * 4;
+        d2[0] = te[0] - T2; d2[1] = te[1]; d2[2] = te[2]; d2[3] = te[3];          // barrier | stage writes | statistics | stores (wave 0)
     }
 #endif
 }
@@ -523,19 +557,31 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
     return true;
 }
 
-template <int BN, int WM, int WN> static int p3_launch_t(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
+template <int BN, int WM, int WN, int EPI, bool BS> static int p3_launch_t(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 {
     static RyLdsAttr attr;
-    if (ry_max_dynamic_lds(attr, reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN>), 160 * 1024)) return RY_ERR_LAUNCH;
+    if (ry_max_dynamic_lds(attr, reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN, EPI, BS>), 160 * 1024)) return RY_ERR_LAUNCH;
     static const unsigned ldspad = getenv("RYOLO_P3_LDSPAD") ? (unsigned)atoi(getenv("RYOLO_P3_LDSPAD")) : 0u;   // occupancy experiments
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes + ldspad, stream, p, g);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN, EPI, BS>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes + ldspad, stream, p, g);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
+}
+
+template <int BN, int WM, int WN> static int p3_launch_e(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
+{
+    // BatchNorm-backward sums ride on the data-gradient epilogues only (conv.hip checks the combination)
+    switch (p.epi) {
+        case EPI_RAW: return p.nbstat ? p3_launch_t<BN, WM, WN, EPI_RAW, true>(p, g, stream) : p3_launch_t<BN, WM, WN, EPI_RAW, false>(p, g, stream);
+        case EPI_ACCUM: return p.nbstat ? p3_launch_t<BN, WM, WN, EPI_ACCUM, true>(p, g, stream) : p3_launch_t<BN, WM, WN, EPI_ACCUM, false>(p, g, stream);
+        case EPI_STATS: return p.nbstat ? RY_ERR_ARG : p3_launch_t<BN, WM, WN, EPI_STATS, false>(p, g, stream);
+        case EPI_AFFINE_ACT: return p.nbstat ? RY_ERR_ARG : p3_launch_t<BN, WM, WN, EPI_AFFINE_ACT, false>(p, g, stream);
+    }
+    return RY_ERR_ARG;
 }
 
 int p3_launch(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 {
-    if (g.BN == 64) return p3_launch_t<64, 4, 1>(p, g, stream);
-    return p3_launch_t<128, 2, 2>(p, g, stream);
+    if (g.BN == 64) return p3_launch_e<64, 4, 1>(p, g, stream);
+    return p3_launch_e<128, 2, 2>(p, g, stream);
 }
 
 // =====================================================================================================================
