@@ -63,6 +63,19 @@ __device__ __forceinline__ V8 ld8(const bf16_t* p)
     const ew_u32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const ew_u32x4*>(p));
     return unpack8(make_uint4(rv.x, rv.y, rv.z, rv.w));
 }
+// asm loads with hand-counted waits (bn_act_bwd_reduce_kernel's read-ahead): the outputs are "defined" for the compiler at the request and
+// must pass through ew_vmwait before their first use
+__device__ __forceinline__ void ew_gload(ew_u32x4& r, const bf16_t* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ew_gload_nt(ew_u32x4& r, const bf16_t* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void ew_vmwait(ew_u32x4& a, ew_u32x4& b, ew_u32x4& c)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+__device__ __forceinline__ uint4 ld8_raw(const bf16_t* p)
+{
+    const ew_u32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const ew_u32x4*>(p));
+    return make_uint4(rv.x, rv.y, rv.z, rv.w);
+}
 __device__ __forceinline__ V8 ld8_keep(const bf16_t* p) { return unpack8(*reinterpret_cast<const uint4*>(p)); }    // will be read again soon
 __device__ __forceinline__ void st8(bf16_t* p, const V8& a)
 {
@@ -259,14 +272,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActParams p)
 template <int ACT, bool Y2>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParams p)
 {
-    __shared__ float red[3][256][8 + 1];
+    constexpr int K = Y2 ? 3 : 2;
+    __shared__ float red[K][256][8 + 1];                          // 18 KiB without the second branch: 8 workgroups per CU
     const int c8 = p.C >> 3;
     const int cols = c8 < 256 ? c8 : 256;
     const int rl = threadIdx.x / cols, nrl = 256 / cols;
     const int cl = threadIdx.x - rl * cols;
     const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
     const int64_t r1 = min(p.M, r0 + p.rows_per_block);
-    constexpr int K = Y2 ? 3 : 2;
     for (int cb = 0; cb < c8; cb += cols) {
         const int cc = cb + cl;
         float s0[8], s1[8], s2[8];
@@ -280,41 +293,80 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const BnActParam
                 sc1[k] = p.co1[2 * p.C + c + k]; sh1[k] = p.co1[3 * p.C + c + k];
                 if (Y2) { sc2[k] = p.co2[2 * p.C + c + k]; sh2[k] = p.co2[3 * p.C + c + k]; }
             }
-#pragma unroll 1                                            // measured: unroll 2 = same, unroll 4 = 1.4x slower (registers -> occupancy)
-            for (int64_t mf = r0 + rl; mf < r1; mf += nrl) {
-                // back-to-front sweep: the tail of dz (just written front-to-back by the dgrad kernels) is still in the 256 MiB
-                // Infinity Cache, and the forward-sweeping apply pass then starts on what this pass read last (measured: -0.3 ms/step;
-                // reversing the apply or the forward pass instead: -0.15 / -0.05 ms)
-                const int64_t m = p.M - 1 - mf;
-                const V8 d = ld8_keep(p.dz + m * p.lddz + c);
-                const V8 a = ld8_keep(p.y1 + m * p.ld1 + c);
-                V8 b;
-                if (Y2) b = ld8(p.y2 + m * p.ld2 + c);
+            // One row ahead in flight: the raw 16-byte loads of row i + 1 are issued before the arithmetic of row i (the last round re-reads
+            // its own row: branch-free).  With the fold below kept out of the register budget this is 5 waves per SIMD x 2 rows in flight;
+            // the first version (no read-ahead, 168 VGPRs = 3 waves) ran at 4.5 TB/s beside the 5.9 of its siblings — it waited for
+            // latency, ~500 VALU cycles per row and wave against a ~3000-cycle round trip.  (Compiler unrolling by 2 / 4 was measured
+            // the same / 1.4x slower in r02: it doubled the registers instead of overlapping the loads.)
+            // back-to-front sweep: the tail of dz (just written front-to-back by the dgrad kernels) is still in the 256 MiB
+            // Infinity Cache, and the forward-sweeping apply pass then starts on what this pass read last (measured: -0.3 ms/step;
+            // reversing the apply or the forward pass instead: -0.15 / -0.05 ms)
+            const int64_t mf = r0 + rl;
+            if (mf < r1) {
+                const int n = (int)((r1 - 1 - mf) / nrl) + 1;          // rows of this lane
+                const bf16_t* pd = p.dz + (p.M - 1 - mf) * p.lddz + c;
+                const bf16_t* pa = p.y1 + (p.M - 1 - mf) * p.ld1 + c;
+                const bf16_t* pb = Y2 ? p.y2 + (p.M - 1 - mf) * p.ld2 + c : nullptr;
+                const int64_t sd = -(int64_t)nrl * p.lddz, sa = -(int64_t)nrl * p.ld1, sb = Y2 ? -(int64_t)nrl * p.ld2 : 0;
+                auto row = [&](const ew_u32x4 dr, const ew_u32x4 ar, const ew_u32x4 br) {
+                    const V8 d = unpack8(make_uint4(dr.x, dr.y, dr.z, dr.w)), a = unpack8(make_uint4(ar.x, ar.y, ar.z, ar.w));
+                    V8 b;
+                    if (Y2) b = unpack8(make_uint4(br.x, br.y, br.z, br.w));
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    float u = a.v[k] * sc1[k] + sh1[k];
-                    if (Y2) u += b.v[k] * sc2[k] + sh2[k];
-                    const float g = d.v[k] * act_d(u, ACT);
-                    s0[k] += g;
-                    s1[k] += g * a.v[k];
-                    if (Y2) s2[k] += g * b.v[k];
+                    for (int k = 0; k < 8; k++) {
+                        float u = a.v[k] * sc1[k] + sh1[k];
+                        if (Y2) u += b.v[k] * sc2[k] + sh2[k];
+                        const float g = d.v[k] * act_d(u, ACT);
+                        s0[k] += g;
+                        s1[k] += g * a.v[k];
+                        if (Y2) s2[k] += g * b.v[k];
+                    }
+                };
+                // Two register sets, rows alternate between them (no copies); the loads and their waits are asm: hipcc's own vmcnt bookkeeping
+                // put a vmcnt(0) at the loop header (the set requested in the previous half-round had to land before the next request went
+                // out), which is the serialization this loop exists to remove.  NL loads per set, in-order return: vmcnt(NL) = "the older set
+                // is here".  No other vector-memory instruction may sit inside the loop.
+                constexpr int NL = Y2 ? 3 : 2;
+                ew_u32x4 d0, a0, b0 = {0, 0, 0, 0}, d1, a1, b1 = {0, 0, 0, 0};
+                __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0) hipcc can see: the coefficient loads end HERE, not at their first use inside the loop
+                ew_gload(d0, pd); ew_gload(a0, pa);
+                if (Y2) ew_gload_nt(b0, pb);
+#pragma unroll 1
+                for (int i = 0;; i += 2) {
+                    const bool m1 = i + 1 < n;
+                    if (m1) { pd += sd; pa += sa; if (Y2) pb += sb; }
+                    ew_gload(d1, pd); ew_gload(a1, pa);
+                    if (Y2) ew_gload_nt(b1, pb);
+                    ew_vmwait<NL>(d0, a0, b0);
+                    row(d0, a0, b0);
+                    if (!m1) break;
+                    const bool m2 = i + 2 < n;
+                    if (m2) { pd += sd; pa += sa; if (Y2) pb += sb; }
+                    ew_gload(d0, pd); ew_gload(a0, pa);
+                    if (Y2) ew_gload_nt(b0, pb);
+                    ew_vmwait<NL>(d1, a1, b1);
+                    row(d1, a1, b1);
+                    if (!m2) break;
                 }
+                ew_vmwait<0>(d0, a0, b0);                             // the read-ahead of the last round (a row already summed) is still in flight
+                ew_vmwait<0>(d1, a1, b1);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; k++) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; if (Y2) red[2][threadIdx.x][k] = s2[k]; }
         __syncthreads();
-        if (rl == 0 && cc < c8) {
-#pragma unroll
-            for (int q = 0; q < K; q++) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    float s = 0.f;
-                    for (int j = 0; j < nrl; j++) s += red[q][j * cols + cl][k];
-                    p.partial[((int64_t)blockIdx.x * K + q) * p.C + (cc << 3) + k] = s;
-                }
-            }
+        // fold of the row lanes: one (statistic, channel) per thread and round, row lanes added in ascending order (the order of the first
+        // version, whose fully unrolled form held the kernel at 168 VGPRs = 3 waves per SIMD: the streaming loop above wants the occupancy)
+        const int ncol = min(cols, c8 - cb) * 8;                   // channels of this column block
+#pragma unroll 1
+        for (int idx = threadIdx.x; idx < K * ncol; idx += 256) {
+            const int q = idx / ncol, ch = idx - q * ncol;
+            const float* r = &red[q][ch >> 3][ch & 7];
+            float s = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < nrl; j++) s += r[j * cols * 9];
+            p.partial[((int64_t)blockIdx.x * K + q) * p.C + (cb << 3) + ch] = s;
         }
     }
 }
