@@ -1051,6 +1051,152 @@ __global__ __launch_bounds__(256, PX == 64 ? 2 : 3) void wgrad1x1_dma_kernel(con
     }
 }
 
+// ---- tapped / strided weight gradient on the same LDS-DMA ring (r04) -------------------------------------------------------
+// dW[co][tap][ci] = sum_p dY[p][co] * X[in(p, tap)][ci] for the layers the halo-ring kernel (conv3x3.hip) does not take: the stride-2 3x3
+// layers (6 launches of yolov7, 2.1 ms at ~490 TF/s on the register-staged kernel above).  Same stage layout, fragment reads and K loop as
+// wgrad1x1_dma_kernel<32>; what changes is the SOURCE of an X piece: LDS-DMA takes a per-lane global address, so the gather (output pixel ->
+// (image, row, column) by multiply-high, input pixel of the lane's tap, bounds -> the zero page) happens on the request side and the
+// padding never exists in LDS as a select.  A 128-column tile = 4 chunks of 32 input channels; chunk q = (tap, channel block) = (q / (Cin/32),
+// q % (Cin/32)) as in the generic kernel, so its split-K slabs and the reduce are unchanged.  A lane's quarter (and with it its tap) is
+// the same for every piece it requests.  Every wave requests 2 dY + 2 X pieces per stage (the pointwise kernel gives waves 0-1 dY and 2-3 X:
+// here that would put the whole gather on two waves); the X addresses of the NEXT request are computed behind the step's MFMAs.
+__global__ __launch_bounds__(256, 3) void wgrad_taps_dma_kernel(const WgradParams p, const WgMagic mg)
+{
+    constexpr int PX = 32, NS = 3, OPB = PX * 256, STB = 2 * OPB, NP = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char wt_lds[NS * STB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t M = (int64_t)p.NB * p.OH * p.OW;
+    const int cchunks = p.Cin / BK, nchunks = p.ntaps * cchunks;
+    const int gx = (p.Cout + 127) / 128, gy = (nchunks + 3) / 4;
+    const int t_id = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t_id % gx, by = (t_id / gx) % gy, bz = t_id / (gx * gy);
+    const int i0 = bx * 128, q0 = by * 4;
+    const int64_t kbeg = (int64_t)bz * p.kchunk;
+    const int64_t kend = min(M, kbeg + p.kchunk);
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg + PX - 1) / PX);
+    const int npix = (int)(kend - kbeg);
+
+    // piece k (0..7) of an operand = stage pixel rows 4k .. 4k + 3, whole 256-byte rows: lane -> (row = lane >> 4, quarter position =
+    // (lane >> 2) & 3, 16-byte slot = lane & 3); position qp of row r holds quarter qp ^ (r & 3) (wgrad1x1_dma_kernel).  Wave w owns k = 2w, 2w + 1.
+    const int prow = lane >> 4, qpos = (lane >> 2) & 3, slot = lane & 3;
+    const int qsrc = qpos ^ (prow & 3);
+    const bool a_ok = i0 + 32 * qsrc + slot * 8 < p.CoutPad;
+    const bf16_t* a_src[2];
+    int pix[2];                                                      // pixel (relative to kbeg) of this lane's row in the NEXT stage to request
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        pix[u] = 4 * (2 * wave + u) + prow;
+        a_src[u] = p.dY + (kbeg + pix[u]) * (int64_t)p.ldY + i0 + 32 * qsrc + slot * 8;
+    }
+    const int64_t step_a = PX * (int64_t)p.ldY;
+    const int q = q0 + qsrc;
+    const bool b_ok = q < nchunks;
+    const int tap = b_ok ? q / cchunks : 0;
+    const int b_c0 = (b_ok ? q - tap * cchunks : 0) * BK + slot * 8;
+    const int b_dh = p.dh[tap], b_dw = p.dw[tap];
+    const unsigned HWo = (unsigned)(p.OH * p.OW);
+    const bf16_t* b_src[2];                                          // X rows of the next stage to request (the zero page for padding / tails)
+    auto gather = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const unsigned m = (unsigned)((int)kbeg + pix[u]);
+            const unsigned img = mg.m_img ? __umulhi(m, mg.m_img) >> mg.s_img : m;          // (m_* == 0: division by one)
+            const unsigned rem = m - img * HWo;
+            const unsigned oh = mg.m_row ? __umulhi(rem, mg.m_row) >> mg.s_row : rem;
+            const unsigned ow = rem - oh * (unsigned)p.OW;
+            const int ih = (int)oh * p.sh + b_dh, iw = (int)ow * p.sw + b_dw;
+            const bool v = b_ok && pix[u] < npix && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            b_src[u] = v ? p.X + (((int64_t)img * p.IH + ih) * p.IW + iw) * p.ldX + b_c0 : p.zeros;
+        }
+    };
+    int issued = 0;
+    auto issue_stage = [&]() {                                       // needs gather() for this stage; leaves pix[] at the following one
+        unsigned char* st = wt_lds + (issued % NS) * STB;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const bf16_t* s_ = (a_ok && pix[u] < npix) ? a_src[u] : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)s_, (lds_void_t*)(st + (2 * wave + u) * 1024), 16, 0, 0);
+            a_src[u] += step_a;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)b_src[u], (lds_void_t*)(st + OPB + (2 * wave + u) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; u++) pix[u] += PX;
+        issued++;
+    };
+    gather();
+    issue_stage();
+    if (nk > 1) { gather(); issue_stage(); }
+    if (nk > 2) gather();
+
+    const int s16 = lane & 15, grp = lane >> 4;
+    const unsigned fr_row = (unsigned)((grp >> 1) * 8 + (s16 >> 2));
+    const unsigned fr_col = (unsigned)((16 * (grp & 1) + 4 * (s16 & 3)) * 2);
+    unsigned fa[2], fbq[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) fa[i] = fr_row * 256u + (unsigned)(((2 * wm + i) ^ (int)(fr_row & 3u)) * 64) + fr_col;
+#pragma unroll
+    for (int j = 0; j < 2; j++) fbq[j] = fr_row * 256u + (unsigned)(((2 * wn + j) ^ (int)(fr_row & 3u)) * 64) + fr_col;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    for (int s = 0; s < nk; s++) {
+        if (s + 1 >= nk) gemm_wait_vm<0>();                          // the stage requested during step s - 1 (operands of step s + 1) may stay in flight
+        else gemm_wait_vm<NP>();
+        __builtin_amdgcn_s_barrier();
+        if (s + NS - 1 < nk) issue_stage();
+        const unsigned base = lds_addr(wt_lds + (s % NS) * STB);
+        bf16x8 af[2][2], bq[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[0][i] = lds_tr16x2(base + fa[i], 1024u);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bq[0][j] = lds_tr16x2(base + (unsigned)OPB + fbq[j], 1024u);
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[1][i] = lds_tr16x2(base + fa[i] + 4096u, 1024u);
+        lds_wait2<4>(af[0][0], af[0][1]);
+        lds_wait2<4>(bq[0][0], bq[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bq[1][j] = lds_tr16x2(base + (unsigned)OPB + fbq[j] + 4096u, 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bq[0][j], acc[i][j], 0, 0, 0);
+        lds_wait2<0>(af[1][0], af[1][1]);
+        lds_wait2<0>(bq[1][0], bq[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bq[1][j], acc[i][j], 0, 0, 0);
+        if (s + NS < nk) gather();                                   // addresses of the stage step s + 1 requests: VALU work in the MFMA shadow
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int NK = p.ntaps * p.Cin;
+    float* part = p.partial + (int64_t)bz * p.Cout * NK;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int kc = by * 128 + 64 * wn + 32 * j + (lane & 31);
+        if (kc >= NK) continue;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int co = i0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (co < p.Cout) part[(int64_t)co * NK + kc] = acc[i][j][e];
+            }
+    }
+}
+
 // dW[co][cin][tap] += sum_z partial[z][co][tap*Cin + cin]   (torch weight layout; fixed summation order => deterministic).
 // One workgroup per (co, CH-channel chunk): P = ntaps*CH/4 float4 positions x ZL split lanes stream the split-K slabs with
 // 16-byte loads (the first version used 4-byte loads, 32 channel lanes x 32 split lanes: 1.9 TB/s over 5.5 GB of slabs per step,
@@ -1368,12 +1514,30 @@ extern "C" int ryolo_conv_wgrad_plan(const WgradParams* pp, int* splitk, size_t*
     return RY_OK;
 }
 
-// 0: generic split-K kernel (conv.hip), 1: 3x3 stride-1 halo-ring kernel (conv3x3.hip) — what ryolo_conv_wgrad will launch
+static bool wgrad_pointwise(const WgradParams& p)
+{
+    return p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.sh == 1 && p.sw == 1 && p.IH == p.OH && p.IW == p.OW && p.OH * p.OW > 1 &&
+           !(getenv("RYOLO_WGRAD_P1") && (atoi(getenv("RYOLO_WGRAD_P1")) & 1) == 0);
+}
+// tapped / strided layers with more than 64 output channels: the LDS-DMA ring with the gather on the request side (RYOLO_WGRAD_TAPS_DMA=0: A/B)
+static bool wgrad_taps_dma(const WgradParams& p, int bm)
+{
+    static const int on = getenv("RYOLO_WGRAD_TAPS_DMA") ? atoi(getenv("RYOLO_WGRAD_TAPS_DMA")) : 1;
+    return on && !wgrad_pointwise(p) && bm == 128 && p.zeros && ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0 &&
+           (int64_t)p.NB * p.OH * p.OW < (1ll << 31);
+}
+
+// 0: generic split-K kernels (conv.hip: register-staged, or the LDS-DMA pointwise form), 1: 3x3 stride-1 halo-ring kernel (conv3x3.hip),
+// 2: tapped LDS-DMA kernel (conv.hip) — what ryolo_conv_wgrad will launch
 extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
 {
     if (!pp || !kernel) return RY_ERR_ARG;
     W3Geom g3;
-    *kernel = w3_geometry(*pp, g3) ? 1 : 0;
+    *kernel = 0;
+    if (w3_geometry(*pp, g3)) { *kernel = 1; return RY_OK; }
+    WgradParams p = *pp;
+    int bm, gx, gy;
+    if (wgrad_geometry(p, bm, gx, gy) == RY_OK && wgrad_taps_dma(p, bm)) *kernel = 2;
     return RY_OK;
 }
 
@@ -1405,8 +1569,7 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     WgMagic mg;
     wg_magic((unsigned)(p.OH * p.OW), mg.m_img, mg.s_img);
     wg_magic((unsigned)p.OW, mg.m_row, mg.s_row);
-    const bool p1 = p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.sh == 1 && p.sw == 1 && p.IH == p.OH && p.IW == p.OW && p.OH * p.OW > 1 &&
-                    !(getenv("RYOLO_WGRAD_P1") && (atoi(getenv("RYOLO_WGRAD_P1")) & 1) == 0);
+    const bool p1 = wgrad_pointwise(p);
     const dim3 wgrid((unsigned)((int64_t)gx * gy * p.splitk));
     // pointwise layers wider than 64 output channels: the LDS-DMA ring kernel (same tiles, same slabs: bm == 128 gives gx = ceil(Cout / 128),
     // gy = ceil(Cin / 128) there too); 0x2 in RYOLO_WGRAD_P1 switches it off for A/B runs
@@ -1414,6 +1577,12 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     if (p1 && bm == 128 && (p1_mode & 2) && p.zeros && ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0) {
         if (p1_mode & 4) hipLaunchKernelGGL(wgrad1x1_dma_kernel<64>, wgrid, dim3(256), 0, stream, p);      // 0x4: 64-pixel K steps (A/B)
         else hipLaunchKernelGGL(wgrad1x1_dma_kernel<32>, wgrid, dim3(256), 0, stream, p);
+        launch_wgrad_reduce(p, p.splitk, stream);
+        RY_CHECK_LAUNCH();
+        return RY_OK;
+    }
+    if (wgrad_taps_dma(p, bm)) {
+        hipLaunchKernelGGL(wgrad_taps_dma_kernel, wgrid, dim3(256), 0, stream, p, mg);
         launch_wgrad_reduce(p, p.splitk, stream);
         RY_CHECK_LAUNCH();
         return RY_OK;

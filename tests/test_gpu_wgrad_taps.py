@@ -1,0 +1,85 @@
+"""The tapped LDS-DMA weight-gradient kernel (wgrad_taps_dma_kernel, csrc/conv.hip: stride-2 3x3 layers and every other tapped / strided
+layer with more than 64 output channels that the halo-ring kernel does not take) through the C ABI against torch's fp32 conv weight gradient
+on the same bf16 operands (model/utils.py:6-32 Conv with stride 2; model/utils.py:146-160 MaxConv's strided branch).  Odd maps (the last
+output row / column reads padding), Cin = 32 / 64 (two or four taps per 128-column tile), Cout not a multiple of 32, channel strides
+wider than the tensors, accumulation into an existing gradient, a 1x3 tap row.  Dispatch is asserted.  Tolerance 2e-3 relative (bf16
+operands, fp32 accumulation in a different order)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(B, H, W, Cin, Cout, k=(3, 3), stride=2, ldx_extra=0, ldy_extra=0, seed=0, expect=2):
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S
+    hip.lib()
+    S.check_layouts()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(seed)
+    kh, kw = k
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    OH, OW = (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
+    ldX, coutp = Cin + ldx_extra, ((Cout + 7) // 8) * 8
+    ldY = coutp + ldy_extra
+    x = torch.randn(B * H * W, ldX, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.zeros(B * OH * OW, ldY, dtype=torch.bfloat16)
+    dy[:, :Cout] = (torch.randn(B * OH * OW, Cout, generator=g) * 0.1).to(torch.bfloat16)
+    dy[:, coutp:] = 3.0                                               # neighbouring slice of a concat buffer: must be ignored
+    dy = dy.to(dev)
+    dw0 = torch.randn(Cout, Cin, kh * kw, generator=g).to(dev)
+    dw = dw0.clone()
+    zeros = torch.zeros(256, dtype=torch.uint8, device=dev)
+    p = S.WgradParams()
+    p.dY, p.ldY, p.Cout, p.CoutPad = dy.data_ptr(), ldY, Cout, coutp
+    p.X, p.NB, p.IH, p.IW, p.Cin, p.ldX = x.data_ptr(), B, H, W, Cin, ldX
+    p.OH, p.OW, p.sh, p.sw, p.ntaps = OH, OW, stride, stride, kh * kw
+    for r in range(kh):
+        for s in range(kw):
+            p.dh[r * kw + s], p.dw[r * kw + s] = r - ph, s - pw
+    p.dW, p.zeros = dw.data_ptr(), zeros.data_ptr()
+    kern, sk, ws = S.I(), S.I(), S.Z()
+    hip.call("ryolo_conv_wgrad_kernel", p, kern)
+    assert kern.value == expect, f"dispatch picked kernel {kern.value} for this shape"
+    hip.call("ryolo_conv_wgrad_plan", p, sk, ws)
+    work = torch.empty(ws.value, dtype=torch.uint8, device=dev)
+    p.partial = work.data_ptr()
+    hip.call("ryolo_conv_wgrad", p, hip.stream())
+    torch.cuda.synchronize()
+    xr = x[:, :Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    w0 = torch.zeros(Cout, Cin, kh, kw, device=dev, requires_grad=True)
+    torch.nn.functional.conv2d(xr, w0, stride=stride, padding=(ph, pw)).backward(dy[:, :Cout].float().view(B, OH, OW, Cout).permute(0, 3, 1, 2))
+    ref = w0.grad.reshape(Cout, Cin, kh * kw)
+    got = dw - dw0                                                    # the kernel ACCUMULATES into the gradient
+    assert float((got - ref).norm() / ref.norm()) < 2e-3
+    # per-tap check: a wrong tap offset on one tap hides inside a norm over nine
+    for t in range(kh * kw):
+        assert float((got[:, :, t] - ref[:, :, t]).norm() / ref[:, :, t].norm()) < 4e-3, f"tap {t}"
+    assert bool(torch.isfinite(dw).all())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (8, 64, 64, 64, 128),         # two taps per 128-column tile, last tile half empty (18 chunks)
+    (8, 50, 50, 128, 128),        # one tap per tile
+    (4, 50, 50, 256, 256),        # two output-channel tiles, two column tiles per tap
+    (16, 33, 47, 64, 72),         # odd map (last output row / column touch the padding), Cout not a multiple of 32
+    (6, 25, 25, 32, 96),          # four taps per tile, output rows shorter than a 32-pixel step
+    (2, 26, 26, 512, 512),        # the deepest stride-2 layer's shape
+])
+def test_taps_dma_wgrad_stride2_3x3(B, H, W, Cin, Cout):
+    _run(B, H, W, Cin, Cout)
+
+
+def test_taps_dma_wgrad_concat_slices():
+    _run(8, 64, 64, 64, 128, ldx_extra=96, ldy_extra=64, seed=4)
+    _run(4, 40, 40, 128, 200, ldx_extra=32, ldy_extra=16, seed=5)
+
+
+def test_taps_dma_wgrad_other_tap_sets():
+    _run(4, 40, 40, 64, 128, k=(1, 3), stride=1, seed=6)             # a 1x3 row of taps, stride 1 (not a 3x3: the ring kernel does not take it)
+    _run(4, 40, 40, 64, 128, k=(3, 3), stride=1, seed=7)             # a 3x3 stride-1 layer too small for the halo-ring kernel (conv3x3.hip: w3_geometry)
+    _run(4, 40, 40, 64, 128, k=(1, 1), stride=2, seed=8)             # strided pointwise (one tap, every other pixel)
+
+
+def test_small_cout_stays_on_the_generic_kernel():
+    _run(4, 40, 40, 32, 64, seed=9, expect=0)
