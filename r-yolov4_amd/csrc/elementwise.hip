@@ -1230,12 +1230,26 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p
 static inline unsigned grid_rows(int64_t M, int C)
 {
     const int c8 = C >> 3, cols = c8 < 256 ? c8 : 256, rpi = 256 / cols;
-    int64_t g = ry_cdiv(M, (int64_t)rpi * 4);               // >= 4 rows per thread
-    if (g > 8192) g = 8192;
+    // 4 rows per thread and NO small cap on the grid: with the 8192-workgroup cap of the first three rounds a thread of a 400^2 layer walked ~40
+    // rows that lie gridDim * rpi rows apart, the resident workgroups drifted apart and the requests in flight at any moment were scattered
+    // over the whole tensor; workgroups that each finish after 4 rows keep them inside a window that moves through memory in dispatch order:
+    // forward 5.0-5.5 -> 6.2 TB/s, backward apply 5.1-5.7 -> 6.3-7.0 TB/s isolated (tools/bench_bnact.py; 2 rows: same forward, apply -6 %;
+    // 1 row: apply 4.5 TB/s; 8 rows: -3 %).  RYOLO_EW_GRID / RYOLO_EW_ROWS: A/B knobs.
+    static const int cap = getenv("RYOLO_EW_GRID") ? atoi(getenv("RYOLO_EW_GRID")) : (1 << 20);
+    static const int rpt = getenv("RYOLO_EW_ROWS") ? atoi(getenv("RYOLO_EW_ROWS")) : 4;
+    int64_t g = ry_cdiv(M, (int64_t)rpi * rpt);
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
 }
-static inline unsigned grid_for(int64_t work_items) { int64_t g = ry_cdiv(work_items, 256); if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g; }
+static inline unsigned grid_for(int64_t work_items)
+{
+    static const int cap = getenv("RYOLO_EW_GRID2") ? atoi(getenv("RYOLO_EW_GRID2")) : 8192;     // A/B knob
+    int64_t g = ry_cdiv(work_items, 256);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
 
 // Statistics of channels [c0, c0 + C) of partial rows that are [2][ld] wide (several BatchNorms behind ONE GEMM launch: sibling
 // convolutions of a block that read the same input are emitted as one GEMM with concatenated output channels).  coeffs: this
@@ -1317,7 +1331,8 @@ extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_pe
     const int cols = c8 < 256 ? c8 : 256;
     const int nrl = 256 / cols;
     int64_t blocks = ry_cdiv(M, (int64_t)nrl * 8);                  // >= 8 rows per row lane
-    if (blocks > 4096) blocks = 4096;                               // (2048 blocks and no fold pass measured 3 ms/step slower: the reduce wants the occupancy)
+    static const int cap = getenv("RYOLO_BN_RED_BLOCKS") ? atoi(getenv("RYOLO_BN_RED_BLOCKS")) : 4096;     // A/B knob
+    if (blocks > cap) blocks = cap;                                 // (2048 blocks and no fold pass measured 3 ms/step slower: the reduce wants the occupancy)
     if (blocks < 1) blocks = 1;
     *rows_per_block = (int)ry_cdiv(M, blocks);
     *nblk = (int)ry_cdiv(M, *rows_per_block);
