@@ -254,14 +254,44 @@ def hsv_gain_numpy(img, r):
     return hsv2bgr_numpy(np.stack((lut_h[hsv[..., 0]], lut_s[hsv[..., 1]], lut_v[hsv[..., 2]]), -1))
 
 
+def area_fast_scales(src_hw, dsize):
+    """cv::resize's `is_area_fast` test (imgproc/src/resize.cpp): scale = 1 / ((double) dst / src) per axis, iscale = saturate_cast<int>(scale)
+    (round to nearest even), fast iff both |scale - iscale| < DBL_EPSILON.  Returns (iscale_x, iscale_y) for a whole-number DOWNSCALE, else None."""
+    NW, NH = dsize
+    SH, SW = src_hw
+    if NW <= 0 or NH <= 0:
+        return None
+    sx, sy = 1.0 / (float(NW) / float(SW)), 1.0 / (float(NH) / float(SH))
+    ix, iy = int(np.rint(sx)), int(np.rint(sy))
+    eps = np.finfo(np.float64).eps
+    if abs(sx - ix) < eps and abs(sy - iy) < eps and ix >= 1 and iy >= 1 and (ix > 1 or iy > 1):
+        return ix, iy
+    return None
+
+
+def resize_area_fast_numpy(src, dsize, ix, iy):
+    """OpenCV's whole-number INTER_AREA path for uint8 (cv::resizeAreaFast_): the iy x ix source block of a destination pixel is summed in
+    int; 2 x 2 blocks take the vector form (sum + 2) >> 2 (round half UP), every other block saturate_cast<uchar>(sum * (1.f / area)) — a
+    float product rounded half to EVEN.  (The generic float accumulation of resize_area_numpy differs from both in ties.)
+    PARITY UNPINNED (OpenCV absent) — restated from cv::ResizeAreaFastVec / resizeAreaFast_Invoker."""
+    NW, NH = dsize
+    s = src[:NH * iy, :NW * ix].astype(np.int64).reshape(NH, iy, NW, ix, -1).sum(axis=(1, 3))
+    if ix == 2 and iy == 2:
+        return ((s + 2) >> 2).astype(np.uint8)
+    scale = np.float32(1.0) / np.float32(ix * iy)
+    return np.clip(np.rint(s.astype(np.float32) * scale), 0, 255).astype(np.uint8)
+
+
 def resize_area_numpy(src, dsize):
     """cv2.resize(src, (w, h), interpolation = INTER_AREA) for uint8 DOWNSCALING, restated from OpenCV's generic cv::ResizeArea_: per
     axis every destination cell covers [d * scale, (d + 1) * scale) of the source — a leading partial source cell, whole cells of
     weight 1 / cellWidth, a trailing partial cell (weights in float); rows are accumulated horizontally, then vertically, in float;
-    cvRound at the end.  (OpenCV takes an integer fast path when both scale factors are whole numbers; its rounding can differ in
-    ties.)  PARITY UNPINNED (OpenCV absent, version un-pinned by the reference)."""
+    cvRound at the end.  Whole-number scale factors take OpenCV's integer path (resize_area_fast_numpy).  PARITY UNPINNED (OpenCV absent, version un-pinned by the reference)."""
     NW, NH = dsize
     SH, SW = src.shape[:2]
+    fast = area_fast_scales((SH, SW), dsize)
+    if fast is not None:
+        return resize_area_fast_numpy(src, dsize, *fast)
 
     def axis(dn, sn):
         scale = sn / dn
@@ -303,6 +333,8 @@ def resize_linear_numpy(src, dsize):
     arithmetic).  PARITY UNPINNED (OpenCV absent, version un-pinned by the reference)."""
     NW, NH = dsize
     SH, SW = src.shape[:2]
+    if area_fast_scales((SH, SW), dsize) == (2, 2):                # cv::resize: INTER_LINEAR at exactly 2x2 IS the INTER_AREA fast path
+        return resize_area_fast_numpy(src, dsize, 2, 2)
 
     def coef(dn, sn):
         o = np.arange(dn, dtype=np.float64)

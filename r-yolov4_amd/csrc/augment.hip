@@ -164,6 +164,34 @@ __global__ __launch_bounds__(256) void mixup_kernel(const uint8_t* __restrict__ 
     out[i] = (uint8_t)(int)v;
 }
 
+// cv::resize's whole-number test (`is_area_fast`, imgproc/src/resize.cpp): scale = 1 / ((double) dst / src) per axis, iscale = saturate_cast<int>
+// (round half even); both |scale - iscale| < DBL_EPSILON.  INTER_AREA downscales by whole numbers take the integer block sum, and INTER_LINEAR
+// at exactly 2 x 2 is switched to that path by OpenCV itself.  ix = iy = 0: generic path.
+__device__ __forceinline__ void area_fast_scales(int SH, int SW, int NH, int NW, int& ix, int& iy)
+{
+    const double sx = 1.0 / ((double)NW / (double)SW), sy = 1.0 / ((double)NH / (double)SH);
+    const int rx = (int)rint(sx), ry = (int)rint(sy);
+    const bool fast = fabs(sx - rx) < 2.220446049250313e-16 && fabs(sy - ry) < 2.220446049250313e-16 && rx >= 1 && ry >= 1 && (rx > 1 || ry > 1);
+    ix = fast ? rx : 0;
+    iy = fast ? ry : 0;
+}
+// cv::resizeAreaFast_ for uint8: the iy x ix block summed in int; 2 x 2 -> (sum + 2) >> 2 (the vector form: round half up), otherwise
+// saturate_cast<uchar>(sum * (1.f / area)) (float product, round half even)
+__device__ __forceinline__ void area_fast_pixel(const uint8_t* __restrict__ src, int SW, int x, int y, int ix, int iy, int* px)
+{
+    int sum[3] = {0, 0, 0};
+    for (int r = 0; r < iy; r++) {
+        const uint8_t* rp = src + ((int64_t)(y * iy + r) * SW + (int64_t)x * ix) * 3;
+        for (int q = 0; q < ix; q++)
+            for (int c = 0; c < 3; c++) sum[c] += rp[q * 3 + c];
+    }
+    if (ix == 2 && iy == 2) { for (int c = 0; c < 3; c++) px[c] = (sum[c] + 2) >> 2; }
+    else {
+        const float scale = 1.f / (float)(ix * iy);
+        for (int c = 0; c < 3; c++) px[c] = min(255, max(0, (int)rintf((float)sum[c] * scale)));
+    }
+}
+
 // Letterbox of pad_to_square (datasets/base_dataset.py:33-56): cv2.resize(img, (NW, NH), INTER_LINEAR) placed at (top, left) of an
 // OH x OW canvas filled with `fill` (cv2.copyMakeBorder, BORDER_CONSTANT).  OpenCV's 8-bit linear resize: source coordinate
 // (x + 0.5) * scale - 0.5, 11-bit coefficients (cvRound), horizontal pass in int, vertical pass ((b0 * (S0 >> 4)) >> 16) + ... + 2 >> 2.
@@ -178,6 +206,14 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     if (NH == SH && NW == SW) {                                     // `if shape[::-1] != new_unpad` — no resize
         const uint8_t* sp = src + ((int64_t)ry * SW + rx) * 3;
         d[0] = sp[0]; d[1] = sp[1]; d[2] = sp[2];
+        return;
+    }
+    int fx, fy;
+    area_fast_scales(SH, SW, NH, NW, fx, fy);
+    if (fx == 2 && fy == 2) {                                       // exactly half size: OpenCV's INTER_LINEAR is its INTER_AREA block mean here
+        int px[3];
+        area_fast_pixel(src, SW, rx, ry, 2, 2, px);
+        d[0] = (uint8_t)px[0]; d[1] = (uint8_t)px[1]; d[2] = (uint8_t)px[2];
         return;
     }
     auto coef = [](int o, int dn, int sn, int& s0, int& a0, int& a1) {
@@ -204,7 +240,8 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
 
 // ---- batched source-image stage of load_image (datasets/base_dataset.py:170-186): cv2.resize to (NW, NH) [+ hsv gain in place] for EVERY
 // source image a batch uses, one launch.  An item reads one image of the resident pool and writes its resized copy into a staging pool;
-// interp 0 = INTER_LINEAR (the 8-bit two-pass integer form of letterbox_kernel above), 1 = INTER_AREA (the float accumulation form of
+// interp 0 = INTER_LINEAR (the 8-bit two-pass integer form of letterbox_kernel above), 1 = INTER_AREA (whole-number scale factors: the integer
+// block sum of cv::resizeAreaFast_, which INTER_LINEAR at exactly 2 x 2 also takes; otherwise the float accumulation form of
 // cv::ResizeArea_: per axis a leading partial cell, whole cells of weight 1 / cellWidth, a trailing partial cell; weights and sums in
 // float, cvRound at the end), 2 = copy (r == 1: the reference skips cv2.resize).  lut >= 0: the three 256-entry tables of hsv() for this
 // image (lib/augmentations.py:8-21) are applied to the resized pixel before it is stored (resize, then hsv in place: same result).
@@ -287,6 +324,11 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
         __syncthreads();
     }
     const int64_t npix = (int64_t)it.NH * it.NW;
+    int fx = 0, fy = 0;                                             // whole-number downscale: OpenCV's integer block path (block-uniform)
+    if (it.interp != 2) {
+        area_fast_scales(it.SH, it.SW, it.NH, it.NW, fx, fy);
+        if (it.interp == 0 && !(fx == 2 && fy == 2)) fx = fy = 0;   // INTER_LINEAR only switches at exactly 2 x 2
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const int y = (int)(i / it.NW), x = (int)(i - (int64_t)y * it.NW);
         const uint8_t* src = pool + it.src_off;
@@ -294,6 +336,8 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
         if (it.interp == 2) {
             const uint8_t* sp = src + ((int64_t)y * it.SW + x) * 3;
             px[0] = sp[0]; px[1] = sp[1]; px[2] = sp[2];
+        } else if (fx) {
+            area_fast_pixel(src, it.SW, x, y, fx, fy, px);
         } else if (it.interp == 0) {
             auto coef = [](int o, int dn, int sn, int& s0, int& a0, int& a1) {
                 const double scale = (double)sn / (double)dn;

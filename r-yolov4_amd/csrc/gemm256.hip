@@ -329,7 +329,8 @@ bool g256_geometry(const ConvGemmParams& p, G256Geom& g)
         // least ~2.4 rounds of one workgroup per CU (a 256-wide tile on a 1.2-round grid idles half the chip in its second round)
         // (and 256-column tiles only: the 256 x 128 form measured 443 TF/s on 512 -> 128 @100^2 against 487 on the generic kernel — half the MFMAs
         // per barrier for the same pixel stream; it stays reachable with RYOLO_GEMM_256=2 for the tests)
-        if (p.Cin < 512 || g.gm * g.gn < 600 || g.BN != 256) return false;
+        static const int mink = [] { const char* e = getenv("RYOLO_GEMM_256_MINK"); return e ? atoi(e) : 512; }();      // A/B knob
+        if (p.Cin < mink || g.gm * g.gn < 600 || g.BN != 256) return false;
     }
     g.lds_bytes = 2u * (256u + (unsigned)g.BN) * 128u;
     return true;

@@ -146,7 +146,8 @@ def test_device_warp_and_hsv_against_numpy_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,new", [((48, 80), (64, 64)), ((64, 64), (64, 64)), ((30, 21), (96, 96)), ((100, 37), (64, 64))])
+@pytest.mark.parametrize("shape,new", [((48, 80), (64, 64)), ((64, 64), (64, 64)), ((30, 21), (96, 96)), ((100, 37), (64, 64)),
+                                       ((128, 100), (64, 64))])          # last: exactly half size (OpenCV's INTER_LINEAR -> 2 x 2 block mean)
 def test_device_letterbox_against_numpy_restatement(shape, new):
     """pad_to_square (datasets/base_dataset.py:33-56): integer plan shared with the reference's arithmetic; resize pixels restate
     OpenCV's 8-bit INTER_LINEAR (parity unpinned) and equal the numpy restatement bit for bit; the border is 114."""
@@ -166,12 +167,14 @@ def test_device_resize_hsv_batch_against_numpy_restatement():
     from oracle import ref_data
     from ryolov4_amd.datasets import augment as A
     rs = np.random.RandomState(5)
-    images = [rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in ((40, 64), (64, 48), (33, 61), (16, 16), (50, 37))]
+    images = [rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in ((40, 64), (64, 48), (33, 61), (16, 16), (50, 37), (45, 60))]
     pool = A.ImagePool(images, torch.device("cuda:0"))
     gains = [(1.01, 1.4, 0.7), (0.99, 0.5, 1.3)]
     luts = np.stack([A.hsv_luts(np.asarray(g, dtype=np.float64)) for g in gains])
     items = [(0, (20, 32), A.INTERP_LINEAR, -1), (1, (32, 24), A.INTERP_AREA, -1), (2, (17, 32), A.INTERP_AREA, 0), (3, (16, 16), A.INTERP_COPY, 1),
-             (4, (64, 47), A.INTERP_LINEAR, 1), (0, (13, 21), A.INTERP_AREA, -1), (1, (32, 24), A.INTERP_LINEAR, 0)]
+             (4, (64, 47), A.INTERP_LINEAR, 1), (0, (13, 21), A.INTERP_AREA, -1), (1, (32, 24), A.INTERP_LINEAR, 0),
+             # whole-number scale factors (cv::resizeAreaFast_): 3 x 3, 4 x 4 and 2 x 4 block sums; INTER_LINEAR at 3 x 3 stays bilinear
+             (5, (15, 20), A.INTERP_AREA, -1), (1, (16, 12), A.INTERP_AREA, 1), (1, (32, 12), A.INTERP_AREA, -1), (5, (15, 20), A.INTERP_LINEAR, -1)]
     stage, offs = A.resize_hsv_batch(pool, items, luts)
     for (img, (nh, nw), interp, lut), off in zip(items, offs):
         src = images[img]
@@ -180,3 +183,22 @@ def test_device_resize_hsv_batch_against_numpy_restatement():
             ref = ref_data.hsv_gain_numpy(ref, gains[lut])
         got = stage[off:off + nh * nw * 3].view(nh, nw, 3).cpu().numpy()
         assert np.array_equal(got, ref), (img, nh, nw, interp, lut, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+
+
+def test_whole_number_area_resize_known_answers():
+    """cv::resizeAreaFast_ restated (oracle/ref_data.py): 2 x 2 blocks round half UP ((sum + 2) >> 2), other whole-number blocks go through a
+    float product rounded half to EVEN; cv::resize switches INTER_LINEAR to that path at exactly 2 x 2 and nowhere else."""
+    from oracle import ref_data
+    a = np.array([[0, 0, 1, 1], [0, 1, 0, 0], [255, 255, 3, 3], [255, 254, 3, 2]], dtype=np.uint8)[:, :, None].repeat(3, 2)
+    exp = np.array([[0, 1], [255, 3]], dtype=np.uint8)                # sums 1, 2 (tie -> up), 1019, 11
+    assert np.array_equal(ref_data.resize_area_numpy(a, (2, 2))[:, :, 0], exp)
+    assert np.array_equal(ref_data.resize_linear_numpy(a, (2, 2))[:, :, 0], exp)
+    b = np.zeros((4, 8, 3), dtype=np.uint8)
+    b[:, :4] = 1                                                       # 4 x 4 block of ones -> 1; second block: a single 8 -> sum 8 / 16 = 0.5 -> even -> 0
+    b[0, 4] = 8
+    assert ref_data.area_fast_scales((4, 8), (2, 1)) == (4, 4)
+    assert ref_data.resize_area_numpy(b, (2, 1))[0, :, 0].tolist() == [1, 0]
+    b[0, 5] = 16                                                       # sum 24 / 16 = 1.5 -> even -> 2
+    assert ref_data.resize_area_numpy(b, (2, 1))[0, :, 0].tolist() == [1, 2]
+    assert ref_data.area_fast_scales((1601, 1200), (600, 800)) is None and ref_data.area_fast_scales((1600, 1200), (600, 800)) == (2, 2)
+    assert ref_data.area_fast_scales((64, 64), (64, 64)) is None       # r == 1 never reaches cv2.resize; not a "downscale" here either
