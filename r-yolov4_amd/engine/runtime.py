@@ -48,7 +48,10 @@ class Runtime:
         # BatchNorm-backward reduce pass folded into the epilogue of the data-gradient launch that completes the activation gradient
         self.fuse_bn_reduce = os.environ.get("RYOLO_FUSE_BN_REDUCE", "1") != "0"
         self.fuse_bn_kernels = int(os.environ.get("RYOLO_FUSE_BN_KERNELS", "3"))      # bit 0: generic GEMM launches, bit 1: 3x3 halo-patch launches
-        self.fuse_bn_max_elems = int(float(os.environ.get("RYOLO_FUSE_BN_MAX_ELEMS", "32e6")))   # only launches with M * N up to this: the fold pays where the stand-alone reduce is latency-bound (A/B in DESIGN.md)
+        # only launches with M * N up to this fold the sums.  Default 0 = no launch does (r04): with the reduce pass at 5 waves per SIMD and one row
+        # of read-ahead the stand-alone pass beats the fold at every size (8-image step 513 vs 506.5 img/s at the old 32e6 gate, 3 alternating runs
+        # each on one box; 64 images equal); the fold stays parity-tested and reachable (tests/test_gpu_bnfuse.py, A/B in DESIGN.md)
+        self.fuse_bn_max_elems = int(float(os.environ.get("RYOLO_FUSE_BN_MAX_ELEMS", "0")))
         self.buffer_reuse = os.environ.get("RYOLO_BUFFER_REUSE", "1") != "0"
         self.wgrad_lanes = int(os.environ.get("RYOLO_WGRAD_LANES", "1"))          # weight gradients round-robin over this many side streams
         self.wgrad_lag = int(os.environ.get("RYOLO_WGRAD_LAG", "8"))             # weight gradients the side stream may fall behind by

@@ -24,6 +24,7 @@ def _grads(ver, mode, fuse, frozen, B=4, S=192):
         m.frozen_bn = True
     rt = m.runtime(DEV)
     rt.fuse_bn_reduce = fuse
+    rt.fuse_bn_max_elems = int(1e12) if fuse else 0              # (the fold is off by default since r04: runtime.py)
     imgs, tg = synth_batch(B, S, 16, mode == "csl", seed=5)
     imgs, tg = imgs.to(DEV), tg.to(DEV)
     crit = (ComputeCSLLoss if mode == "csl" else ComputeKFIoULoss)(m, HYP)
