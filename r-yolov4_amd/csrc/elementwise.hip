@@ -1331,8 +1331,11 @@ extern "C" int ryolo_bn_act_bwd_blocks(int64_t M, int C, int* nblk, int* rows_pe
     const int cols = c8 < 256 ? c8 : 256;
     const int nrl = 256 / cols;
     int64_t blocks = ry_cdiv(M, (int64_t)nrl * 8);                  // >= 8 rows per row lane
-    static const int cap = getenv("RYOLO_BN_RED_BLOCKS") ? atoi(getenv("RYOLO_BN_RED_BLOCKS")) : 4096;     // A/B knob
-    if (blocks > cap) blocks = cap;                                 // (2048 blocks and no fold pass measured 3 ms/step slower: the reduce wants the occupancy)
+    // 1280 = 5 resident workgroups x 256 CUs: one round of workgroups, each walking one contiguous run of rows, and a third of the partial rows
+    // for the finalize kernel (r04 kernel, same box, alternating runs: 856 img/s at 1280 vs 853 at 4096 / 2560 / 2048, 850 at 640; with the r02
+    // kernel — 3 waves per SIMD, no read-ahead — 2048 blocks had been 3 ms/step slower than 4096).  RYOLO_BN_RED_BLOCKS: A/B knob.
+    static const int cap = getenv("RYOLO_BN_RED_BLOCKS") ? atoi(getenv("RYOLO_BN_RED_BLOCKS")) : 1280;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     *rows_per_block = (int)ry_cdiv(M, blocks);
     *nblk = (int)ry_cdiv(M, *rows_per_block);
