@@ -12,6 +12,8 @@ last $O/prof_b64.json > $P/${TAG}_bench_b64_under_rocprofv3_serialized.json
 cp gpurun_out/${TAG}_pmc_step_traffic.json $P/${TAG}_pmc_step_traffic.json
 cp $O/per_launch_b64.txt $P/${TAG}_per_launch_table_b64.txt
 cp $O/per_launch_b8.txt $P/${TAG}_per_launch_table_b8.txt
+cp $O/bnact_passes.txt $P/${TAG}_bnact_passes.txt
+( cat $O/power_clocks_bench.txt; echo; cat $O/power_clocks.txt ) > $P/${TAG}_power_clocks.txt
 cp $O/nms_times.json $P/${TAG}_nms_times.json
 cp $O/infer.json $P/${TAG}_infer_yolov7_kfiou_800.json
 cp $O/infer_1024_b8.json $P/${TAG}_infer_yolov7_kfiou_1024_b8_graph.json
