@@ -1489,7 +1489,9 @@ static int wgrad_geometry(WgradParams& p, int& bm, int& gx, int& gy)
     bm = p.Cout <= 64 ? 64 : 128;
     gx = (int)ry_cdiv(p.Cout, bm);
     gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), 4);
-    static const int target = getenv("RYOLO_WGRAD_BLOCKS") ? atoi(getenv("RYOLO_WGRAD_BLOCKS")) : 768;   // = 3 resident workgroups x 256 CUs (measured best of 768/1024/1536/2560); env knob for A/B runs
+    // 512 = 2 workgroups x 256 CUs (r04: +0.4 % step over 768, a third fewer split-K slabs; 384 equal, 256 -0.8 %; r01-r03 measured 768 best of
+    // 768 / 1024 / 1536 / 2560 against the BatchNorm kernels of those rounds); env knob for A/B runs
+    static const int target = getenv("RYOLO_WGRAD_BLOCKS") ? atoi(getenv("RYOLO_WGRAD_BLOCKS")) : 512;
     int64_t want = ry_cdiv(target, (int64_t)gx * gy);                // one full wave of resident workgroups by default
     int64_t maxsplit = ry_cdiv(M, 16 * BK);                          // at least 16 K-steps per split
     int64_t sk = want > maxsplit ? maxsplit : want;

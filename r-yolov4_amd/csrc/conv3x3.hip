@@ -1123,7 +1123,10 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.gx = (int)ry_cdiv(p.Cout, 128);
     g.gc = p.Cin / 32;
     if (g.Mp >= (1ll << 31)) return false;                        // 32-bit stream coordinates
-    static const int w3_target = getenv("RYOLO_W3_BLOCKS") ? atoi(getenv("RYOLO_W3_BLOCKS")) : 512;   // 2 resident workgroups x 256 CUs (A/B knob)
+    // one workgroup per CU (r04; 512 = two per CU until then): with the BatchNorm passes at 5-8 waves per SIMD on the main stream the side stream
+    // does better with fewer, longer workgroups (half the split-K slabs, prologue amortised over twice the steps): same-box step 863 -> 874 img/s
+    // at 256, 868 at 128 / 192, 860 at 768 (A/B knob)
+    static const int w3_target = getenv("RYOLO_W3_BLOCKS") ? atoi(getenv("RYOLO_W3_BLOCKS")) : 256;
     int64_t sk = ry_cdiv(w3_target, (int64_t)g.gx * g.gc);
     static const int minsteps = getenv("RYOLO_W3_MINSTEPS") ? atoi(getenv("RYOLO_W3_MINSTEPS")) : 24;   // measured 24 / 48 / 128: shorter splits fill the chip, the two-halo prologue still amortises
     const int64_t maxsplit = g.Mp / ((int64_t)minsteps * 32);      // K-steps per split: the ring prologue (2 halos) must amortise

@@ -352,15 +352,17 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
     }
 }
 
-// RYOLO_GEMM_WS: 0 off (DEFAULT), 1 grids with >= 6 tiles per wave, 2 every eligible grid (parity tests on small grids).
-// Off by default because of what the measurements said: isolated on random data the kernel is 11-21 % faster than
+// RYOLO_GEMM_WS: 0 off, 1 grids with >= 6 tiles per wave (DEFAULT since the end of r04), 2 every eligible grid (parity tests on small grids).
+// It was off through r03 and most of r04 because of what the measurements said then: isolated on random data the kernel is 11-21 % faster than
 // the generic one on every K <= 256 layer shape of yolov7 (tools/bench_conv.py), but inside the training plan those launches run at
 // 4.3-5.2 TB/s on either kernel (HBM-bound; the sum over the 16 eligible launches is 3.84 vs 3.97 ms) and a workgroup that owns a whole CU
 // (160 KiB LDS) cannot share it with the weight-gradient stream: the step is 0.4 % SLOWER (770.1 vs 773.4 img/s, alternating same-box
 // runs); inference at batch 64 gains 1 %.
 static int ws_mode()
 {
-    static const int m = getenv("RYOLO_GEMM_WS") ? atoi(getenv("RYOLO_GEMM_WS")) : 0;
+    // on by size since the end of r04: with 512 / 256 weight-gradient workgroups on the side stream (conv.hip, conv3x3.hip) the step gains 0.25 %
+    // from it (three alternating same-box comparisons); with 768 / 512 it lost 0.4 % (above)
+    static const int m = getenv("RYOLO_GEMM_WS") ? atoi(getenv("RYOLO_GEMM_WS")) : 1;
     return m;
 }
 
