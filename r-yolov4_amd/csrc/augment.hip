@@ -64,6 +64,17 @@ __global__ __launch_bounds__(256) void paste_rects_kernel(const uint8_t* __restr
     }
 }
 
+// Two horizontally adjacent BGR pixels (6 bytes) as ONE unaligned 8-byte load (hipcc emits a single global_load_dwordx2 for it on gfx950); the
+// caller guarantees 8 readable bytes (pixel index + 3 <= pixels of the image).  Per-channel byte loads made the bilinear kernels request-bound:
+// 12 loads per output pixel for 4 taps x 3 channels, now 2.
+__device__ __forceinline__ unsigned long long load_px2(const uint8_t* p)
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ int px2_byte(unsigned long long v, int k) { return (int)((v >> (8 * k)) & 255ull); }
+
 // dst[b] = warpPerspective(src[b], M[b]) with flags INTER_LINEAR, borderMode CONSTANT, borderValue (114, 114, 114).
 // Minv [B][9] double: the INVERSE of the matrix the caller passed to cv2.warpPerspective (OpenCV inverts it itself).
 __global__ __launch_bounds__(256) void warp_perspective_kernel(const uint8_t* __restrict__ src, int SH, int SW, const double* __restrict__ Minv,
@@ -98,6 +109,16 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const uint8_t* __
     }
     const uint8_t* sb = src + (int64_t)b * SH * SW * 3;
     uint8_t* d = dst + (((int64_t)b * DH + y) * DW + x) * 3;
+    if (sx >= 0 && sx + 1 < SW && sy >= 0 && sy + 1 < SH && (int64_t)(sy + 1) * SW + sx + 3 <= (int64_t)SH * SW) {
+        // all four taps inside the image (and 8 readable bytes behind the lower pair): the same integer sums from two 8-byte loads
+        const unsigned long long r0 = load_px2(sb + ((int64_t)sy * SW + sx) * 3), r1 = load_px2(sb + ((int64_t)(sy + 1) * SW + sx) * 3);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int acc = px2_byte(r0, c) * w[0] + px2_byte(r0, c + 3) * w[1] + px2_byte(r1, c) * w[2] + px2_byte(r1, c + 3) * w[3];
+            d[c] = (uint8_t)((acc + (1 << 14)) >> 15);
+        }
+        return;
+    }
     for (int c = 0; c < 3; c++) {
         int acc = 0;
         for (int k = 0; k < 4; k++) {
@@ -324,13 +345,19 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
         __syncthreads();
     }
     const int64_t npix = (int64_t)it.NH * it.NW;
+    __shared__ uint8_t slut[768];                                   // this image's three hsv tables: three scattered GLOBAL byte reads per pixel otherwise
+    if (it.lut >= 0) {
+        for (int t = threadIdx.x; t < 768; t += 256) slut[t] = luts[(int64_t)it.lut * 768 + t];
+        __syncthreads();
+    }
     int fx = 0, fy = 0;                                             // whole-number downscale: OpenCV's integer block path (block-uniform)
     if (it.interp != 2) {
         area_fast_scales(it.SH, it.SW, it.NH, it.NW, fx, fy);
         if (it.interp == 0 && !(fx == 2 && fy == 2)) fx = fy = 0;   // INTER_LINEAR only switches at exactly 2 x 2
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
-        const int y = (int)(i / it.NW), x = (int)(i - (int64_t)y * it.NW);
+    // (pixel index in 32 bits: the host rejects images of 2^31 pixels; a 64-bit division per pixel was a third of this kernel's instructions)
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)npix; i += gridDim.x * 256u) {
+        const int y = (int)(i / (unsigned)it.NW), x = (int)(i - (unsigned)y * (unsigned)it.NW);
         const uint8_t* src = pool + it.src_off;
         int px[3];
         if (it.interp == 2) {
@@ -354,6 +381,15 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
             coef(x, it.NW, it.SW, sx, ax0, ax1);
             coef(y, it.NH, it.SH, sy, by0, by1);
             const int sx1 = min(sx + 1, it.SW - 1), sy1 = min(sy + 1, it.SH - 1);
+            if (sx1 == sx + 1 && (int64_t)sy1 * it.SW + sx + 3 <= (int64_t)it.SH * it.SW) {      // the pair of each row in one 8-byte load (load_px2)
+                const unsigned long long q0 = load_px2(src + ((int64_t)sy * it.SW + sx) * 3), q1 = load_px2(src + ((int64_t)sy1 * it.SW + sx) * 3);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int r0 = px2_byte(q0, c) * ax0 + px2_byte(q0, c + 3) * ax1;
+                    const int r1 = px2_byte(q1, c) * ax0 + px2_byte(q1, c + 3) * ax1;
+                    px[c] = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                }
+            } else
             for (int c = 0; c < 3; c++) {
                 const int r0 = src[((int64_t)sy * it.SW + sx) * 3 + c] * ax0 + src[((int64_t)sy * it.SW + sx1) * 3 + c] * ax1;
                 const int r1 = src[((int64_t)sy1 * it.SW + sx) * 3 + c] * ax0 + src[((int64_t)sy1 * it.SW + sx1) * 3 + c] * ax1;
@@ -375,8 +411,8 @@ __global__ __launch_bounds__(256) void resize_hsv_batch_kernel(const uint8_t* __
             if (ay.has_hi) row(ay.hi, ay.whi);
             for (int c = 0; c < 3; c++) px[c] = min(255, max(0, (int)rintf(acc[c])));
         }
-        if (it.lut >= 0) hsv_lut_pixel(px[0], px[1], px[2], luts + (int64_t)it.lut * 768, divtab);
-        uint8_t* d = stage + it.dst_off + i * 3;
+        if (it.lut >= 0) hsv_lut_pixel(px[0], px[1], px[2], slut, divtab);
+        uint8_t* d = stage + it.dst_off + (int64_t)i * 3;
         d[0] = (uint8_t)px[0]; d[1] = (uint8_t)px[1]; d[2] = (uint8_t)px[2];
     }
 }
@@ -388,8 +424,10 @@ extern "C" int ryolo_resize_hsv_batch(const uint8_t* pool, const void* items_dev
 {
     if (nitems < 0 || max_pixels < 0) return RY_ERR_ARG;
     if (nitems == 0 || max_pixels == 0) return RY_OK;
-    if (!pool || !items_dev || !stage || nitems > 65535) return RY_ERR_ARG;
-    const int64_t bx = ry_cdiv(max_pixels, 256);
+    if (!pool || !items_dev || !stage || nitems > 65535 || max_pixels >= (1ll << 31)) return RY_ERR_ARG;
+    // 8 pixels per thread: a workgroup's set-up (the hsv division tables: two double-precision divisions per thread; the whole-number test; the LUT
+    // copy) cost more than its 1-2 pixels per thread did with one workgroup per 256 pixels
+    const int64_t bx = ry_cdiv(max_pixels, 256 * 8);
     hipLaunchKernelGGL(resize_hsv_batch_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)nitems), dim3(256), 0, stream, pool,
                        reinterpret_cast<const ResizeItem*>(items_dev), luts, stage);
     RY_CHECK_LAUNCH();

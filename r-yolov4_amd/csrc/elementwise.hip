@@ -914,6 +914,7 @@ __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __res
 // ImplicitM, of dout*pre.  One workgroup = one image x HEAD_CPB cells, walked as sub-tiles of TC cells staged in LDS; the column sums
 // live in registers across the sub-tiles (4 channels x every other cell per thread), one partial row per workgroup as before.
 #define HEAD_CPB 128
+template <int MAXQ>                                           // channel quads per thread of the column sums: 1 (C <= 512: every head of the reference) or 4 (C <= 2048)
 __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, int ldp,
                                                               const float* __restrict__ mul, int B, int gs, int na, int attrs, int TC,
                                                               bf16_t* __restrict__ dpre, int ldd, float* __restrict__ partial /*[nblk][2][C]*/)
@@ -929,7 +930,6 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
     // column sums: thread (cl, c4) owns channels 4*c4 .. 4*c4+3 of the cells with (cell & 1) == cl; loop when C > 512
     const int c4n = (C + 3) >> 2;
     const int cl = threadIdx.x & 1, c4l = threadIdx.x >> 1;       // 128 channel-quad lanes x 2 cell lanes
-    constexpr int MAXQ = 4;                                       // C <= 2048
     float sb[MAXQ][4], sm[MAXQ][4];
 #pragma unroll
     for (int j = 0; j < MAXQ; j++)
@@ -1479,7 +1479,9 @@ extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ld
     if (C > 2048) return RY_ERR_UNSUPPORTED;
     const int TC = head_tile_cells(C);
     const size_t lds = ((size_t)TC * (C + 1) + C) * sizeof(float);
-    hipLaunchKernelGGL(head_finish_bwd_kernel, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch);
+    // (with four quads per thread compiled in for every C the kernel held 179 VGPRs = 2 waves per SIMD)
+    if (C <= 512) hipLaunchKernelGGL(head_finish_bwd_kernel<1>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch);
+    else hipLaunchKernelGGL(head_finish_bwd_kernel<4>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch);
     const float* part = fold_rows(scratch, rows, 2 * C, scratch + (int64_t)rows * 2 * C, stream);
     hipLaunchKernelGGL(head_grad_rows_kernel, dim3((unsigned)ry_cdiv(2 * C, 256)), dim3(256), 0, stream, part, rows, C, dbias, mul ? dmul : nullptr);
     RY_CHECK_LAUNCH();

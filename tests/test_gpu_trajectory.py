@@ -9,10 +9,16 @@ multiplying the initial weights by (1 + 1e-3 N(0,1)) — a perturbation 4x small
 (On another host CPU the perturbed runs end at 1.10 / 1.13: the BLAS summation order is one more such perturbation.)  The unperturbed
 fp32 run is ONE member of that family, not its centre, so it is not a curve a bf16 path can be held to point by point.  The test
 therefore builds the family on the host it runs on — exact fp32, the bf16-storage-emulating oracle (tests/bf16_emu.py), exact fp32
-from two 1e-3-perturbed weight sets — and asserts that every step of the HIP curve lies inside its envelope widened by BAND (5 %),
+from FOUR 1e-3-perturbed weight sets — and asserts that every step of the HIP curve lies inside its envelope widened by BAND (5 %),
 that it falls by at least a third, and that the size of the total parameter update matches the oracle's (0.8 ... 1.25).  The
 distance to the unperturbed curve and the update cosines are reported (gpurun_out/r03_trajectory.json), not asserted; the per-node
-parity of the same plan is tests/test_gpu_teacher_forced.py."""
+parity of the same plan is tests/test_gpu_teacher_forced.py.
+
+r04: with two perturbed members the envelope was a sample of four curves of a distribution that spreads 45 % at step 40, and a legitimate
+re-ordering of fp32 sums on the device (the BatchNorm-backward sums taken by the stand-alone reduce pass instead of the GEMM epilogue,
+1280 instead of 4096 partial rows) moved the SGD curve from 0.6 % to 5.2 % outside it at one step — while moving it CLOSER to the unperturbed
+fp32 curve (max distance 0.285 -> 0.109, head-update cosine 0.85 -> 0.92); restoring that summation order restores the old curve bit for
+bit.  The family now has four perturbed members; BAND is unchanged."""
 import json
 import os
 
@@ -27,6 +33,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAND = 0.05
+PERTURBED_SEEDS = (1, 2, 3, 4)      # r04: four perturbed members (two until then — see the module docstring)
 
 
 def weights_init_normal(m):                                      # train.py:28-33
@@ -93,7 +100,7 @@ def test_loss_trajectory_follows_the_oracle(opt_name, steps):
     emu = ref_model.Yolo(nc, CFG, mode, ver)
     emu.load_state_dict(sd0)
     family["bf16_emulation"] = oracle_run(emulate_bf16(emu))
-    for seed in (1, 2):
+    for seed in PERTURBED_SEEDS:
         pert = ref_model.Yolo(nc, CFG, mode, ver)
         pert.load_state_dict(sd0)
         gen = torch.Generator().manual_seed(seed)

@@ -20,10 +20,12 @@ B=64 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/prof
 B=8 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b8.txt 2>&1
 # 4b. BatchNorm + activation passes alone (forward, backward reduce + finalize, backward apply) and socket power / clocks while the step runs
 timeout 300 python tools/bench_bnact.py 10 > $O/bnact_passes.txt 2>&1
-( for i in $(seq 1 100); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power \(W\)" | sed 's/=*//g' | tr -s ' \t' ' ' | tr '\n' ' '; echo; sleep 0.25; done ) > $O/power_clocks.txt 2>&1 &
+set +x
+( for i in $(seq 1 100); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power \(W\)" | sed 's/=*//g' | tr -s ' \t' ' ' | tr '\n' ' '; echo; sleep 0.25; done ) > $O/power_clocks.txt 2>/dev/null &
 SMI=$!
 timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-b8 --no-loader 2>/dev/null | tail -1 | cut -c1-160 > $O/power_clocks_bench.txt
 kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
+set -x
 rocm-smi --showmaxpower 2>/dev/null | grep -i "power" >> $O/power_clocks.txt
 # 5. NMS, inference
 timeout 600 python tools/time_nms.py > $O/nms.txt 2>&1; cp gpurun_out/nms_times.json $O/nms_times.json
