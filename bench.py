@@ -450,11 +450,18 @@ def main():
             fm, fh = tf / MFMA_BF16_PEAK_TFLOPS, gb / HBM_PEAK_GBS
             head = ({"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fh, 4)} if fh > fm else
                     {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fm, 4)})
-            return {"kernel": k, **head, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
-                    "algorithmic_bytes_per_launch": int(v["bytes"] / max(1, v["launches"])), "traffic": pmc.get(k),
-                    "launches_per_step": v["launches"] // steps,
-                    "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
-                    "share_of_step": round(v["seconds"] / dt_inst, 4)}
+            out = {"kernel": k, **head, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                   "algorithmic_bytes_per_launch": int(v["bytes"] / max(1, v["launches"])), "traffic": pmc.get(k),
+                   "launches_per_step": v["launches"] // steps,
+                   "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
+                   "share_of_step": round(v["seconds"] / dt_inst, 4)}
+            if "wgrad" in k:
+                # weight gradients run on the side stream of the timed step and are SIZED for that (one / two workgroups per CU since r04: the
+                # other wave slots belong to the main stream's kernels); this instrumented pass times every launch ALONE on the GPU
+                out["note"] = ("side-stream kernel sized for co-residency with the main stream (RYOLO_W3_BLOCKS=256 / RYOLO_WGRAD_BLOCKS=512: "
+                               "one / two workgroups per CU); timed alone here — at two / three per CU the same class is faster alone "
+                               "(ring: 7.2 ms, 788 TF/s) and the step 1.3 % slower (DESIGN.md section 3)")
+            return out
         res = {"roofline": roof(*max(summ.items(), key=lambda kv: kv[1]["seconds"]))}     # dominant kernel class by time
         # BASELINE.json north_star quotes the MFMA fraction of the 3x3 convs separately: the halo-patch kernel (fwd + dgrad)
         k33 = "conv3x3_patch_kernel<256x128>"

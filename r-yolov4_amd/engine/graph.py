@@ -233,6 +233,10 @@ class Graph:
             if fam == 1:
                 return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl, by)
             if fam == 2:
+                # plain pointwise launches of the persistent kernel (on by size since r04) belong to the K <= 256 / K > 256 split of bench.py
+                # like the generic kernel's 1x1 instantiation; its tapped / pool-gradient instantiations do not
+                if p.nclasses == 1 and p.cls[0].ntaps == 1 and not p.s2d_cin and not p.pool_idx:
+                    return ("gemm1x1_ws_kernel", fl, by, "K<=256" if p.Cin <= 256 else "K>256")
                 return ("gemm1x1_ws_kernel", fl, by)
             if fam == 3:
                 return ("conv3x3_ws64_kernel", fl, by)
