@@ -1575,7 +1575,9 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
     const dim3 wgrid((unsigned)((int64_t)gx * gy * p.splitk));
     // pointwise layers wider than 64 output channels: the LDS-DMA ring kernel (same tiles, same slabs: bm == 128 gives gx = ceil(Cout / 128),
     // gy = ceil(Cin / 128) there too); 0x2 in RYOLO_WGRAD_P1 switches it off for A/B runs
-    static const int p1_mode = getenv("RYOLO_WGRAD_P1") ? atoi(getenv("RYOLO_WGRAD_P1")) : 3;      // bit 0 pointwise addressing, bit 1 the LDS-DMA kernel, bit 2 its 64-pixel steps
+    // bit 0 pointwise addressing, bit 1 the LDS-DMA kernel, bit 2 its 64-pixel steps (on since the end of r04: with two workgroups per CU on the side
+    // stream — wgrad_geometry — the two-stage 64-pixel form is +0.45 % on the step, three alternating runs; at three per CU, r03, it was neutral)
+    static const int p1_mode = getenv("RYOLO_WGRAD_P1") ? atoi(getenv("RYOLO_WGRAD_P1")) : 7;
     if (p1 && bm == 128 && (p1_mode & 2) && p.zeros && ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0) {
         if (p1_mode & 4) hipLaunchKernelGGL(wgrad1x1_dma_kernel<64>, wgrid, dim3(256), 0, stream, p);      // 0x4: 64-pixel K steps (A/B)
         else hipLaunchKernelGGL(wgrad1x1_dma_kernel<32>, wgrid, dim3(256), 0, stream, p);

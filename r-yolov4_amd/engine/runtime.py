@@ -30,7 +30,9 @@ class Runtime:
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)       # source of padded rows for the LDS-DMA GEMM loop
         # bits 0-7: generic mainloop (1 LDS-DMA ring [default], 0 register staged);
         # 0x200: 3x3 stride-1 layers run the halo-patch kernel (csrc/conv3x3.hip)
-        self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200)), 0)
+        # 0x100 (32-channel stages only in the generic tapped GEMM) is part of the default since the end of r04: the 64-channel stages (0x201) were
+        # +1-2 % on their launches against the r02 side stream; with the lighter side stream of r04 the smaller LDS footprint wins (+0.5 % step, 3 runs)
+        self.gemm_pipe = int(os.environ.get("RYOLO_GEMM_PIPE", str(1 | 0x200 | 0x100)), 0)
         self.fuse_stem_bn = os.environ.get("RYOLO_FUSE_STEM_BN", "1") != "0"      # BN + act backward applied inside the stem wgrad kernel
         # 3x3 stride-1 first layer (yolov4 / yolov7): the raw conv output is never stored — statistics pass + fused BN/activation
         # forward, and ONE backward pass over dz that recomputes it from the image (csrc/stem.hip: stem3x3_bwd_kernel)
