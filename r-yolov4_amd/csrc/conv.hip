@@ -694,11 +694,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
     // Infinity-Cache traffic for a 3x3 layer — the kernel ran at the speed of its loads (ablation in DESIGN.md).
     const int cchunks = p.Cin / BK;
     const int nchunks = p.ntaps * cchunks;
-    const int gx = (p.Cout + BM - 1) / BM, gy = (nchunks + 3) / 4;
+    // chunks per column tile: 4, or 3 = ONE KERNEL ROW per tile for a 3x3 layer with 32 input channels and <= 64 output channels (the 32 -> 64
+    // stride-2 layer at 800 -> 400; wgrad_row_tiles on the host).  With 4 the nine taps split 4 / 4 / 1: the three tiles of a pixel range ran at
+    // different speeds, nothing they read was shared in L2, and the launch moved 9.1 GB for 3.9 GB of operands (PMC).  Row tiles do equal work on
+    // the same dY rows at the same time, and a tile's three taps are three ADJACENT input pixels of one input row.
+    const int CPT = (BM == 64 && p.ntaps == 9 && cchunks == 1) ? 3 : 4;
+    const int gx = (p.Cout + BM - 1) / BM, gy = (nchunks + CPT - 1) / CPT;
     const int t_id = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = t_id % gx, by = (t_id / gx) % gy, bz = t_id / (gx * gy);
     const int i0 = bx * BM;                            // output-channel block
-    const int q0 = by * 4;                             // first 32-wide column chunk (tap-major, then cin)
+    const int q0 = by * CPT;                           // first 32-wide column chunk (tap-major, then cin)
     const int64_t kbeg = (int64_t)bz * p.kchunk;
     const int64_t kend = min(M, kbeg + p.kchunk);
     if (kbeg >= kend) return;
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
     for (int u = 0; u < 2; u++) {
         const int id = tid + 256 * u;
         const int q = q0 + (id >> 7);
-        b_chunk_ok[u] = q < nchunks;
+        b_chunk_ok[u] = (id >> 7) < CPT && q < nchunks;
         const int qq = b_chunk_ok[u] ? q : 0;
         b_tap[u] = qq / cchunks;
         b_c0[u] = (qq - b_tap[u] * cchunks) * BK + (id & 3) * 8;
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
     for (int j = 0; j < TN; j++) {
         const int col = wn * (BN / WN) + j * 32 + (lane & 31);
         const int q = q0 + (col >> 5);
-        if (q >= nchunks) continue;
+        if ((col >> 5) >= CPT || q >= nchunks) continue;
         const int kc = q * BK + (col & 31);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
@@ -1488,7 +1493,8 @@ static int wgrad_geometry(WgradParams& p, int& bm, int& gx, int& gy)
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     bm = p.Cout <= 64 ? 64 : 128;
     gx = (int)ry_cdiv(p.Cout, bm);
-    gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), 4);
+    const int cpt = (bm == 64 && p.ntaps == 9 && p.Cin == BK) ? 3 : 4;      // conv_wgrad_kernel<64>: one kernel row per column tile
+    gy = (int)ry_cdiv((int64_t)p.ntaps * (p.Cin / BK), cpt);
     // 512 = 2 workgroups x 256 CUs (r04: +0.4 % step over 768, a third fewer split-K slabs; 384 equal, 256 -0.8 %; r01-r03 measured 768 best of
     // 768 / 1024 / 1536 / 2560 against the BatchNorm kernels of those rounds); env knob for A/B runs
     static const int target = getenv("RYOLO_WGRAD_BLOCKS") ? atoi(getenv("RYOLO_WGRAD_BLOCKS")) : 512;
