@@ -136,13 +136,16 @@ int ryolo_conv_gemm(const ConvGemmParams* p, ryolo_stream_t stream);
 int ryolo_conv_gemm_stats_rows(int64_t M, int Nout, int pipe, int* rows);
 /* which kernel ryolo_conv_gemm runs for *p and the number of partial-statistics rows its epilogue 1 writes; `kernel` may be null.
  * *kernel & 0xff: 0 generic implicit GEMM, 1 the 3x3 stride-1 halo-patch kernel (pipe bit 0x200, eligible layers), 2 the weight-stationary
- * persistent 1x1 kernel (RYOLO_GEMM_WS); for 0 also bit 0x100 = the 1x1 instantiation, bits 12-15 = tile rows / 64, bits 16-19 = tile columns / 32 */
+ * persistent 1x1 kernel (RYOLO_GEMM_WS and its tapped / pool-gradient instantiations), 3 the persistent weight-stationary 3x3 kernel for 64 -> <= 64
+ * channels (conv3x3_ws.hip), 4 the 256-wide 8-wave pointwise kernel (gemm256.hip; bits 16-19 = tile columns / 32); for 0 also bit 0x100 = the 1x1
+ * instantiation, bits 12-15 = tile rows / 64, bits 16-19 = tile columns / 32 */
 int ryolo_conv_gemm_plan(const ConvGemmParams* p, int* stats_rows, int* kernel);
 /* weight gradient: split-K over output pixels into p->partial ([splitk][Cout][taps*Cin] fp32, size from _plan), then a
  * deterministic reduction that accumulates into the torch-layout .grad [Cout][Cin][kh*kw] (no float atomics). */
 int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_bytes);
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
-/* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K, 1 the 3x3 stride-1 halo-ring kernel (needs p->zeros) */
+/* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K (register-staged, or the LDS-DMA pointwise form), 1 the 3x3 stride-1 halo-ring
+ * kernel (needs p->zeros), 2 the tapped LDS-DMA kernel (tapped / strided layers with > 64 output channels; needs p->zeros) */
 int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
 /* weights of a stride-2 3x3 (pad 1) data gradient in its space-to-depth form (ConvGemmParams.s2d_cin): w fp32 [Cout][Cin][3][3] ->
  * out bf16 [4 * Cin][4][round_up(Cout, 32)] */
