@@ -159,6 +159,11 @@ def _cpu_baseline_worker(ver, mode, nc, size, threads, budget_s):
     """Child process: the oracle restatement's training step on the host cores; prints one JSON line."""
     from oracle import ref_model, ref_ops
     from ryolov4_amd.synth import CFG, HYP, synth_batch
+    if hasattr(os, "sched_setaffinity"):                       # the parent may be pinned to its GPU's cores (parallel.bind_rank): the baseline is not
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
+        except OSError:
+            pass
     torch.set_num_threads(threads)
     torch.manual_seed(42)
     net = ref_model.Yolo(nc, CFG, mode, ver)
@@ -185,36 +190,33 @@ def _cpu_baseline_worker(ver, mode, nc, size, threads, budget_s):
 
 def cpu_baseline(args, budget_s=20.0):
     """The oracle restatement (oracle/ref_model.py + ref_ops.py, pinned to the imported reference by the golden fixtures) doing the
-    same training step on the host cores, as BASELINE.md §3 / SURVEY §8(d) prescribe: fp32, batch 2, torch.set_num_threads(
-    os.cpu_count()), SGD nesterov; one untimed step, then steps until ~budget_s is spent, best step reported.  BOUNDED: each attempt is a
-    child process with a hard time limit — on the 256-thread GPU hosts torch-CPU's convolution backward is oversubscribed at
-    os.cpu_count() threads (one batch-2 step took ~300 s in the first r02 run, 0.007 img/s) and would turn this benchmark into a
-    ten-minute job; a second attempt with 32 threads (the setting torch-CPU actually scales to on these hosts) follows when the host has more, the
-    better of the attempts that finished is reported, and `cores` / `sample` say what ran."""
+    same training step on the host cores (BASELINE.md §3 / SURVEY §8(d)): fp32, batch 2, SGD nesterov; one untimed step, then steps until
+    ~budget_s is spent, best step reported.  BOUNDED: a child process with a hard time limit.  Threads: min(32, os.cpu_count()) — SURVEY
+    §8(d) says torch.set_num_threads(os.cpu_count()), and rounds 2-4 tried exactly that first on every run: on the 256-thread GPU hosts
+    torch-CPU's convolution backward is oversubscribed there (one batch-2 step ~300 s = 0.007 img/s in r02; no timed step within 50 s in
+    any run of r03 / r04; 128 threads: 0.31 img/s) and the attempt only cost every bench run 50 s.  32 threads is where torch-CPU scales to on
+    these hosts (1.0-1.4 img/s); `cores` / `sample` say what ran."""
     import subprocess
     ncpu = os.cpu_count() or 1
-    results, notes = [], []
-    for threads, limit in [(ncpu, 2 * budget_s + 10)] + ([(32, 3 * budget_s + 15)] if ncpu > 32 else []):
-        code = ("import sys; sys.path.insert(0, %r); import bench; bench._cpu_baseline_worker(%r, %r, %d, %d, %d, %f)"
-                % (ROOT, args.ver, args.mode, args.nc, args.size, threads, budget_s))
-        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-        try:
-            r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=limit)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("CPUBASE ")]
-            if r.returncode == 0 and line:
-                d = json.loads(line[-1][len("CPUBASE "):])
-                results.append((d["batch"] / min(d["times"]), threads, d))
-                notes.append(f"torch.set_num_threads({threads}): {d['batch'] / min(d['times']):.3f} img/s")
-                continue
-        except subprocess.TimeoutExpired:
-            pass
-        notes.append(f"torch.set_num_threads({threads}) did not finish a warm-up + a timed step within {int(limit)} s")
-    if not results:
-        return {"value": None, "unit": "img/s", "cores": 0, "kind": "port", "host_cpu_count": ncpu, "sample": "; ".join(notes)}
-    value, threads, d = max(results)
-    return {"value": round(value, 4), "unit": "img/s", "cores": threads, "kind": "port", "host_cpu_count": ncpu,
-            "sample": f"best of {len(d['times'])} timed training step(s) (after 1 untimed) of batch {d['batch']} at {args.size}x{args.size} "
-                      f"({args.ver} {args.mode} nc={args.nc}), fp32 torch-CPU oracle; attempts: " + "; ".join(notes)}
+    threads = min(32, ncpu)
+    limit = 3 * budget_s + 15
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench._cpu_baseline_worker(%r, %r, %d, %d, %d, %f)"
+            % (ROOT, args.ver, args.mode, args.nc, args.size, threads, budget_s))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    note = f"torch.set_num_threads({threads}) did not finish a warm-up + a timed step within {int(limit)} s"
+    try:
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=limit)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("CPUBASE ")]
+        if r.returncode == 0 and line:
+            d = json.loads(line[-1][len("CPUBASE "):])
+            value = d["batch"] / min(d["times"])
+            return {"value": round(value, 4), "unit": "img/s", "cores": threads, "kind": "port", "host_cpu_count": ncpu,
+                    "sample": f"best of {len(d['times'])} timed training step(s) (after 1 untimed) of batch {d['batch']} at {args.size}x{args.size} "
+                              f"({args.ver} {args.mode} nc={args.nc}), fp32 torch-CPU oracle, torch.set_num_threads({threads}) of {ncpu} host threads "
+                              "(all-threads runs never finished a step on these hosts in rounds 2-4: docstring)"}
+    except subprocess.TimeoutExpired:
+        pass
+    return {"value": None, "unit": "img/s", "cores": 0, "kind": "port", "host_cpu_count": ncpu, "sample": note}
 
 
 def nms_block(dev):
@@ -265,7 +267,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-b8", action="store_true", help="skip the second regime (8 images per GPU)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop block (the same step fed by DeviceLoader)")
-    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="gradient bucket format on xGMI (bf16: fp32 accumulate on receive)")
+    ap.add_argument("--wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="gradient bucket format on xGMI (bf16: fp32 accumulate on receive); auto = parallel.pick_wire: bf16 for <= 16 images per GPU")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo only for plumbing tests")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -294,6 +297,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    # every rank on the cores of ITS GPU's NUMA node (one node: LOCAL_WORLD_SIZE ranks share the sockets); the loader's decode pool is sized to it
+    n_local = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    aff = parallel.bind_rank(int(os.environ.get("LOCAL_RANK", "0")), n_local, device_of_rank=[0] * n_local if args.same_device else None)
     if rank == 0:
         ge.build()                                     # one rank checks/builds the shared library, the others wait
     if world > 1:
@@ -307,7 +313,8 @@ def main():
     model = Yolo(args.nc, CFG, args.mode, args.ver)
     model.apply(weights_init_normal)
     model.to(dev).train()
-    dp = parallel.DataParallel(model, wire=args.wire)
+    dp = parallel.DataParallel(model, wire=parallel.pick_wire(args.batch, world, args.wire))
+    dp._reducer.timing = world > 1
     rt = model.runtime()
     crit = (ComputeCSLLoss if args.mode == "csl" else ComputeKFIoULoss)(model, HYP)
     lr = 0.01
@@ -322,6 +329,7 @@ def main():
         steps again with a HIP-event pair around every conv launch for the rooflines."""
         imgs, targets = synth_batch(batch, args.size, args.nc, args.mode == "csl", seed=42 + rank, per_image=64)
         imgs, targets = imgs.to(dev), targets.to(dev)          # inputs resident in HBM before the timed region
+        dp.set_wire(parallel.pick_wire(batch, world, args.wire))
 
         def step():
             outs = model(imgs, training=True)
@@ -342,11 +350,15 @@ def main():
         g = rt.graph(batch, args.size, args.size, True)
         # ---- the timed region: EXACTLY K steps, nothing else on the stream --------------------------------------------------------
         barrier()
+        dp._reducer.collective_ms()                           # (drop the warm-up steps' stamps)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        torch.cuda.synchronize()
+        dt_rank = time.perf_counter() - t0                    # this rank's own K steps (before it waits for the others)
         barrier()
         dt = time.perf_counter() - t0
+        coll_ms = dp._reducer.collective_ms() / steps if world > 1 else None
         # ---- the same K steps again with a HIP-event pair around every conv launch (per-kernel durations for the rooflines).  Kept
         # out of the timed region: ~600 event records per step cost ~3 %, the kernels themselves run unchanged (the durations agree
         # with the rocprofv3 summary of the same command, profiles/).
@@ -364,11 +376,17 @@ def main():
             g.timer = None
             g.serial = False
         loss_last = read_loss()
+        per_rank = None
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dict(dt=dt, dt_inst=dt_inst, timer=timer, loss_first=loss_first, loss_last=loss_last, batch=batch, steps=steps)
+            mine = torch.tensor([dt_rank / steps * 1e3, coll_ms], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = {"ms_per_step": [round(float(e[0]), 3) for e in every], "allreduce_ms_per_step": [round(float(e[1]), 3) for e in every],
+                        "wire": dp.wire}
+        return dict(dt=dt, dt_inst=dt_inst, timer=timer, loss_first=loss_first, loss_last=loss_last, batch=batch, steps=steps, per_rank=per_rank)
 
     def loader_fed(batch, steps, warmup, budget_frac=None, npool=256):
         """the SAME training step fed by the device-side loader instead of one resident synthetic batch.  A synthetic
@@ -394,7 +412,7 @@ def main():
             labels.append(rs.randint(0, args.nc, size=nobj).astype(np.float32))
         total = npool * side * side * 3
         kw = {} if budget_frac is None else dict(pool_budget_bytes=int(total * budget_frac))        # (one image per slab: per-image LRU)
-        ds = BaseDataset(hyp, args.size, True, args.mode == "csl", False, device=dev, decode_workers=8, **kw)
+        ds = BaseDataset(hyp, args.size, True, args.mode == "csl", False, device=dev, decode_workers=aff.get("decode_threads", 8), **kw)
         ds.set_arrays(images, polys, labels)
         loader = DeviceLoader(ds, batch, shuffle=True)
         _r.seed(1234 + rank)
@@ -520,9 +538,25 @@ def main():
         mx, mn = rt.flat.clone(), rt.flat.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        affs = [None] * world
+        dist.all_gather_object(affs, aff)
+
+        def spread(pr):
+            """What the first SCALE run needs to explain itself: every rank's own step time (before it waits for the others) and the time
+            its gradient buckets spent in their collectives on the side stream (from 'bucket final' to 'sum back', peers' skew included)."""
+            if pr is None:
+                return None
+            ms, ar = pr["ms_per_step"], pr["allreduce_ms_per_step"]
+            return {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step_by_rank": ms, "allreduce_ms_per_step_min": min(ar),
+                    "allreduce_ms_per_step_max": max(ar), "allreduce_ms_per_step_by_rank": ar, "grad_wire": pr["wire"]}
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_in_allreduce": int(ones.item()),
                      "replicas_bit_identical": bool(torch.equal(mx, mn)), "devices": "all ranks on cuda:0 (--same-device)" if args.same_device else "one GPU per rank",
-                     "grad_bucket_mb": round(dp.bucket_bytes / 2 ** 20, 1) if hasattr(dp, "bucket_bytes") else None, "grad_wire": args.wire}
+                     "grad_bucket_mb": round(dp.bucket_bytes / 2 ** 20, 1) if hasattr(dp, "bucket_bytes") else None,
+                     "grad_wire": parallel.pick_wire(args.batch, world, args.wire), "grad_wire_rule": args.wire,
+                     "per_rank": spread(m["per_rank"]), "per_rank_b8": spread(m8["per_rank"]) if m8 is not None else None,
+                     "affinity": [{"rank": r, **a} for r, a in enumerate(affs)], "rccl_env": parallel.rccl_env(),
+                     "note": "allreduce_ms = time of the bucket collectives on their side stream (overlapped with backward); the part of it the step "
+                             "actually waits for is ms_per_step(N) - ms_per_step(1)"}
     if rank != 0:
         return
     dt, loss_first, loss_last = m["dt"], m["loss_first"], m["loss_last"]
@@ -534,7 +568,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"C4: DOTA {args.ver} {args.mode} nc={args.nc} {args.size}x{args.size}, batch {args.batch}/GPU, fwd+loss+bwd+SGD-nesterov step"
-                               + (f", RCCL all-reduce of 37.9M grads ({args.wire} on the wire)" if world > 1 else ""),
+                               + (f", RCCL all-reduce of 37.9M grads ({parallel.pick_wire(args.batch, world, args.wire)} on the wire)" if world > 1 else ""),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "targets_per_image": 64,
                    "weights": "random init N(0,0.02) (train.py:28-33)"},
     }
@@ -542,6 +576,7 @@ def main():
     out["train_loss"] = {"first_step": round(loss_first, 4), "after_timed_steps": round(loss_last, 4),
                          "finite": bool(math.isfinite(loss_first) and math.isfinite(loss_last) and bool(torch.isfinite(rt.flat).all()))}
     out["hbm_resident"] = mem
+    out["host_affinity"] = aff
     if dist_info is not None:
         out["distributed"] = dist_info
     gf = TRAIN_GFLOP_PER_IMG.get((args.ver, args.mode, args.size))

@@ -180,7 +180,7 @@ class ImagePool:
             img = np.repeat(img[:, :, :1], 3, axis=2)
         self._shapes[i] = tuple(img.shape[:2])
         # straight into PINNED staging (inside the worker thread: numpy copies release the GIL), so the host holds one copy per image in flight
-        stage = torch.empty(img.shape[0] * img.shape[1] * 3, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+        stage = torch.empty(img.shape[0] * img.shape[1] * 3, dtype=torch.uint8, pin_memory=self.device.type == "cuda" and torch.cuda.is_available())
         np.copyto(stage.numpy().reshape(img.shape), img, casting="unsafe")
         return stage
 
@@ -331,7 +331,7 @@ def _to_device(arr, dev):
     dev = torch.device(dev)
     if dev.type != "cuda":
         return torch.from_numpy(raw.copy()).to(dev)
-    stage = torch.empty(max(raw.size, 1), dtype=torch.uint8, pin_memory=True)
+    stage = torch.empty(max(raw.size, 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
     stage.numpy()[:raw.size] = raw
     return stage[:max(raw.size, 1)].to(dev, non_blocking=True)
 

@@ -91,7 +91,12 @@ def _default_imsize(path):
         return None
 
 
-_POOL_CACHE = {}          # (image file list, device, budget) -> (ImagePool, parsed labels): test.py calls load_data once per evaluation
+_POOL_CACHE = {}          # (image + label file lists, class list, device, budget, decoder) -> (ImagePool, parsed labels): test.py calls load_data once per evaluation
+
+
+def clear_pool_cache():
+    """Drop every shared pool (each pins at least one slab of device memory for as long as it is cached)."""
+    _POOL_CACHE.clear()
 
 
 class BaseDataset:
@@ -121,7 +126,15 @@ class BaseDataset:
         its shard only.  Call before the first batch."""
         if self._pool is not None:
             raise RuntimeError("BaseDataset.shard: call before the first batch is assembled")
-        self.img_files, self.label_files = self.img_files[rank::world_size], self.label_files[rank::world_size]
+        # every rank gets EXACTLY ceil(n / world) files (torch's DistributedSampler convention: the short shards wrap around to the head of
+        # the list): ranks then run the same number of batches of the same sizes — a rank with one batch more would sit in a gradient
+        # all-reduce that has no peer (n = 129, world 2, batch 64: 2 batches vs 1), and unequal last batches would be weighted equally by
+        # grad_scale = 1 / world
+        n = len(self.img_files)
+        if n:
+            per = -(-n // world_size)
+            idx = [(rank + k * world_size) % n for k in range(per)]
+            self.img_files, self.label_files = [self.img_files[i] for i in idx], [self.label_files[i] for i in idx]
         return self
 
     def __len__(self):
@@ -150,7 +163,11 @@ class BaseDataset:
         one pool (test.py calls load_data for every evaluation)."""
         if self._pool is None:
             files = self.img_files
-            key = (tuple(files), str(self.device), self.pool_budget_bytes, self.pool_slab_bytes, id(self.imread) if self.imread is not _default_imread else 0)
+            # the key holds the decoder OBJECT (a reference: an id() could be reused after garbage collection) and everything the parsed
+            # labels depend on — label files, the class list of the concrete dataset, the label convention — so two datasets over the same
+            # images with different classes or label directories never see each other's class indices
+            key = (tuple(files), tuple(self.label_files), tuple(getattr(self, "category", None) or ()), type(self).__name__, bool(self.normalized_labels),
+                   str(self.device), self.pool_budget_bytes, self.pool_slab_bytes, self.imread)
             if self.share_pool and key in _POOL_CACHE:
                 self._pool, self._labels = _POOL_CACHE[key]
                 return self._pool

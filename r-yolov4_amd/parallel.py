@@ -13,6 +13,102 @@ import torch
 import torch.distributed as dist
 
 
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _fmt_cpulist(cpus):
+    cpus, parts, i = sorted(cpus), [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(parts)
+
+
+def _gpu_local_cpus(index):
+    """CPUs of the NUMA node the GPU `index` hangs off: /sys/bus/pci/devices/<domain:bus:dev.0>/local_cpulist (the same topology
+    `rocm-smi --showtoponuma` prints); None when the device or the file is not there (CPU-only box, container without sysfs)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        cpus = _parse_cpulist(open(f"{base}/local_cpulist").read())
+        try:
+            node = int(open(f"{base}/numa_node").read())
+        except (OSError, ValueError):
+            node = -1
+        return (cpus, node) if cpus else None
+    except Exception:                                                   # no GPU / no sysfs: the caller splits what it has evenly
+        return None
+
+
+def plan_affinity(local_rank, n_local, device_of_rank=None, allowed=None, gpu_cpus=_gpu_local_cpus):
+    """Which host cores local rank `local_rank` of `n_local` gets: the cores of ITS GPU's NUMA node, and when several ranks' GPUs share a
+    node (MI355X chassis: 8 GPUs on 2 sockets) an equal contiguous slice of them per rank — loader decode threads, the launch thread and
+    RCCL's proxy threads of a rank then stay on the socket whose PCIe root the GPU is on, and no two ranks fight for a core.  Pure
+    function of the topology (every rank computes the same plan without talking): returns {"cpus": [...], "numa_node", "source"}."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    device_of_rank = device_of_rank or list(range(n_local))
+    info = [gpu_cpus(device_of_rank[r]) for r in range(n_local)]
+    if any(i is None for i in info):
+        per = max(1, len(allowed) // n_local)
+        mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        return {"cpus": mine, "numa_node": None, "source": "even split of the allowed cores (no PCI topology in sysfs)"}
+    sets = [tuple(sorted(set(c) & set(allowed)) or allowed) for c, _ in info]
+    sharers = [r for r in range(n_local) if sets[r] == sets[local_rank]]
+    pool = list(sets[local_rank])
+    per = max(1, len(pool) // len(sharers))
+    k = sharers.index(local_rank)
+    mine = pool[k * per:(k + 1) * per] or pool
+    return {"cpus": mine, "numa_node": info[local_rank][1], "source": "sysfs local_cpulist of the rank's GPU, split over the ranks of that node"}
+
+
+def bind_rank(local_rank, n_local, device_of_rank=None, max_threads=16):
+    """Pin this process (and the threads it will start) to its slice of plan_affinity() and size torch's host thread pool to it (the
+    loader's decode pool reads `decode_threads`).  RYOLO_BIND=0 turns it off.  Returns the record bench.py prints per rank."""
+    if os.environ.get("RYOLO_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return {"bound": False, "cpus": _fmt_cpulist(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    plan = plan_affinity(local_rank, n_local, device_of_rank)
+    try:
+        os.sched_setaffinity(0, plan["cpus"])
+        bound = True
+    except OSError:
+        bound = False
+    threads = max(1, min(max_threads, len(plan["cpus"])))
+    torch.set_num_threads(threads)
+    return {"bound": bound, "cpus": _fmt_cpulist(plan["cpus"]), "n_cpus": len(plan["cpus"]), "numa_node": plan["numa_node"],
+            "host_threads": threads, "decode_threads": max(1, min(8, len(plan["cpus"]) - 1)), "source": plan["source"]}
+
+
+def rccl_env():
+    """RCCL knobs that matter beside two compute streams: the channel count bounds how many CUs the collective's kernels occupy while
+    backward is still running (each channel is one workgroup).  RYOLO_RCCL_CHANNELS=n sets NCCL_MIN/MAX_NCHANNELS before the communicator
+    exists; whatever is in effect is reported by bench.py."""
+    n = os.environ.get("RYOLO_RCCL_CHANNELS")
+    if n:
+        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(int(n))
+    return {k: os.environ[k] for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO", "GPU_MAX_HW_QUEUES") if k in os.environ}
+
+
+def pick_wire(batch_per_gpu, world, requested="auto"):
+    """fp32 or bf16 gradient buckets on xGMI, by rule: the all-reduce moves 151.5 MB (fp32) per step whatever the batch; against the
+    ~73 ms step of 64 images per GPU it is hidden under backward, against the ~15 ms step of 8 images per GPU (the reference's nominal
+    batch 64 over 8 GPUs) it is not — there bf16 on the wire (fp32 accumulate on receive, replicas still bit-identical) halves it."""
+    if requested != "auto":
+        return requested
+    return "bf16" if (world > 1 and batch_per_gpu <= 16) else "fp32"
+
+
 def init_from_env(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run contract)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -22,6 +118,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        rccl_env()
         be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if be == "nccl":
@@ -54,6 +151,27 @@ def allreduce_flat(flat, bucket_bytes=64 << 20, async_op=False):
     return works
 
 
+_A2A = {}
+
+
+def _has_all_to_all(probe):
+    """Decided ONCE per (backend, device type), collectively (every rank runs the same probe at the same point), never by catching an
+    error around a real bucket: on RCCL a failed collective on some ranks followed by a different collective on the others is a hang."""
+    key = (dist.get_backend(), probe.device.type)
+    if key not in _A2A:
+        if key[0] == "nccl":
+            _A2A[key] = True
+        else:
+            w = dist.get_world_size()
+            a = torch.zeros(w, dtype=probe.dtype, device=probe.device)
+            try:
+                dist.all_to_all_single(torch.empty_like(a), a)
+                _A2A[key] = True
+            except RuntimeError:
+                _A2A[key] = False
+    return _A2A[key]
+
+
 def allreduce_bf16_wire(view, scratch=None):
     """Sum the fp32 tensor `view` over all ranks moving bf16 over the wire and accumulating in fp32 ON RECEIVE (75.8 MB
     instead of 151.5 MB per step for yolov7).  A direct reduce-scatter + all-gather over the point-to-point links, not a ring:
@@ -75,9 +193,9 @@ def allreduce_bf16_wire(view, scratch=None):
     send[:n].copy_(view)                                           # fp32 -> bf16 (round to nearest even)
     if padded > n:
         send[n:].zero_()
-    try:
+    if _has_all_to_all(send):
         dist.all_to_all_single(recv, send)
-    except RuntimeError:                                           # backend without all_to_all (older gloo): same data movement by all_gather
+    else:                                                          # gloo has no all_to_all on some builds: same data movement by all_gather
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send)
         r = dist.get_rank()
@@ -110,13 +228,21 @@ class _Reducer:
             raise ValueError("wire must be 'fp32' or 'bf16'")
         self.bucket_bytes = bucket_bytes
         self.wire = wire
-        self.scratch = None
+        self.scratch = {}                 # bf16 staging buffers PER STREAM (side stream / caller's stream): never shared across streams
         self.events = []
         self.bounds = None
         self.plans = {}
-        self.works = []
         self.done = set()
         self.side = None
+        self.timing = False               # bench.py: HIP-event pairs around every bucket's collective on the stream it runs on
+        self.stamps = []
+
+    def collective_ms(self):
+        """Sum of the bucket collectives' durations since the last call (needs .timing and a device synchronize before): time on the
+        side stream from 'bucket final' to 'sum back in the buffer', waiting for slower peers included."""
+        ms = sum(a.elapsed_time(b) for a, b in self.stamps)
+        self.stamps = []
+        return ms
 
     def _bounds(self, rt):
         if self.bounds is None:
@@ -131,6 +257,12 @@ class _Reducer:
             cuts.append(n)
             self.bounds = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         return self.bounds
+
+    def _collective(self, view, key):
+        if self.wire == "bf16":
+            self.scratch[key] = allreduce_bf16_wire(view, self.scratch.get(key))
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True).wait()     # RCCL: the CURRENT stream waits, the host does not
 
     def _launch(self, rt, k):
         if k in self.done:
@@ -148,19 +280,21 @@ class _Reducer:
                 se = getattr(rt, "side_event", None)          # weight gradients of this bucket still running on the engine's
                 if se is not None:                            # second stream (Graph.run): the collective waits for them too
                     self.side.wait_event(se)
-                if self.wire == "bf16":
-                    self.scratch = allreduce_bf16_wire(view, self.scratch)      # buckets share one scratch: they run in order on this stream
-                    self.events.append(self.side.record_event())
-                else:
-                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
-        elif self.wire == "bf16":
-            self.scratch = allreduce_bf16_wire(view, self.scratch)
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.side)
+                self._collective(view, "side")                # buckets run in order on this stream and share its scratch
+                if self.timing:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(self.side)
+                    self.stamps.append((t0, t1))
+                self.events.append(self.side.record_event())
         else:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+            self._collective(view, "host")
 
     def bucket_hooks(self, rt, g):
         """{backward tape index: callable} for Graph.run."""
-        self.works, self.events, self.done = [], [], set()
+        self.events, self.done = [], set()
         bounds = self._bounds(rt)
         plan = self.plans.get(id(g))
         if plan is None:
@@ -175,11 +309,9 @@ class _Reducer:
     def __call__(self, rt):
         for k in range(len(self._bounds(rt))):
             self._launch(rt, k)
-        for w in self.works:
-            w.wait()                                   # the current (compute) stream waits for the collective
         for ev in self.events:
-            torch.cuda.current_stream().wait_event(ev)
-        self.works, self.events = [], []
+            torch.cuda.current_stream().wait_event(ev)    # the compute stream waits for the collectives, the host does not
+        self.events = []
 
 
 class _Hook:
@@ -231,10 +363,17 @@ class DataParallel:
     def _reduce(self, rt):
         if self.wire == "bf16":
             elems = max(1, self.bucket_bytes // 4)
+            sc = self._reducer.scratch
             for a, b in bucket_bounds(rt.gflat.numel(), elems):
-                self._reducer.scratch = allreduce_bf16_wire(rt.gflat[a:b], self._reducer.scratch)
+                sc["main"] = allreduce_bf16_wire(rt.gflat[a:b], sc.get("main"))     # the caller's stream has its own staging buffers
         else:
             allreduce_flat(rt.gflat, self.bucket_bytes)
+
+    def set_wire(self, wire):
+        """Switch the bucket format between steps (bench.py: fp32 for the 64-image step, bf16 for the 8-image one)."""
+        if wire not in ("fp32", "bf16"):
+            raise ValueError("wire must be 'fp32' or 'bf16'")
+        self.wire = self._reducer.wire = wire
 
     def no_sync(self):
         """Context manager: backward passes inside it only accumulate into the local flat gradient buffer (no collective)."""

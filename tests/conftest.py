@@ -21,6 +21,18 @@ def pytest_configure(config):
     torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
 
 
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` (or no marker filter) on a box without a HIP device: the gpu-marked tests SKIP with the reason instead of failing in
+    whatever allocates first (pinned staging, a device tensor).  On the GPU box nothing is skipped by this."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False here)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

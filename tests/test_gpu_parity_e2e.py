@@ -5,8 +5,12 @@
     the HIP path to the bf16-emulating oracle may not exceed 1.5x the distance between the fp32 oracle and that same emulation
     (+ a small absolute slack), for the loss and for the gradient direction (1 - cos over all parameters).
 (b) end-to-end loss and decoded boxes on the BASELINE configurations' shapes (C1 yolov4 kfiou 416 b2, C2 yolov4 608, C3 yolov7 csl
-    800) against the FP32 oracle, eval-mode BatchNorm: the measured errors are REPORTED against the north star's 1e-3 (written to
-    gpurun_out/r02_parity_e2e.json and printed); asserted is what is true for bf16 activations: <= 1e-2."""
+    800, C4 yolov7 kfiou nc=16 800 — the bench network) against the FP32 oracle, eval-mode BatchNorm.  ASSERTED is the north star's own
+    line: boxes and every loss item < 1e-3 relative (measured r04: boxes <= 3.1e-4, items <= 7.3e-5).  Scores (obj * cls after two sigmoids
+    of bf16-rounded logits: a 2^-9 relative logit error of a logit of magnitude ~4 is ~8e-3 absolute in the logit, times sigmoid' <= 0.25)
+    are held to 2e-3 (measured 8.8e-4 on C3, 6.7e-5 on C1 / C2); the raw head maps — bf16 activations end to end, not a north-star
+    quantity — to 5e-3 (measured 2.0e-3 ... 2.5e-3 = a few bf16 ulps accumulated over ~100 layers).  Written to
+    gpurun_out/r02_parity_e2e.json and printed."""
 import json
 import os
 
@@ -83,7 +87,7 @@ def test_full_network_train_mode_backward_vs_noise_floor(ver, mode):
 
 
 @pytest.mark.parametrize("cfg,ver,mode,nc,S,B", [("C1", "yolov4", "kfiou", 2, 416, 2), ("C2", "yolov4", "kfiou", 2, 608, 1),
-                                                 ("C3", "yolov7", "csl", 16, 800, 1)])
+                                                 ("C3", "yolov7", "csl", 16, 800, 1), ("C4", "yolov7", "kfiou", 16, 800, 1)])
 def test_end_to_end_loss_and_boxes_vs_fp32_oracle(cfg, ver, mode, nc, S, B):
     from ryolov4_amd.lib.loss import ComputeCSLLoss, ComputeKFIoULoss
     from ryolov4_amd.model.yolo import Yolo
@@ -112,4 +116,5 @@ def test_end_to_end_loss_and_boxes_vs_fp32_oracle(cfg, ver, mode, nc, S, B):
                boxes_rel_l2=e_box, scores_rel_l2=e_score, loss_items_rel=e_items, head_maps_rel_l2=e_maps,
                north_star_1e3_met=dict(boxes=e_box < 1e-3, losses=max(e_items.values()) < 1e-3))
     _report(f"e2e_{cfg}", rep)
-    assert e_box < 1e-2 and e_score < 1e-2 and max(e_items.values()) < 1e-2 and max(e_maps) < 1e-2, rep
+    assert e_box < 1e-3 and max(e_items.values()) < 1e-3, rep          # the north star's tolerance, as stated
+    assert e_score < 2e-3 and max(e_maps) < 5e-3, rep                 # (docstring: why these two are not 1e-3)

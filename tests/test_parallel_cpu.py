@@ -264,3 +264,87 @@ def test_bf16_wire_gradient_buckets_gloo_world2():
     from ryolov4_amd import parallel
     with pytest.raises(ValueError):
         parallel._Reducer(1024, wire="fp8")
+
+
+# ---- round 5: 8-GPU readiness that needs no 8-GPU node and the unequal-shard hang -----------------
+def test_affinity_plan_splits_numa_nodes_between_the_ranks_that_share_them():
+    """MI355X chassis shape: 8 GPUs on 2 sockets.  Ranks 0-3 hang off node 0 (cores 0-63), ranks 4-7 off node 1 (64-127): every rank gets
+    a quarter of ITS node, no two ranks share a core, and every rank computes the same plan on its own."""
+    from ryolov4_amd import parallel
+    topo = lambda dev: (list(range(0, 64)) if dev < 4 else list(range(64, 128)), 0 if dev < 4 else 1)
+    plans = [parallel.plan_affinity(r, 8, allowed=range(128), gpu_cpus=topo) for r in range(8)]
+    sets = [set(p["cpus"]) for p in plans]
+    assert all(len(s) == 16 for s in sets)
+    assert all(sets[a].isdisjoint(sets[b]) for a in range(8) for b in range(a + 1, 8))
+    assert all(max(sets[r]) < 64 for r in range(4)) and all(min(sets[r]) >= 64 for r in range(4, 8))
+    assert [p["numa_node"] for p in plans] == [0] * 4 + [1] * 4
+    # two ranks on ONE device (bench.py --same-device plumbing runs): still distinct halves
+    two = [parallel.plan_affinity(r, 2, device_of_rank=[0, 0], allowed=range(128), gpu_cpus=topo) for r in range(2)]
+    assert set(two[0]["cpus"]).isdisjoint(two[1]["cpus"]) and len(two[0]["cpus"]) == 32
+    # a cgroup that allows only part of the node: the plan stays inside it
+    part = [parallel.plan_affinity(r, 8, allowed=range(0, 8), gpu_cpus=topo)["cpus"] for r in range(8)]
+    assert sorted(sum(part, [])) == list(range(8))          # (node 1's cores are outside the cgroup: its ranks share what is allowed)
+    # no PCI topology (this container): even split of what the process may use
+    flat = [parallel.plan_affinity(r, 4, allowed=range(8), gpu_cpus=lambda d: None) for r in range(4)]
+    assert [p["cpus"] for p in flat] == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert parallel._fmt_cpulist([0, 1, 2, 5, 7, 8]) == "0-2,5,7-8" and parallel._parse_cpulist("0-2,5,7-8\n") == [0, 1, 2, 5, 7, 8]
+
+
+def test_wire_rule():
+    from ryolov4_amd import parallel
+    assert parallel.pick_wire(64, 8) == "fp32" and parallel.pick_wire(8, 8) == "bf16" and parallel.pick_wire(8, 1) == "fp32"
+    assert parallel.pick_wire(8, 8, "fp32") == "fp32" and parallel.pick_wire(64, 8, "bf16") == "bf16"
+
+
+def test_shards_are_equal_when_the_file_count_does_not_divide():
+    """n = 129 files, world 2, batch 64 was 2 batches on rank 0 and 1 on rank 1 (an all-reduce without a peer).  Now both shards hold
+    ceil(129 / 2) = 65 files (the short one wraps around), every file is in some shard, and the loaders agree on the batch count."""
+    from ryolov4_amd.datasets.base_dataset import BaseDataset, DeviceLoader
+    hyp = {"hsv_h": 0, "hsv_s": 0, "hsv_v": 0, "rotate": 0, "translate": 0, "scale": 0, "flipud": 0, "fliplr": 0, "mosaic": 0, "mixup": 0}
+    for n, world, bs in ((129, 2, 64), (10, 4, 3), (7, 8, 2), (64, 8, 8)):
+        lens, seen, nb = [], set(), []
+        for rank in range(world):
+            ds = BaseDataset(hyp, 64, False, False, False, device="cpu")
+            ds.img_files = [f"img{i}" for i in range(n)]
+            ds.label_files = [f"lab{i}" for i in range(n)]
+            ld = DeviceLoader(ds, bs, shuffle=False, side_stream=False, rank=rank, world_size=world)
+            lens.append(len(ds))
+            nb.append(len(ld))
+            seen |= set(ds.img_files)
+            assert [f.replace("img", "lab") for f in ds.img_files] == ds.label_files
+        assert len(set(lens)) == 1 and lens[0] == -(-n // world) and len(set(nb)) == 1, (n, world, lens, nb)
+        assert seen == {f"img{i}" for i in range(n)}
+
+
+def _uneven_worker(rank, world, port, q):
+    """The loop of train.py over a DeviceLoader-shaped iteration with one all-reduce per batch: with unequal shards this deadlocks."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ryolov4_amd import parallel
+    from ryolov4_amd.datasets.base_dataset import BaseDataset, DeviceLoader
+    parallel.init_from_env(backend="gloo")
+    hyp = {"hsv_h": 0, "hsv_s": 0, "hsv_v": 0, "rotate": 0, "translate": 0, "scale": 0, "flipud": 0, "fliplr": 0, "mosaic": 0, "mixup": 0}
+    ds = BaseDataset(hyp, 64, False, False, False, device="cpu")
+    ds.img_files = [f"img{i}" for i in range(129)]
+    ds.label_files = list(ds.img_files)
+    ld = DeviceLoader(ds, 64, shuffle=False, side_stream=False, rank=rank, world_size=world)
+    n, sizes = len(ds), []
+    for a in range(0, n, ld.batch_size):                                 # (DeviceLoader.__iter__'s slicing, without touching pixels)
+        sizes.append(len(range(a, min(n, a + ld.batch_size))))
+        g = torch.ones(4) * (rank + 1)
+        dist.all_reduce(g)
+    q.put((rank, sizes))
+    dist.destroy_process_group()
+
+
+def test_uneven_file_count_does_not_hang_the_allreduce_loop():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == [64, 1]
