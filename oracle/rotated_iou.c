@@ -17,8 +17,12 @@
  *   - deg->rad and cos/sin in double, rounded to float, times 0.5f  (get_rotated_vertices);
  *   - centre shift computed in double, rounded to float             (single_box_iou_rotated);
  *   - EPS comparisons done in double exactly as written upstream;
- *   - hull sort = the deterministic O(n^2) exchange sort of the CUDA path (std::sort on the CPU path
- *     of detectron2 is not reproducible in C).
+ *   - hull sort = the deterministic O(n^2) exchange sort of the CUDA path — the path lib/general.py:177 runs on (the reference calls
+ *     nms_rotated on GPU tensors).  detectron2's CPU path orders the same points with std::sort and a comparator that is not a strict
+ *     weak order for near-collinear points (so its result is implementation-defined); that variant is built beside this one from the
+ *     same file with -DORA_HULL_STDSORT (symbols ora_cpusort_*, the ordering itself in hull_stdsort.cpp = the real std::sort of this
+ *     toolchain's libstdc++) ONLY to measure how the two orderings differ on the failure families (tests/test_iou_fuzz.py,
+ *     profiles/r05_iou_sort_variants.json) — it is not the parity contract.
  * Suppression predicate: gt_only=1 -> iou > thr (CUDA semantics, what the reference runs on GPU),
  *                        gt_only=0 -> iou >= thr (detectron2 CPU kernel semantics).
  */
@@ -28,6 +32,16 @@
 #include <string.h>
 
 typedef struct { float x, y; } pt_t;
+
+#ifdef ORA_HULL_STDSORT
+/* second build of this file: detectron2's CPU-path hull ordering; every exported symbol gets the ora_cpusort_ prefix */
+void ora_hull_stdsort(pt_t *q_from_1, int n_minus_1);                      /* hull_stdsort.cpp: std::sort(q + 1, q + n, comparator) */
+#define ora_single_box_iou_rotated ora_cpusort_single_box_iou_rotated
+#define ora_pairwise_iou_rotated   ora_cpusort_pairwise_iou_rotated
+#define ora_diag_iou_rotated       ora_cpusort_diag_iou_rotated
+#define ora_nms_rotated            ora_cpusort_nms_rotated
+#define ora_nms_mask               ora_cpusort_nms_mask
+#endif
 
 static inline float dot2(pt_t a, pt_t b) { return a.x * b.x + a.y * b.y; }
 static inline float cross2(pt_t a, pt_t b) { return a.x * b.y - b.x * a.y; }
@@ -104,8 +118,16 @@ static int convex_hull_graham(const pt_t *p, int n, pt_t *q)
     pt_t tmp = q[0]; q[0] = q[t]; q[t] = tmp;
 
     float dist[24];
+#ifdef ORA_HULL_STDSORT
+    /* CPU path of box_iou_rotated_utils.h: std::sort(q + 1, q + num_in, cmp), cmp(A, B) = |cross(A, B)| < 1e-6 ? |A|^2 < |B|^2 : cross(A, B) > 0;
+     * the squared distances are computed AFTER the sort there */
+    ora_hull_stdsort(q + 1, n - 1);
+    for (int i = 0; i < n; i++) dist[i] = dot2(q[i], q[i]);
+    for (int i = n; i < n - 1; i++) {                                      /* (the exchange sort below is the CUDA path: skipped) */
+#else
     for (int i = 0; i < n; i++) dist[i] = dot2(q[i], q[i]);
     for (int i = 1; i < n - 1; i++) {
+#endif
         for (int j = i + 1; j < n; j++) {
             float cp = cross2(q[i], q[j]);
             if ((cp < -1e-6) || (fabs((double)cp) < 1e-6 && dist[i] > dist[j])) {
