@@ -1104,6 +1104,19 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.PWp = p.OW + 2;
     g.HPp = p.OH + 2;
     g.Mp = (int64_t)p.NB * g.HPp * g.PWp;
+    if (g.Mp >= (1ll << 31)) return false;                        // 32-bit stream coordinates
+    for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
+    for (int t = 0; t < 9; t++) g.tap_of[(p.dh[t] + 1) * 3 + p.dw[t] + 1] = t;
+    auto magic = [](unsigned d, unsigned& m, unsigned& sh) {         // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (d >= 3 here: padded sizes)
+        unsigned l = 0;
+        while ((1ull << l) < d) l++;
+        m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+        sh = l - 1;
+    };
+    magic((unsigned)(g.HPp * g.PWp), g.m_img, g.s_img);
+    magic((unsigned)g.PWp, g.m_row, g.s_row);
+    // round 5: the 8-wave form (conv3x3_wgrad8.hip: 2 x (5 | 4) accumulator blocks per wave, rings of any length) where it applies
+    if (w8_geometry(p, g)) { g.ok = 1; return true; }
     g.co64 = p.Cout <= 64 ? 1 : 0;
     // RYOLO_W3_STEP64 (A/B knob): bit 0 = 64-pixel K steps for <= 64 output channels, bit 1 = for the 128-channel tiles (conv3x3_wgrad64_kernel)
     static const int step64 = getenv("RYOLO_W3_STEP64") ? atoi(getenv("RYOLO_W3_STEP64")) : 3;
@@ -1122,7 +1135,6 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     g.RX = rx;
     g.gx = (int)ry_cdiv(p.Cout, 128);
     g.gc = p.Cin / 32;
-    if (g.Mp >= (1ll << 31)) return false;                        // 32-bit stream coordinates
     // one workgroup per CU (r04; 512 = two per CU until then): with the BatchNorm passes at 5-8 waves per SIMD on the main stream the side stream
     // does better with fewer, longer workgroups (half the split-K slabs, prologue amortised over twice the steps): same-box step 863 -> 874 img/s
     // at 256, 868 at 128 / 192, 860 at 768 (A/B knob)
@@ -1138,16 +1150,6 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
     const int kstep = g.step64 ? 64 : 32;
     g.kchunk = ry_cdiv(ry_cdiv(g.Mp, sk), kstep) * kstep;
     g.splitk = (int)ry_cdiv(g.Mp, g.kchunk);
-    for (int t = 0; t < 9; t++) g.toff[t] = p.dh[t] * g.PWp + p.dw[t];
-    for (int t = 0; t < 9; t++) g.tap_of[(p.dh[t] + 1) * 3 + p.dw[t] + 1] = t;
-    auto magic = [](unsigned d, unsigned& m, unsigned& sh) {         // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31 (d >= 3 here: padded sizes)
-        unsigned l = 0;
-        while ((1ull << l) < d) l++;
-        m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
-        sh = l - 1;
-    };
-    magic((unsigned)(g.HPp * g.PWp), g.m_img, g.s_img);
-    magic((unsigned)g.PWp, g.m_row, g.s_row);
     g.lds_bytes = (g.step64 ? 2u * (g.co64 ? 8192u : 16384u) : W3_NS * (g.co64 ? 4096u : 8192u)) + (unsigned)g.RX * 64u;
     static const int w3_mirror = getenv("RYOLO_W3_MIRROR") ? atoi(getenv("RYOLO_W3_MIRROR")) : 1;      // A/B knob
     g.mirror = (g.step64 && w3_mirror && g.lds_bytes + 1024u <= 80u * 1024u) ? 1 : 0;
@@ -1159,6 +1161,7 @@ bool w3_geometry(const WgradParams& p, W3Geom& g)
 
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream)
 {
+    if (g.v8) return w8_launch(p, g, stream);
     static RyLdsAttr attr_f, attr_t, attr_64f, attr_64t, attr_64fm, attr_64tm;
     if (ry_max_dynamic_lds(attr_f, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<false>), 160 * 1024) ||
         ry_max_dynamic_lds(attr_t, reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<true>), 160 * 1024) ||

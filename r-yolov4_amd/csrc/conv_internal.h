@@ -236,6 +236,7 @@ struct W3Geom {
     int toff[9];               // dh * PWp + dw per tap (caller's tap order)
     int tap_of[9];             // caller's tap index of the tap (dh, dw) at 3 * (dh + 1) + (dw + 1) (the 64-pixel kernels walk the taps row by row)
     int mirror;                // 1: the ring is followed by a copy of its first 16 rows (conv3x3_wgrad64_kernel: immediate row offsets never wrap)
+    int v8;                    // 0: the 4-wave kernels of conv3x3.hip; 2 / 4: conv3x3_wgrad8_kernel<NCO> (conv3x3_wgrad8.hip), gc then counts 64-channel chunks
     unsigned lds_bytes;
     // exact n / d for 0 <= n < 2^31 as (mulhi(n, m) >> s): d = HPp * PWp (padded pixels per image) and d = PWp (padded row length) —
     // the DMA address generation decomposes a padded pixel index without loops or branches
@@ -243,6 +244,8 @@ struct W3Geom {
 };
 bool w3_geometry(const WgradParams& p, W3Geom& g);
 int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
+bool w8_geometry(const WgradParams& p, W3Geom& g);           // conv3x3_wgrad8.hip, called by w3_geometry on a W3Geom whose padded sizes / taps / magic numbers are set
+int w8_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
 
 // ---- weight-stationary persistent 1x1 GEMM (gemm1x1.hip): Cin <= 256, identity grid, bf16 epilogues ---------------------------------
 struct Ws1Geom {

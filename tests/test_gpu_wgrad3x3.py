@@ -2,7 +2,13 @@
 gradient on the same bf16 operands: both variants (128-channel tiles; <= 64 output channels with split K halves), channel
 strides wider than the tensors (concat slices), Cout that is not a multiple of 32, odd map sizes, accumulation into an existing
 gradient.  Sizes are chosen so the library's own dispatch picks the ring kernel (asserted).  Tolerance 2e-3 relative (bf16
-operands, fp32 accumulation in a different order)."""
+operands, fp32 accumulation in a different order).
+
+Round 5: layers with Cin % 64 == 0 run on the 8-wave form (csrc/conv3x3_wgrad8.hip: 2 x (5 | 4) accumulator blocks per wave, rings of any
+length with a mirrored head) by default — the cases below with Cin 64 / 128 / 192 / 256 exercise both of its instantiations (<= 64 output
+channels: pixel halves + two slabs; 128-channel tiles: output-channel pairs), ring wrap-around over many laps (long K ranges on narrow maps),
+maps as wide as its LDS budget allows, ragged Cout, concat strides; Cin = 32 stays on the 4-wave kernels, and the whole file runs once more
+with RYOLO_W3_V8=0 in tests/test_gpu_forced_kernels.py so that those keep their coverage for every shape."""
 import pytest
 import torch
 
@@ -60,6 +66,20 @@ def _run(B, H, W, Cin, Cout, ldx_extra=0, ldy_extra=0, seed=0):
 ])
 def test_ring_wgrad(B, H, W, Cin, Cout):
     _run(B, H, W, Cin, Cout)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (64, 25, 25, 256, 256),       # the 25 x 25 layers of the step: 320-row rings, many laps per K range
+    (16, 50, 50, 128, 128),       # one output tile, two 64-channel chunks
+    (8, 100, 100, 128, 256),      # 448-row rings
+    (8, 100, 100, 64, 64),        # <= 64 output channels: pixel halves, two slabs per range
+    (4, 200, 200, 64, 64),        # 640-row rings (the widest map inside the 8-wave form's LDS budget)
+    (24, 31, 45, 192, 200),       # odd map, three chunks, ragged second output tile (72 of 128 channels)
+    (48, 37, 29, 64, 40),         # <= 64 form with a ragged second quarter
+    (128, 17, 23, 64, 128),       # tiny maps: a K range crosses many images, most ring rows are padding
+])
+def test_ring_wgrad_8wave_form(B, H, W, Cin, Cout):
+    _run(B, H, W, Cin, Cout, seed=B + W)
 
 
 def test_ring_wgrad_concat_slices():
