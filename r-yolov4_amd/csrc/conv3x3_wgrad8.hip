@@ -280,17 +280,22 @@ bool w8_geometry(const WgradParams& p, W3Geom& g)
     const int need = 2 * (g.PWp + 1) + 209;                          // two halos + this step + the next + alignment slack (conv3x3.hip)
     const int rx = (int)ry_cdiv(need, 64) * 64;
     const unsigned lds = 2u * (unsigned)(rx + W8_MIRROR) * 64u + 2u * (unsigned)nco * 4096u;
-    static const int max_kib = getenv("RYOLO_W3_V8_LDS") ? atoi(getenv("RYOLO_W3_V8_LDS")) : 112;    // leave the main stream's kernels their LDS
+    // An 8-wave workgroup holds 2 x 224 of a SIMD's 512 registers: no wave of the main stream's matrix kernels fits beside it, the CU is this
+    // workgroup's alone whatever its LDS share — so the ring may take the whole 160 KiB (W = 400: 1024 rows, 148 KiB), and the grid is sized
+    // to HALF the chip: measured on the step (same box, alternating, img/s) 256 workgroups 879 (the 4-wave kernels at 256: 883), 192 888,
+    // 160 904*, 128 894 / 908*, 96 898*, 64 891* (* = a faster box).  The side stream then owns 128 CUs at full speed and the main stream the
+    // other 128 undisturbed, instead of both sharing every CU's issue slots, registers and LDS.
+    static const int max_kib = getenv("RYOLO_W3_V8_LDS") ? atoi(getenv("RYOLO_W3_V8_LDS")) : 160;
     if (lds > (unsigned)max_kib * 1024u) return false;
     const int gx = (int)ry_cdiv(p.Cout, 128), gc = p.Cin / 64;
-    static const int target = getenv("RYOLO_W3_BLOCKS") ? atoi(getenv("RYOLO_W3_BLOCKS")) : 256;      // one workgroup per CU
+    static const int target = getenv("RYOLO_W3_V8_BLOCKS") ? atoi(getenv("RYOLO_W3_V8_BLOCKS")) : 128;
     int64_t sk = ry_cdiv(target, (int64_t)gx * gc);
     static const int minsteps = getenv("RYOLO_W3_MINSTEPS") ? atoi(getenv("RYOLO_W3_MINSTEPS")) : 24;
     const int64_t maxsplit = g.Mp / ((int64_t)minsteps * 32);
     if (sk > maxsplit) sk = maxsplit;
     if (sk < 1) sk = 1;
     static const bool force = getenv("RYOLO_W3_FORCE") != nullptr;
-    if ((int64_t)gx * gc * sk < 64 && !force) return false;           // small problems: the generic kernel's finer tiles fill the chip better
+    if ((int64_t)gx * gc * sk < 48 && !force) return false;           // small problems: the generic kernel's finer tiles fill the chip better
     g.v8 = nco;
     g.co64 = nco == 2 ? 1 : 0;
     g.step64 = 1;

@@ -73,7 +73,8 @@ def test_ring_wgrad(B, H, W, Cin, Cout):
     (16, 50, 50, 128, 128),       # one output tile, two 64-channel chunks
     (8, 100, 100, 128, 256),      # 448-row rings
     (8, 100, 100, 64, 64),        # <= 64 output channels: pixel halves, two slabs per range
-    (4, 200, 200, 64, 64),        # 640-row rings (the widest map inside the 8-wave form's LDS budget)
+    (4, 200, 200, 64, 64),        # 640-row rings
+    (1, 400, 400, 64, 64),        # 1024-row rings: 148 KiB of LDS, the widest map of the 800 x 800 step
     (24, 31, 45, 192, 200),       # odd map, three chunks, ragged second output tile (72 of 128 channels)
     (48, 37, 29, 64, 40),         # <= 64 form with a ragged second quarter
     (128, 17, 23, 64, 128),       # tiny maps: a K range crosses many images, most ring rows are padding
