@@ -145,7 +145,8 @@ int ryolo_conv_gemm_plan(const ConvGemmParams* p, int* stats_rows, int* kernel);
 int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_bytes);
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
 /* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K (register-staged, or the LDS-DMA pointwise form), 1 the 3x3 stride-1 halo-ring
- * kernel (needs p->zeros), 2 the tapped LDS-DMA kernel (tapped / strided layers with > 64 output channels; needs p->zeros) */
+ * kernel (needs p->zeros), 2 the tapped LDS-DMA kernel (tapped / strided layers with > 64 output channels; needs p->zeros), 3 the 8-wave
+ * 256 x 256-tile pointwise kernel (stride-1 1x1 layers with Cin >= 256 and Cout > 128; needs p->zeros) */
 int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
 /* weights of a stride-2 3x3 (pad 1) data gradient in its space-to-depth form (ConvGemmParams.s2d_cin): w fp32 [Cout][Cin][3][3] ->
  * out bf16 [4 * Cin][4][round_up(Cout, 32)] */

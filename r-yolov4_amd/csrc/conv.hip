@@ -1517,6 +1517,11 @@ extern "C" int ryolo_conv_wgrad_plan(const WgradParams* pp, int* splitk, size_t*
     if (rc) return rc;
     W3Geom g3;
     if (w3_geometry(p, g3)) p.splitk = g3.slabs;               // 3x3 stride-1 layers: halo-ring kernel (conv3x3.hip)
+    else {
+        int sk8, gx8, gy8;
+        int64_t kc8;
+        if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) p.splitk = sk8;      // wide pointwise layers: 8-wave 256 x 256 tiles (wgrad1x1_8w.hip)
+    }
     *splitk = p.splitk;
     *workspace_bytes = (size_t)p.splitk * p.Cout * p.ntaps * p.Cin * sizeof(float);
     return RY_OK;
@@ -1536,7 +1541,7 @@ static bool wgrad_taps_dma(const WgradParams& p, int bm)
 }
 
 // 0: generic split-K kernels (conv.hip: register-staged, or the LDS-DMA pointwise form), 1: 3x3 stride-1 halo-ring kernel (conv3x3.hip),
-// 2: tapped LDS-DMA kernel (conv.hip) — what ryolo_conv_wgrad will launch
+// 2: tapped LDS-DMA kernel (conv.hip), 3: the 8-wave 256 x 256 pointwise kernel (wgrad1x1_8w.hip) — what ryolo_conv_wgrad will launch
 extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
 {
     if (!pp || !kernel) return RY_ERR_ARG;
@@ -1544,6 +1549,11 @@ extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
     *kernel = 0;
     if (w3_geometry(*pp, g3)) { *kernel = 1; return RY_OK; }
     WgradParams p = *pp;
+    {
+        int sk8, gx8, gy8;
+        int64_t kc8;
+        if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) { *kernel = 3; return RY_OK; }
+    }
     int bm, gx, gy;
     if (wgrad_geometry(p, bm, gx, gy) == RY_OK && wgrad_taps_dma(p, bm)) *kernel = 2;
     return RY_OK;
@@ -1565,6 +1575,17 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
         launch_wgrad_reduce(p, g3.slabs, stream);
         RY_CHECK_LAUNCH();
         return RY_OK;
+    }
+    {
+        int sk8, gx8, gy8;
+        int64_t kc8;
+        if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) {
+            const int rc8 = w1x8_launch(p, stream);
+            if (rc8) return rc8;
+            launch_wgrad_reduce(p, sk8, stream);
+            RY_CHECK_LAUNCH();
+            return RY_OK;
+        }
     }
     if ((int64_t)p.NB * p.OH * p.OW >= (1ll << 31)) return RY_ERR_UNSUPPORTED;       // 32-bit pixel indices in the gather
     auto wg_magic = [](unsigned d, unsigned& m, unsigned& sh) {      // n / d == mulhi(n, m) >> sh for 0 <= n < 2^31

@@ -247,6 +247,10 @@ int w3_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
 bool w8_geometry(const WgradParams& p, W3Geom& g);           // conv3x3_wgrad8.hip, called by w3_geometry on a W3Geom whose padded sizes / taps / magic numbers are set
 int w8_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
 
+// ---- pointwise weight gradient on 256 x 256 tiles, 8 waves (wgrad1x1_8w.hip): eligibility + split (what ryolo_conv_wgrad_plan reports), launch
+bool w1x8_geometry(const WgradParams& p, int* splitk, int64_t* kchunk, int* gx, int* gy);
+int w1x8_launch(const WgradParams& p, hipStream_t stream);
+
 // ---- weight-stationary persistent 1x1 GEMM (gemm1x1.hip): Cin <= 256, identity grid, bf16 epilogues ---------------------------------
 struct Ws1Geom {
     int ok;

@@ -257,6 +257,8 @@ class Graph:
             hip.call("ryolo_conv_wgrad_kernel", p, kern)
             if kern.value == 1:
                 return ("conv3x3_wgrad_kernel<128x9x32>", fl, by)
+            if kern.value == 3:
+                return ("wgrad1x1_8w_kernel<256x256>", fl, by)
             return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl, by)
         return (name, 0, 0)
 
