@@ -288,7 +288,7 @@ bool w8_geometry(const WgradParams& p, W3Geom& g)
     static const int max_kib = getenv("RYOLO_W3_V8_LDS") ? atoi(getenv("RYOLO_W3_V8_LDS")) : 160;
     if (lds > (unsigned)max_kib * 1024u) return false;
     const int gx = (int)ry_cdiv(p.Cout, 128), gc = p.Cin / 64;
-    static const int target = getenv("RYOLO_W3_V8_BLOCKS") ? atoi(getenv("RYOLO_W3_V8_BLOCKS")) : 128;
+    static const int target = getenv("RYOLO_W3_V8_BLOCKS") ? atoi(getenv("RYOLO_W3_V8_BLOCKS")) : 96;
     int64_t sk = ry_cdiv(target, (int64_t)gx * gc);
     static const int minsteps = getenv("RYOLO_W3_MINSTEPS") ? atoi(getenv("RYOLO_W3_MINSTEPS")) : 24;
     const int64_t maxsplit = g.Mp / ((int64_t)minsteps * 32);

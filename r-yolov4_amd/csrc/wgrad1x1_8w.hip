@@ -195,7 +195,7 @@ bool w1x8_geometry(const WgradParams& p, int* splitk, int64_t* kchunk, int* gx_o
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     if (M >= (1ll << 31) || M < 64) return false;
     const int gx = (int)ry_cdiv(p.Cout, 256), gy = (int)ry_cdiv(p.Cin, 256);
-    static const int target = getenv("RYOLO_WGRAD_8W_BLOCKS") ? atoi(getenv("RYOLO_WGRAD_8W_BLOCKS")) : 128;
+    static const int target = getenv("RYOLO_WGRAD_8W_BLOCKS") ? atoi(getenv("RYOLO_WGRAD_8W_BLOCKS")) : 96;
     int64_t sk = ry_cdiv(target, (int64_t)gx * gy);
     const int64_t maxsplit = ry_cdiv(M, 16 * 64);                     // at least 16 steps per split
     if (sk > maxsplit) sk = maxsplit;

@@ -11,6 +11,7 @@ launches (forward, backward) over pre-allocated NHWC bf16 buffers:
 PyTorch only owns the memory (torch.empty) and the stream.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -20,6 +21,8 @@ from . import structs as S
 
 BF16 = torch.bfloat16
 
+
+_DEBUG_SKIP_SIDE = os.environ.get("RYOLO_DEBUG_SKIP_SIDE") == "1"     # tools only: never set in a run that reports numbers
 
 class Buf:
     """[N*H*W, C] bf16 activation buffer (NHWC, channel stride = C) and, lazily, its gradient twin."""
@@ -353,7 +356,9 @@ class Graph:
                     main.wait_event(pending)
                     pending = None
             kind, fl, by, *sub = self.meta.get((tid, i), (name, 0, 0)) if timer is not None else (name, 0, 0)
-            if fl:
+            if on_side and side_idx is not None and _DEBUG_SKIP_SIDE:
+                rc = 0                               # diagnostic only (RYOLO_DEBUG_SKIP_SIDE=1): the step WITHOUT its weight gradients = what the main stream costs alone
+            elif fl:
                 e0, e1 = timer.pair()
                 e0.record(lane_stream if on_side else None)
                 rc = fn(*args, sst if on_side else st)
