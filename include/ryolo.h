@@ -148,6 +148,8 @@ int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
  * kernel (needs p->zeros), 2 the tapped LDS-DMA kernel (tapped / strided layers with > 64 output channels; needs p->zeros), 3 the 8-wave
  * 256 x 256-tile pointwise kernel (stride-1 1x1 layers with Cin >= 256 and Cout > 128; needs p->zeros) */
 int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
+/* launch shape of that kernel: workgroups, waves per workgroup (8: a workgroup holds its CU exclusively and the grid is sized to part of the chip) */
+int ryolo_conv_wgrad_grid(const WgradParams* p, int* workgroups, int* waves);
 /* weights of a stride-2 3x3 (pad 1) data gradient in its space-to-depth form (ConvGemmParams.s2d_cin): w fp32 [Cout][Cin][3][3] ->
  * out bf16 [4 * Cin][4][round_up(Cout, 32)] */
 int ryolo_pack_s2d(const float* w, int Cout, int Cin, bf16_t* out, ryolo_stream_t stream);

@@ -1559,6 +1559,34 @@ extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
     return RY_OK;
 }
 
+// launch shape of the split-K kernel ryolo_conv_wgrad will use: workgroups and waves per workgroup.  The 8-wave kernels (conv3x3_wgrad8.hip,
+// wgrad1x1_8w.hip) hold a CU exclusively (2 x ~200+ registers per SIMD lane, 76-150 KiB of LDS) and are sized to PART of the chip: a launch timed
+// alone then occupies `workgroups` of the 256 CUs — bench.py prices such a launch against the CUs it holds as well as against the whole chip.
+extern "C" int ryolo_conv_wgrad_grid(const WgradParams* pp, int* workgroups, int* waves)
+{
+    if (!pp || !workgroups || !waves) return RY_ERR_ARG;
+    WgradParams p = *pp;
+    int bm, gx, gy;
+    const int rc = wgrad_geometry(p, bm, gx, gy);
+    if (rc) return rc;
+    W3Geom g3;
+    if (w3_geometry(p, g3)) {
+        *workgroups = g3.gx * g3.gc * g3.splitk;
+        *waves = g3.v8 ? 8 : 4;
+        return RY_OK;
+    }
+    int sk8, gx8, gy8;
+    int64_t kc8;
+    if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) {
+        *workgroups = gx8 * gy8 * sk8;
+        *waves = 8;
+        return RY_OK;
+    }
+    *workgroups = gx * gy * p.splitk;
+    *waves = 4;
+    return RY_OK;
+}
+
 extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
 {
     if (!pp) return RY_ERR_ARG;

@@ -256,12 +256,16 @@ class Graph:
             p = args[0]
             fl = 2 * p.NB * p.OH * p.OW * p.Cout * p.ntaps * p.Cin
             by = p.NB * p.OH * p.OW * p.Cout * 2 + p.NB * p.IH * p.IW * p.Cin * 2 + p.Cout * p.ntaps * p.Cin * 4
-            kern = S.I()
+            kern, wgs, waves = S.I(), S.I(), S.I()
             hip.call("ryolo_conv_wgrad_kernel", p, kern)
+            hip.call("ryolo_conv_wgrad_grid", p, wgs, waves)
+            # fifth field: CUs a launch of this kernel holds when it runs alone (8-wave workgroups are CU-exclusive and the grid covers part
+            # of the chip: conv3x3_wgrad8.hip); None = the whole chip
+            cus = min(256, wgs.value) if waves.value == 8 else None
             if kern.value == 1:
-                return ("conv3x3_wgrad_kernel<128x9x32>", fl, by)
+                return ("conv3x3_wgrad_kernel<128x9x32>", fl, by, None, cus)
             if kern.value == 3:
-                return ("wgrad1x1_8w_kernel<256x256>", fl, by)
+                return ("wgrad1x1_8w_kernel<256x256>", fl, by, None, cus)
             return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl, by)
         return (name, 0, 0)
 

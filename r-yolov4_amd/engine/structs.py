@@ -89,6 +89,7 @@ for _name, _sig in {
     "ryolo_conv_wgrad": [_PTR(WgradParams), P],
     "ryolo_conv_wgrad_plan": [_PTR(WgradParams), _PTR(I), _PTR(Z)],
     "ryolo_conv_wgrad_kernel": [_PTR(WgradParams), _PTR(I)],
+    "ryolo_conv_wgrad_grid": [_PTR(WgradParams), _PTR(I), _PTR(I)],
     "ryolo_stem3x3_plan": [I, I, I, I, _PTR(I), _PTR(Z)],
     "ryolo_stem3x3_fwd": [_PTR(StemParams), P],
     "ryolo_stem3x3_wgrad": [_PTR(StemWgradParams), P],
