@@ -85,6 +85,10 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_8w_kernel(const WgradParams p
     for (int i = 0; i < 4; i++) fa[i] = lds_addr(w1x8_lds) + fr_row * 512u + (unsigned)(((4 * wm + i) ^ (int)(fr_row & 3u)) * 64) + fr_col;
 #pragma unroll
     for (int j = 0; j < 2; j++) fb[j] = lds_addr(w1x8_lds) + (unsigned)OPB + fr_row * 512u + (unsigned)(((2 * wn + j) ^ (int)(fr_row & 3u)) * 64) + fr_col;
+    // Layers narrower than the tile (Cout <= 128: the wm = 1 waves; Cin = 128: the wn >= 2 waves) keep the 8-wave shape: the waves without a
+    // block still bring their share of the stage, the others compute — those layers are HBM-bound (<= 128 flop/B), the matrix rate of two or
+    // four waves per CU covers their bytes, and they stay on the side stream's CUs instead of spreading thin over the chip.
+    const bool active = (i0 + 128 * wm < p.Cout) && (j0 + 64 * wn < p.Cin);
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -124,8 +128,10 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_8w_kernel(const WgradParams p
                 ah[ks & 1][i] = lds_tr16_off<off + 2048>(fa[i] + sb);
             }
         };
-        read_first(std::integral_constant<int, 0>{});
-        read_second(std::integral_constant<int, 0>{});
+        if (active) {
+            read_first(std::integral_constant<int, 0>{});
+            read_second(std::integral_constant<int, 0>{});
+        }
         auto slice = [&](auto kc) {
             constexpr int ks = decltype(kc)::value;
             constexpr bool last = ks == 3;
@@ -161,15 +167,21 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_8w_kernel(const WgradParams p
                 }
             }
         };
-        slice(std::integral_constant<int, 0>{});
-        slice(std::integral_constant<int, 1>{});
-        slice(std::integral_constant<int, 2>{});
-        slice(std::integral_constant<int, 3>{});
+        if (active) {
+            slice(std::integral_constant<int, 0>{});
+            slice(std::integral_constant<int, 1>{});
+            slice(std::integral_constant<int, 2>{});
+            slice(std::integral_constant<int, 3>{});
+        } else if (more) {                                            // a wave whose 128 x 64 block lies outside the layer only moves data
+#pragma unroll
+            for (int u = 0; u < 8; u++) issue_piece((s + 1) & 1, u);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (more) advance();
     }
     // split-K partial tile -> workspace [z][Cout][Cin] fp32
     float* part = p.partial + (int64_t)bz * p.Cout * p.Cin;
+    if (!active) return;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int ci = j0 + 64 * wn + 32 * j + (lane & 31);
@@ -190,7 +202,11 @@ bool w1x8_geometry(const WgradParams& p, int* splitk, int64_t* kchunk, int* gx_o
     static const int on = getenv("RYOLO_WGRAD_8W") ? atoi(getenv("RYOLO_WGRAD_8W")) : 1;       // A/B knob
     if (!on || !p.zeros) return false;
     if (p.ntaps != 1 || p.dh[0] != 0 || p.dw[0] != 0 || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
-    if (p.Cin < 256 || p.Cin % 32 || p.Cout <= 128) return false;     // narrower layers: a 256-wide tile would idle half its waves
+    // Cin >= 256 and Cout > 128 by default.  Narrower layers (down to 128 channels: RYOLO_WGRAD_8W_MINC=128) run correctly with idle waves (`active`
+    // in the kernel; tests/test_gpu_wgrad1x1.py forces it) but cost the step 1 % (same box, three alternating runs: 905.9 vs 894.4 img/s): their
+    // 4-wave launches are short, HBM-bound and overlap well as they are.
+    static const int min_c = getenv("RYOLO_WGRAD_8W_MINC") ? atoi(getenv("RYOLO_WGRAD_8W_MINC")) : 256;
+    if (p.Cin < min_c || p.Cin % 32 || p.Cout <= min_c / 2) return false;
     if (p.ldX % 8 || p.ldY % 8 || p.CoutPad % 8 || ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15)) return false;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     if (M >= (1ll << 31) || M < 64) return false;

@@ -2,7 +2,7 @@
 through the C ABI against torch's fp32 conv weight gradient on the same bf16 operands (model/utils.py:6-32 `Conv` with k = 1: autograd of
 nn.Conv2d w.r.t. its weight).  Ragged tiles on both channel axes (Cout = 396 = the merged head width of the bench network, Cin = 320), channel
 strides wider than the tensors (concat slices), K ranges that end inside a 64-pixel step, accumulation into an existing gradient; dispatch is
-asserted (kernel 3), narrower layers must stay on the 4-wave kernels.  Tolerance 2e-3 relative (bf16 operands, fp32 accumulation in a
+asserted (kernel 3), narrower layers stay on the 4-wave kernels by default (the idle-wave form of the 8-wave kernel is tested behind its knob).  Tolerance 2e-3 relative (bf16 operands, fp32 accumulation in a
 different order).  The 4-wave kernels keep their coverage for these shapes through RYOLO_WGRAD_8W=0 in tests/test_gpu_forced_kernels.py."""
 import pytest
 
@@ -30,3 +30,19 @@ def test_pointwise_wgrad_8wave_concat_slices():
 def test_narrow_pointwise_layers_stay_on_the_4wave_kernels():
     _run(8, 50, 50, 128, 256, k=(1, 1), stride=1, seed=6, expect=0)
     _run(8, 50, 50, 256, 128, k=(1, 1), stride=1, seed=7, expect=0)
+
+
+def test_layers_narrower_than_the_tile_idle_some_waves():
+    """RYOLO_WGRAD_8W_MINC=128 (off by default: -1 % on the step): Cout <= 128 (the wm = 1 waves have no block), Cin = 128 (the wn >= 2 waves), both —
+    those waves only move data.  The knob is read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+    code = ("from tests.test_gpu_wgrad_taps import _run\n"
+            "_run(24, 50, 50, 128, 256, k=(1, 1), stride=1, seed=6, expect=3)\n"
+            "_run(24, 50, 50, 256, 128, k=(1, 1), stride=1, seed=7, expect=3)\n"
+            "_run(24, 50, 50, 128, 128, k=(1, 1), stride=1, seed=8, expect=3)\n"
+            "_run(24, 50, 50, 192, 72, k=(1, 1), stride=1, seed=9, expect=0)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RYOLO_WGRAD_8W_MINC="128"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
