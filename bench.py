@@ -100,7 +100,7 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
 }
 
 
-PMC_PROFILE = "profiles/r04_pmc_step_traffic.json"        # regenerated by tools/pmc_step.sh whenever a kernel of the step changes
+PMC_PROFILE = "profiles/r05_pmc_step_traffic.json"        # regenerated by tools/pmc_step.sh whenever a kernel of the step changes
 
 
 def source_sha256():

@@ -1,13 +1,13 @@
-# End-of-round evidence on ONE GPU box (run from the repo root through gpurun; round 4): PMC step traffic, default bench line, rocprofv3 kernel
-# stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/r04m/
+# End-of-round evidence on ONE GPU box (run from the repo root through gpurun; round 5): PMC step traffic, default bench line, rocprofv3 kernel
+# stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/r05m/
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04m
+O=$R/gpurun_out/r05m
 mkdir -p $O
 cd $R
 # 1. PMC traffic of the step (then the bench line reads it)
-timeout 1500 bash tools/pmc_step.sh r04 > $O/pmc_step.txt 2>&1
-cp gpurun_out/r04_pmc_step_traffic.json profiles/r04_pmc_step_traffic.json
+timeout 1500 bash tools/pmc_step.sh r05 > $O/pmc_step.txt 2>&1
+cp gpurun_out/r05_pmc_step_traffic.json profiles/r05_pmc_step_traffic.json
 # 2. default bench line
 ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
 # 3. rocprofv3 kernel stats, serialized streams, b64 and b8
@@ -18,6 +18,16 @@ cd $R
 # 4. per-launch tables
 B=64 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b64.txt 2>&1
 B=8 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b8.txt 2>&1
+# 4a. the 8-wave weight-gradient kernels ALONE: whole-chip grids (256 workgroups) and the shipped part-of-the-chip grids (96), old 4-wave kernels beside them
+( for sh in "64 100 128 128 3" "64 50 256 256 3" "64 25 512 512 3" "64 100 64 64 3" "64 200 64 64 3" "64 400 64 64 3" "64 100 128 256 3" "64 200 256 256 1" "64 100 512 512 1" "64 50 1024 1024 1" "64 25 2048 512 1"; do
+    set -- $sh
+    for cfg in "RYOLO_W3_V8=0 RYOLO_WGRAD_8W=0" "RYOLO_W3_V8_BLOCKS=256 RYOLO_WGRAD_8W_BLOCKS=256" "RYOLO_W3_V8_BLOCKS=96 RYOLO_WGRAD_8W_BLOCKS=96"; do
+      echo "[$cfg] $(env $cfg CHECK=0 python tools/bench_wgrad.py $1 $2 $3 $4 $5 1 20 2>&1 | tail -1)"
+    done
+  done ) > $O/wgrad_isolated.txt 2>&1
+# 4a'. PMC groups for the ring weight-gradient kernel: 8-wave form at whole-chip sizing, 4-wave form beside it
+( RYOLO_W3_V8_BLOCKS=256 bash tools/pmc_wgrad.sh v8_128x128_100 64 100 128 128 3 1 3; RYOLO_W3_V8=0 bash tools/pmc_wgrad.sh w4_128x128_100 64 100 128 128 3 1 3;
+  RYOLO_W3_V8_BLOCKS=256 bash tools/pmc_wgrad.sh v8_64x64_200 64 200 64 64 3 1 3; RYOLO_WGRAD_8W_BLOCKS=256 bash tools/pmc_wgrad.sh p8_512x512_100 64 100 512 512 1 1 3 ) > $O/pmc_wgrad.txt 2>&1
 # 4b. BatchNorm + activation passes alone (forward, backward reduce + finalize, backward apply) and socket power / clocks while the step runs
 timeout 300 python tools/bench_bnact.py 10 > $O/bnact_passes.txt 2>&1
 set +x

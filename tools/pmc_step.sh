@@ -2,7 +2,7 @@
 # HBM traffic of every kernel class of one training step: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes
 # (MI355X_MICROARCH.md: they do not fit one pass; never combined with sys/hip tracing).  Run on the GPU box from the repo root:
 #   bash tools/pmc_step.sh [round tag, default r02]   ->  gpurun_out/<tag>_pmc_step_traffic.json  (copy to profiles/)
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 STEPS=3

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 ARGS="$@"
-for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM" "TCP_TCC_READ_REQ TCC_HIT TCC_MISS TCC_REQ" "FETCH_SIZE" "WRITE_SIZE"; do
+for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "TCP_TCC_READ_REQ TCC_HIT TCC_MISS TCC_REQ" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES"; do
   tag=$(echo $pass | cut -d' ' -f1)
   CHECK=0 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmcw_${TAG}_$tag -o p -- python $R/tools/bench_wgrad.py $ARGS > /dev/null 2>&1
 done
