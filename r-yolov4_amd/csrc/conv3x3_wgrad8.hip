@@ -54,7 +54,11 @@ template <int N> __device__ __forceinline__ void w8_wait6(ry_s16x4& a, ry_s16x4&
 template <int NCO>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParams p, const W3Geom g)
 {
-    constexpr int DYS = NCO * 4096;                                  // one dY stage: [NCO quarters][4 slots of 8 channels][64 px][16 B]
+    // one dY stage: [NCO quarters][4 slots of 8 channels][64 px][16 B] with 64 bytes of padding behind every slot: a transposed fragment read
+    // touches 4 rows x 16 B of each of the 4 slots, and with 1024-byte slots all four sit on the same 16 banks — a 4-way conflict on every dY
+    // read (PMC of the first cut: SQ_LDS_BANK_CONFLICT 48 % of SQ_LDS_IDX_ACTIVE; the 4-wave kernels have the same layout but read dY a
+    // quarter as often).  1088-byte slots put them on banks 0 / 16 / 32 / 48.
+    constexpr int DSL = 1024 + 64, DQS = 4 * DSL, DYS = NCO * DQS;
     constexpr int NKS = NCO == 4 ? 4 : 2;                            // 16-pixel slices a wave multiplies per step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
     };
     auto issue_dy1 = [&](int stage, int u) {
         const bf16_t* src = (dsrc && (u ? d_ok1 : d_ok0)) ? dsrc + u * 8 : p.zeros;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + dqr * 4096 + (ds0 + u) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + dqr * DQS + (ds0 + u) * DSL), 16, 0, 0);
         if (u == NDY - 1) dq += 64;
     };
     for (int it = 0; it < pro_iters; it++) { prep_x(); issue_x(); }   // rows of step 0 with both halos
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
     const int fr_col = (16 * (grp & 1) + 4 * (s16 & 3)) * 2;
     const unsigned xr_l = lds_addr(w8_lds) + (unsigned)cc * RB + (unsigned)(fr_row * 64 + fr_col);     // lane constant inside this wave's ring
     // dY fragment (slot-major stage): channel fr_col / 2 = 8 * slot + c of quarter q0 (+ 1), row 32 kh + 16 ks + fr_row (+ 4)
-    const unsigned da_l = lds_addr(dyst) + (unsigned)(q0 * 4096 + (fr_col >> 4) * 1024 + (32 * kh + fr_row) * 16 + (fr_col & 15));
+    const unsigned da_l = lds_addr(dyst) + (unsigned)(q0 * DQS + (fr_col >> 4) * DSL + (32 * kh + fr_row) * 16 + (fr_col & 15));
     int rp = (int)kbeg + 32 * kh - x0;                                // (scalar) ring row of this wave's first pixel of the step, < RX:
     if (rp >= RX) rp -= RX;                                           //   kbeg - x0 < HALO + 64 and RX >= 2 HALO + 209
 #ifdef W3_TIMING
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
                     constexpr unsigned ao = (unsigned)(16 * ks * 16);
                     al[ks & 1][0] = lds_tr16_off<ao>(da_s);
                     ah[ks & 1][0] = lds_tr16_off<ao + 64>(da_s);
-                    al[ks & 1][1] = lds_tr16_off<ao + 4096>(da_s);
-                    ah[ks & 1][1] = lds_tr16_off<ao + 4096 + 64>(da_s);
+                    al[ks & 1][1] = lds_tr16_off<ao + DQS>(da_s);
+                    ah[ks & 1][1] = lds_tr16_off<ao + DQS + 64>(da_s);
                 }
                 if constexpr (j == 0 || dwi == 0) {                   // first tap of a kernel row in this wave's list: its base, wrapped once
                     int v = rp + 16 * ks + (dhi - 1) * PWp - 1;       // scalar; |16 ks + (dh) PWp - 1| < RX
@@ -279,7 +283,7 @@ bool w8_geometry(const WgradParams& p, W3Geom& g)
     const int nco = p.Cout <= 64 ? 2 : 4;
     const int need = 2 * (g.PWp + 1) + 209;                          // two halos + this step + the next + alignment slack (conv3x3.hip)
     const int rx = (int)ry_cdiv(need, 64) * 64;
-    const unsigned lds = 2u * (unsigned)(rx + W8_MIRROR) * 64u + 2u * (unsigned)nco * 4096u;
+    const unsigned lds = 2u * (unsigned)(rx + W8_MIRROR) * 64u + 2u * (unsigned)nco * 4352u;           // (dY stages: 4 slots of 1088 B per quarter)
     // An 8-wave workgroup holds 2 x 224 of a SIMD's 512 registers: no wave of the main stream's matrix kernels fits beside it, the CU is this
     // workgroup's alone whatever its LDS share — so the ring may take the whole 160 KiB (W = 400: 1024 rows, 148 KiB), and the grid is sized
     // to HALF the chip: measured on the step (same box, alternating, img/s) 256 workgroups 879 (the 4-wave kernels at 256: 883), 192 888,

@@ -42,7 +42,8 @@ def test_layers_narrower_than_the_tile_idle_some_waves():
             "_run(24, 50, 50, 128, 256, k=(1, 1), stride=1, seed=6, expect=3)\n"
             "_run(24, 50, 50, 256, 128, k=(1, 1), stride=1, seed=7, expect=3)\n"
             "_run(24, 50, 50, 128, 128, k=(1, 1), stride=1, seed=8, expect=3)\n"
-            "_run(24, 50, 50, 192, 72, k=(1, 1), stride=1, seed=9, expect=0)\n")
+            "_run(24, 50, 50, 192, 72, k=(1, 1), stride=1, seed=9, expect=3)\n"          # ragged first tile: 72 of 256 output channels
+            "_run(24, 50, 50, 192, 64, k=(1, 1), stride=1, seed=10, expect=0)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RYOLO_WGRAD_8W_MINC="128"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -51,7 +51,8 @@ def _run(B, H, W, Cin, Cout, k=(3, 3), stride=2, ldx_extra=0, ldy_extra=0, seed=
     torch.nn.functional.conv2d(xr, w0, stride=stride, padding=(ph, pw)).backward(dy[:, :Cout].float().view(B, OH, OW, Cout).permute(0, 3, 1, 2))
     ref = w0.grad.reshape(Cout, Cin, kh * kw)
     got = dw - dw0                                                    # the kernel ACCUMULATES into the gradient
-    assert float((got - ref).norm() / ref.norm()) < 2e-3
+    err = float((got - ref).norm() / ref.norm())
+    assert err < 2e-3, f"relative error {err:.3e} (max abs {float((got - ref).abs().max()):.3e}, reference norm {float(ref.norm()):.3e})"
     # per-tap check: a wrong tap offset on one tap hides inside a norm over nine
     for t in range(kh * kw):
         assert float((got[:, :, t] - ref[:, :, t]).norm() / ref[:, :, t].norm()) < 4e-3, f"tap {t}"
