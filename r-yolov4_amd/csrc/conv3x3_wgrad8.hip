@@ -78,6 +78,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
     const int H = p.OH, W = p.OW, PWp = g.PWp, HPp = g.HPp;
     const int HALO = PWp + 1;
     const int RX = g.RX;
+    // PD = prefetch distance in steps (g.pd): the requests issued during step s bring the operands of step s + PD into dY stage (s + PD) % (PD + 1)
+    // and PD * 64 rows further down the rings.  All 8 waves of the CU meet at ONE barrier per step, so whatever a step waits for at its top is
+    // exposed on every SIMD at once (the 4-wave kernels ran two independent workgroups per CU): PD = 1 left 27 % of the wave cycles parked in
+    // s_waitcnt / s_barrier (PMC, profiles/r05_pmc_wgrad_ring) — a step of ~1 us does not cover an HBM round trip under load; PD = 2 does,
+    // for one more dY stage and 64 more ring rows of LDS (the CU is this workgroup's alone anyway).
+    const int PD = g.pd;
     const unsigned RB = (unsigned)(RX + W8_MIRROR) * 64u;             // bytes of one ring with its mirrored head
     unsigned char* const dyst = w8_lds + 2u * RB;
     const int kend32 = (int)kend, Mp32 = (int)g.Mp;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
     const bf16_t* const dy_base = p.dY + i0 + 32 * dqr + ds0 * 8;
     const bool d_ok0 = (i0 + 32 * dqr + ds0 * 8) < p.CoutPad, d_ok1 = (i0 + 32 * dqr + ds0 * 8 + 8) < p.CoutPad;
     const int x0 = (int)(((kbeg - HALO) >> 6) << 6);                 // ring origin: aligned down to 64 (arithmetic shift: also for negatives)
-    const int pro_iters = ((int)kbeg + 64 + HALO + 16 - x0 + 63) >> 6;
+    const int pro_iters = ((int)kbeg + 64 * PD + HALO + 16 - x0 + 63) >> 6;
     int xq = x0 + 16 * xp + (lane >> 2);                              // this lane's padded row of the next ring request
     int xslot = 16 * xp;                                              // (scalar) ring row the next piece lands on
     int dq = (int)kbeg + lane;                                        // this lane's dY pixel of the next request
@@ -119,11 +125,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
         dsrc = ok ? dy_base + (int64_t)pix * p.ldY : nullptr;
     };
     unsigned char* const xring_w = w8_lds + (unsigned)xc * RB;        // the ring this wave fills
+    int n_issued = 0;                                                 // (scalar) LDS-DMA instructions of the current step so far
     auto issue_x = [&]() {
         const bf16_t* src = xsrc ? xsrc : p.zeros;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring_w + (unsigned)xslot * 64u), 16, 0, 0);
-        if (xslot < W8_MIRROR)                                        // wave-uniform: twice per lap of the ring
+        n_issued++;
+        if (xslot < W8_MIRROR) {                                      // wave-uniform: twice per lap of the ring
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xring_w + (unsigned)(xslot + RX) * 64u), 16, 0, 0);
+            n_issued++;
+        }
         xq += 64;
         xslot += 64;
         if (xslot >= RX) xslot -= RX;
@@ -131,14 +141,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
     auto issue_dy1 = [&](int stage, int u) {
         const bf16_t* src = (dsrc && (u ? d_ok1 : d_ok0)) ? dsrc + u * 8 : p.zeros;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dyst + stage * DYS + dqr * DQS + (ds0 + u) * DSL), 16, 0, 0);
+        n_issued++;
         if (u == NDY - 1) dq += 64;
     };
-    for (int it = 0; it < pro_iters; it++) { prep_x(); issue_x(); }   // rows of step 0 with both halos
+    for (int it = 0; it < pro_iters; it++) { prep_x(); issue_x(); }   // rows of steps 0 .. PD - 1 with both halos
     prep_dy();
 #pragma unroll
     for (int u = 0; u < NDY; u++) issue_dy1(0, u);
-    prep_x();                                                         // the requests of step 0 (operands of step 1)
+    int pend = 0;                                                     // (scalar) LDS-DMA instructions this wave issued for a LATER step than the next one to run
+    if (PD == 2 && nk > 1) {                                          // dY of step 1: the only requests that may still be in flight when step 0 starts
+        prep_dy();
+#pragma unroll
+        for (int u = 0; u < NDY; u++) issue_dy1(1, u);
+        pend = NDY;
+    }
+    prep_x();                                                         // the requests of step 0 (operands of step PD)
     prep_dy();
+    auto wait_pending = [&]() {                                       // "at most `pend` of my requests in flight": in-order return = everything older has landed
+        if (pend == 0) w8_wait_vm<0>();
+        else if (pend == 1) w8_wait_vm<1>();
+        else if (pend == 2) w8_wait_vm<2>();
+        else if (pend == 3) w8_wait_vm<3>();
+        else w8_wait_vm<4>();
+    };
 
     // ---- fragment addressing: transposed reads, lane -> (pixel row, channel) inside a 16-lane group (conv.hip)
     const int s16 = lane & 15, grp = lane >> 4;
@@ -166,11 +191,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[j][a][e] = 0.f;
+        int st_cur = 0, st_nxt = PD == 2 ? 2 : 1;                     // dY stage of this step, stage the step's requests fill: (s + PD) % (PD + 1)
         for (int s = 0; s < nk; s++) {
 #ifdef W3_TIMING
             const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-            w8_wait_vm<0>();                                          // everything this wave requested one step ago has landed
+            wait_pending();                                           // this wave's requests for step s have landed (those for step s + 1 may fly on: PD = 2)
 #ifdef W3_TIMING
             const unsigned long long tw1 = __builtin_readcyclecounter();
 #endif
@@ -179,8 +205,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
             t_wait += tw1 - tw0;
             t_bar += __builtin_readcyclecounter() - tw1;
 #endif
-            const bool more = s + 1 < nk;
-            const unsigned da_s = da_l + (unsigned)((s & 1) * DYS);
+            const bool more = s + PD < nk;
+            const unsigned da_s = da_l + (unsigned)(st_cur * DYS);
+            n_issued = 0;
             ry_s16x4 al[2][2], ah[2][2], bl[NU], bh[NU];              // [slice parity][quarter]: the dY pair of slice ks + 1 is read under slice ks
             unsigned gaddr[2 * NKS];                                  // lane address of the dw = -1 fragment of a (slice, kernel row) group
             auto read_u = [&](auto uc) {
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
                         if constexpr (U == 0) issue_x();
-                        else issue_dy1((s + 1) & 1, U - 1);
+                        else issue_dy1(st_nxt, U - 1);
                     }
                 }
                 if constexpr (U == NU / 2 + 1 || U == NU / 2 + 3) {
@@ -244,6 +271,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad8_kernel(const WgradParam
             __builtin_amdgcn_sched_barrier(0);
             rp += 64;
             if (rp >= RX) rp -= RX;
+            pend = PD == 2 ? n_issued : 0;                            // PD = 1: the next step needs what this one requested
+            st_cur = st_cur + 1 > PD ? 0 : st_cur + 1;
+            st_nxt = st_nxt + 1 > PD ? 0 : st_nxt + 1;
         }
 #ifdef W3_TIMING
         const unsigned long long T2 = __builtin_readcyclecounter();
@@ -281,9 +311,16 @@ bool w8_geometry(const WgradParams& p, W3Geom& g)
     static const int on = getenv("RYOLO_W3_V8") ? atoi(getenv("RYOLO_W3_V8")) : 1;          // A/B knob: 0 = the 4-wave kernels of r03 / r04
     if (!on || p.Cin % 64) return false;
     const int nco = p.Cout <= 64 ? 2 : 4;
-    const int need = 2 * (g.PWp + 1) + 209;                          // two halos + this step + the next + alignment slack (conv3x3.hip)
-    const int rx = (int)ry_cdiv(need, 64) * 64;
-    const unsigned lds = 2u * (unsigned)(rx + W8_MIRROR) * 64u + 2u * (unsigned)nco * 4352u;           // (dY stages: 4 slots of 1088 B per quarter)
+    static const int pd_max = getenv("RYOLO_W3_V8_PD") ? atoi(getenv("RYOLO_W3_V8_PD")) : 2;       // A/B knob: 1 = the first cut (one step of prefetch)
+    int pd = pd_max >= 2 ? 2 : 1, rx = 0;
+    unsigned lds = 0;
+    for (; pd >= 1; pd--) {                                          // two steps of prefetch where the LDS has the room (every map of the 800 x 800 step but 400 x 400)
+        const int need = 2 * (g.PWp + 1) + 209 + 64 * (pd - 1);      // two halos + this step + the pd steps in flight + alignment slack (conv3x3.hip)
+        rx = (int)ry_cdiv(need, 64) * 64;
+        lds = 2u * (unsigned)(rx + W8_MIRROR) * 64u + (unsigned)(pd + 1) * (unsigned)nco * 4352u;     // (dY stages: 4 slots of 1088 B per quarter)
+        if (lds <= 160u * 1024u) break;
+    }
+    if (pd < 1) return false;
     // An 8-wave workgroup holds 2 x 224 of a SIMD's 512 registers: no wave of the main stream's matrix kernels fits beside it, the CU is this
     // workgroup's alone whatever its LDS share — so the ring may take the whole 160 KiB (W = 400: 1024 rows, 148 KiB), and the grid is sized
     // to HALF the chip: measured on the step (same box, alternating, img/s) 256 workgroups 879 (the 4-wave kernels at 256: 883), 192 888,
@@ -301,6 +338,7 @@ bool w8_geometry(const WgradParams& p, W3Geom& g)
     static const bool force = getenv("RYOLO_W3_FORCE") != nullptr;
     if ((int64_t)gx * gc * sk < 48 && !force) return false;           // small problems: the generic kernel's finer tiles fill the chip better
     g.v8 = nco;
+    g.pd = pd;
     g.co64 = nco == 2 ? 1 : 0;
     g.step64 = 1;
     g.mirror = 1;

@@ -236,6 +236,7 @@ struct W3Geom {
     int toff[9];               // dh * PWp + dw per tap (caller's tap order)
     int tap_of[9];             // caller's tap index of the tap (dh, dw) at 3 * (dh + 1) + (dw + 1) (the 64-pixel kernels walk the taps row by row)
     int mirror;                // 1: the ring is followed by a copy of its first 16 rows (conv3x3_wgrad64_kernel: immediate row offsets never wrap)
+    int pd;                    // conv3x3_wgrad8_kernel: prefetch distance in steps (1 or 2)
     int v8;                    // 0: the 4-wave kernels of conv3x3.hip; 2 / 4: conv3x3_wgrad8_kernel<NCO> (conv3x3_wgrad8.hip), gc then counts 64-channel chunks
     unsigned lds_bytes;
     // exact n / d for 0 <= n < 2^31 as (mulhi(n, m) >> s): d = HPp * PWp (padded pixels per image) and d = PWp (padded row length) —
