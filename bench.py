@@ -95,7 +95,8 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
     "conv3x3_ws64_kernel": r"conv3x3_ws64_kernel<",                                   # persistent weight-stationary 64 -> <= 64 channel 3x3 (conv3x3_ws.hip)
     "conv_wgrad_kernel<128>": r"conv_wgrad_kernel<128, |wgrad1x1_dma_kernel|wgrad_taps_dma_kernel",   # (register-staged + the LDS-DMA pointwise / tapped forms)
     "conv_wgrad_kernel<64>": r"conv_wgrad_kernel<64, ",
-    "wgrad1x1_8w_kernel<256x256>": r"wgrad1x1_8w_kernel",                              # 8-wave pointwise weight gradient (wgrad1x1_8w.hip)
+    "wgrad1x1_8w_kernel<256x256>": r"wgrad1x1_8w_kernel",
+    "conv3x3s2_wgrad8_kernel": r"conv3x3s2_wgrad8_kernel",                            # 8-wave parity-plane ring weight gradient of the stride-2 3x3 layers                              # 8-wave pointwise weight gradient (wgrad1x1_8w.hip)
     "conv3x3_wgrad_kernel<128x9x32>": r"conv3x3_wgrad(64|8)?_kernel<",
 }
 

@@ -146,7 +146,8 @@ int ryolo_conv_wgrad_plan(const WgradParams* p, int* splitk, size_t* workspace_b
 int ryolo_conv_wgrad(const WgradParams* p, ryolo_stream_t stream);
 /* which kernel ryolo_conv_wgrad launches for *p: 0 generic split-K (register-staged, or the LDS-DMA pointwise form), 1 the 3x3 stride-1 halo-ring
  * kernel (needs p->zeros), 2 the tapped LDS-DMA kernel (tapped / strided layers with > 64 output channels; needs p->zeros), 3 the 8-wave
- * 256 x 256-tile pointwise kernel (stride-1 1x1 layers with Cin >= 256 and Cout > 128; needs p->zeros) */
+ * 256 x 256-tile pointwise kernel (stride-1 1x1 layers with Cin >= 256 and Cout > 128; needs p->zeros), 4 the 8-wave parity-plane ring kernel
+ * (3x3 stride-2 pad-1 layers with more than 64 output channels; needs p->zeros) */
 int ryolo_conv_wgrad_kernel(const WgradParams* p, int* kernel);
 /* launch shape of that kernel: workgroups, waves per workgroup (8: a workgroup holds its CU exclusively and the grid is sized to part of the chip) */
 int ryolo_conv_wgrad_grid(const WgradParams* p, int* workgroups, int* waves);

@@ -252,6 +252,10 @@ int w8_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
 bool w1x8_geometry(const WgradParams& p, int* splitk, int64_t* kchunk, int* gx, int* gy);
 int w1x8_launch(const WgradParams& p, hipStream_t stream);
 
+// ---- 3x3 stride-2 weight gradient on parity-plane rings, 8 waves (conv3x3s2_wgrad8.hip): eligibility (+ slabs, workgroups), launch
+bool ws2_geometry(const WgradParams& p, int* slabs, int* workgroups);
+int ws2_launch(const WgradParams& p, hipStream_t stream);
+
 // ---- weight-stationary persistent 1x1 GEMM (gemm1x1.hip): Cin <= 256, identity grid, bf16 epilogues ---------------------------------
 struct Ws1Geom {
     int ok;
