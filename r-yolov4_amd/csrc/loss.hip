@@ -468,6 +468,11 @@ __global__ __launch_bounds__(256) void loss_match_grad_kernel(const LossParams p
     const int c0 = p.mode == 0 ? 5 : 6;
     const float kc = p.cls * inv_n / (float)(p.nc > 0 ? p.nc : 1);
     const float kt = p.theta_gain * inv_n / 180.f;
+    // (r05: the gradient map is no longer cleared beforehand — this kernel defines every element of an owned row except the objectness one,
+    // loss_obj_kernel the rest of the map)
+    if (p.nc == 1 && lane == 0) gp[c0] = 0.f;                                    // a single class carries no class term (lib/loss.py:223,399)
+    if (p.nc > 64)
+        for (int k = lane; k < p.nc; k += 64) gp[c0 + k] = 0.f;                  // wide class heads accumulate in memory below (same lane, program order)
     float gbox[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float gcls = 0.f, gth[3] = {0.f, 0.f, 0.f};
     const float xc = (p.nc > 1 && lane < p.nc) ? ps[c0 + lane] : 0.f;             // nc <= 64 classes per lane pass (looped below if more)
@@ -526,12 +531,61 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
     const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
     const int och = p.mode == 0 ? 4 : 5;
     const float kg = p.obj / (float)s.cells;
+    const float rattrs = 1.0f / (float)attrs;
+    const int lane = threadIdx.x & 63;
     float acc = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < s.cells; i += gridDim.x * 256) {
-        const float x = p.head[scale][(int64_t)i * attrs + och];
-        const float t = s.tconf[i];
-        acc += fl_val(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
-        if (p.compute_grad) p.grad[scale][(int64_t)i * attrs + och] = kg * fl_grad(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
+    // r05: this kernel also DEFINES the gradient map (it used to be cleared by a 1.3 GB hipMemsetAsync at the benchmark size, long before this pass
+    // scattered one float per 88-byte row into it).  A wave owns 64 consecutive cells = one contiguous run of 64 * attrs floats: it writes the whole
+    // run — zeros with the objectness gradient in place — as 16-byte stores; rows of MATCHED cells (owner >= 0) keep what loss_match_grad_kernel
+    // wrote before this launch, so a run that holds one takes the element-wise path.  Same cell -> thread mapping and summation order as before:
+    // loss values are bit-identical.
+    for (int ib = blockIdx.x * 256; ib < s.cells; ib += gridDim.x * 256) {          // (uniform trip count: the shuffles below need every lane)
+        const int i = ib + threadIdx.x;
+        const bool valid = i < s.cells;
+        float g = 0.f;
+        if (valid) {
+            const float x = p.head[scale][(int64_t)i * attrs + och];
+            const float t = s.tconf[i];
+            acc += fl_val(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
+            if (p.compute_grad) g = kg * fl_grad(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
+        }
+        if (!p.compute_grad) continue;
+        const int w0 = ib + (int)(threadIdx.x & ~63u);                              // first cell of this wave's run
+        if (w0 >= s.cells) continue;                                                // (wave-uniform)
+        const int ncell = min(64, s.cells - w0);
+        const int own = valid ? s.owner[i] : -1;
+        const bool plain = __ballot(own >= 0) == 0ull && ncell == 64;
+        float* const base = p.grad[scale] + (int64_t)w0 * attrs;
+        const int nflo = ncell * attrs;
+        if (plain) {
+            const int trips = (nflo + 255) >> 8;                                      // uniform: every lane takes part in every shuffle
+            for (int k = 0; k < trips; k++) {                                        // nflo = 64 * attrs: a multiple of 4, base 16-byte aligned
+                const int f0 = 256 * k + 4 * lane;
+                int c = (int)((float)f0 * rattrs);
+                if (c * attrs > f0) c--;
+                if ((c + 1) * attrs <= f0) c++;
+                const int e1 = och - (f0 - c * attrs);                              // position of cell c's objectness element inside this quad
+                const float gv = __shfl(g, c < 64 ? c : 63, 64);                    // (attrs >= 7 > 4: a quad holds at most one objectness element,
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                         //  and never the NEXT cell's: that one sits >= och + 1 >= 5 further)
+                if (e1 == 0) v.x = gv; else if (e1 == 1) v.y = gv; else if (e1 == 2) v.z = gv; else if (e1 == 3) v.w = gv;
+                if (f0 < nflo) *reinterpret_cast<float4*>(base + f0) = v;
+            }
+        } else {
+            const int trips = (nflo + 63) >> 6;
+            for (int k = 0; k < trips; k++) {
+                const int f = 64 * k + lane;
+                int c = (int)((float)f * rattrs);
+                if (c * attrs > f) c--;
+                if ((c + 1) * attrs <= f) c++;
+                const int cs = c < 64 ? c : 63;
+                const float gv = __shfl(g, cs, 64);
+                const int oc = __shfl(own, cs, 64);
+                if (f < nflo) {
+                    if (f - c * attrs == och) base[f] = gv;
+                    else if (oc < 0) base[f] = 0.f;
+                }
+            }
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -613,13 +667,13 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
     size_t need;
     carve(p, s, &need);
     if (p.ws_bytes < need) return RY_ERR_WORKSPACE;
-    const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
+    // (attrs: see loss_obj_kernel)
     if (hipMemsetAsync(p.ws, 0, need, stream) != hipSuccess) return RY_ERR_LAUNCH;
     for (int i = 0; i < 3; i++) {
         if (!p.head[i] || (p.compute_grad && !p.grad[i])) return RY_ERR_ARG;
         if (hipMemsetAsync(s[i].owner, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
         if (p.compute_grad && hipMemsetAsync(s[i].head, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
-        if (p.compute_grad && hipMemsetAsync(p.grad[i], 0, (size_t)s[i].cells * attrs * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
+        // (p.grad[i] is NOT cleared here any more: loss_match_grad_kernel + loss_obj_kernel define every element, r05)
     }
     if (p.nt > 0) {
         hipLaunchKernelGGL(loss_targets_count_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
