@@ -18,13 +18,16 @@ cd $R
 # 4. per-launch tables
 B=64 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b64.txt 2>&1
 B=8 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b8.txt 2>&1
+python tools/highres_floor_table.py $O/per_launch_b64.txt > $O/highres_layers_vs_floor.txt 2>&1
 # 4a. the 8-wave weight-gradient kernels ALONE: whole-chip grids (256 workgroups) and the shipped part-of-the-chip grids (96), old 4-wave kernels beside them
+set +x
 ( for sh in "64 100 128 128 3" "64 50 256 256 3" "64 25 512 512 3" "64 100 64 64 3" "64 200 64 64 3" "64 400 64 64 3" "64 100 128 256 3" "64 200 256 256 1" "64 100 512 512 1" "64 50 1024 1024 1" "64 25 2048 512 1"; do
     set -- $sh
     for cfg in "RYOLO_W3_V8=0 RYOLO_WGRAD_8W=0" "RYOLO_W3_V8_BLOCKS=256 RYOLO_WGRAD_8W_BLOCKS=256" "RYOLO_W3_V8_BLOCKS=96 RYOLO_WGRAD_8W_BLOCKS=96"; do
       echo "[$cfg] $(env $cfg CHECK=0 python tools/bench_wgrad.py $1 $2 $3 $4 $5 1 20 2>&1 | tail -1)"
     done
   done ) > $O/wgrad_isolated.txt 2>&1
+set -x
 # 4a'. PMC groups for the ring weight-gradient kernel: 8-wave form at whole-chip sizing, 4-wave form beside it
 ( RYOLO_W3_V8_BLOCKS=256 bash tools/pmc_wgrad.sh v8_128x128_100 64 100 128 128 3 1 3; RYOLO_W3_V8=0 bash tools/pmc_wgrad.sh w4_128x128_100 64 100 128 128 3 1 3;
   RYOLO_W3_V8_BLOCKS=256 bash tools/pmc_wgrad.sh v8_64x64_200 64 200 64 64 3 1 3; RYOLO_WGRAD_8W_BLOCKS=256 bash tools/pmc_wgrad.sh p8_512x512_100 64 100 512 512 1 1 3 ) > $O/pmc_wgrad.txt 2>&1
@@ -55,7 +58,8 @@ BACKEND=nccl timeout 600 python tools/dp_check.py > $O/dp_check_rccl1.txt 2>&1
 # 9. loader feed rate, mAP parity (600 steps), GPU test suite
 timeout 600 python tools/bench_pipeline.py > $O/pipeline.txt 2>&1; cp gpurun_out/pipeline.json $O/pipeline.json
 timeout 300 python tools/bench_loader.py 64 800 10 > $O/loader_diag.txt 2>&1; cp gpurun_out/loader_diag.json $O/loader_diag.json
-# (mAP parity at 512 images / 16 classes / 3 seeds: tools/map_parity.py, 10 min of mostly CPU oracle time — run once per round, not here)
+# mAP parity where the detector detects (r05): HIP-trained weights at mAP@0.5 >= 0.5 evaluated on both paths (the CPU oracle only evaluates: ~10 s per seed)
+timeout 900 python tools/map_parity.py --reverse --seeds 3 > $O/map_parity_reverse.txt 2>&1
 timeout 1800 python -m pytest tests -m gpu -q --durations=10 > $O/gpu_test_suite.txt 2>&1; tail -n 3 $O/gpu_test_suite.txt
 ls -la $O
 tail -n 3 $O/pmc_step.txt; cat $O/bench_time.txt; tail -n 2 $O/dp_check_gloo2.txt; tail -n 2 $O/dp_check_rccl1.txt
