@@ -66,10 +66,29 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
     const unsigned long long T0 = __builtin_readcyclecounter();
     unsigned long long T1 = 0, T2 = 0, T3 = 0;
 #endif
-    const TapClass& tc = p.cls[blockIdx.z];
+    // Tap classes (the four output-parity classes of a stride-2 data gradient) read the SAME dY rows.  With the class on blockIdx.z the dispatcher
+    // finishes class 0 over the whole tensor before class 1 begins and dY comes from HBM once per class (PMC r04: 3.97 GB for 1.97 GB of operands
+    // on the 128 -> 64 layer).  r05, class-chunked order (host: launch_gemm puts the chunk length / 16 into bits 16-27 of `pipe` and launches a
+    // 1-D grid): the linear block id walks chunk by chunk, inside a chunk class by class, inside a class tile by tile — thousands of
+    // workgroups of ONE class run at a time (the classes have 1 / 2 / 2 / 4 taps: interleaving them tile by tile, tried in r04, left them
+    // unbalanced and was slower), and a chunk's dY (tens of MB) is still in the 256 MiB Infinity Cache when the next class asks for it.
+    int cls_i = blockIdx.z, tile_i;
+    if (const int cht = (p.pipe >> 16) & 0xfff) {
+        const int ncls = p.nclasses, T = (int)gridDim.x / ncls, CH = cht * 16;
+        const int L = blockIdx.x;
+        const int chunk = L / (CH * ncls);
+        const int base = chunk * CH;
+        const int nin = min(CH, T - base);
+        const int within = L - chunk * CH * ncls;
+        cls_i = within / nin;
+        tile_i = base + xcd_remap(within - cls_i * nin, nin);
+    } else {
+        tile_i = xcd_remap(blockIdx.x, gridDim.x);
+    }
+    const TapClass& tc = p.cls[cls_i];
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int gridN = (p.Nout + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = tile_i;
     const int mb = tile / gridN, nb = tile - mb * gridN;
     const int64_t m0 = (int64_t)mb * BM;
     const int n0 = nb * BN;
@@ -1284,26 +1303,33 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     const int64_t gm = ry_cdiv(M, BM), gn = ry_cdiv(p.Nout, BN);
     if (gm * gn > 0x7fffffff) return RY_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)(gm * gn), 1, p.nclasses);
+    dim3 grid((unsigned)(gm * gn), 1, p.nclasses);
+    ConvGemmParams q = p;
+    // several tap classes over one input: class-chunked 1-D order (conv_gemm_kernel); RYOLO_GEMM_CLS_CHUNK = tiles per chunk (0: classes on blockIdx.z)
+    static const int cls_chunk = getenv("RYOLO_GEMM_CLS_CHUNK") ? atoi(getenv("RYOLO_GEMM_CLS_CHUNK")) : 1024;     // same-box img/s: 0 -> 934.0, 256 -> 936.3, 512 -> 936.0, 1024 -> 937.9 (three alternating runs each)
+    if (p.nclasses > 1 && cls_chunk >= 16 && gm * gn * p.nclasses <= 0x7fffffff) {
+        q.pipe = (p.pipe & 0xffff) | ((cls_chunk / 16 > 0xfff ? 0xfff : cls_chunk / 16) << 16);
+        grid = dim3((unsigned)(gm * gn * p.nclasses), 1, 1);
+    }
     const bool ident = gemm_ident(p);
     const bool t1 = PIPE == 1 && gemm_is_t1(p);
     if constexpr (PIPE == 1) {
         if (t1) {
-            if (p.nbstat) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true, true>), grid, dim3(256), 0, stream, p);
-            else if (p.epi == EPI_ACCUM) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true, true>), grid, dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true, true>), grid, dim3(256), 0, stream, p);
+            if (p.nbstat) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true, true>), grid, dim3(256), 0, stream, q);
+            else if (p.epi == EPI_ACCUM) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true, true>), grid, dim3(256), 0, stream, q);
+            else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true, true>), grid, dim3(256), 0, stream, q);
             return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
         }
     }
     if (p.nbstat) {                                             // (identity grid by gemm_check; the pool gradient may ride along)
-        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, false>), grid, dim3(256), 0, stream, p);
+        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true>), grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, false>), grid, dim3(256), 0, stream, q);
     } else if (p.epi == EPI_ACCUM) {
-        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, false>), grid, dim3(256), 0, stream, p);
+        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true>), grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, false>), grid, dim3(256), 0, stream, q);
     } else {
-        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, false>), grid, dim3(256), 0, stream, p);
+        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true>), grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, false>), grid, dim3(256), 0, stream, q);
     }
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
