@@ -28,5 +28,4 @@ def test_direct_cases_with_the_persistent_kernel_forced():
     _child(["tests/conv3x3_ws_cases.py"], 900)
 
 
-def test_block_and_network_parity_with_the_persistent_kernel_forced():
-    _child(["tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py"], 1800)
+# (the block / network / per-node suites with RYOLO_P3_WS64=2: tests/test_gpu_forced_kernels.py, merged child of r05)

@@ -12,26 +12,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_block_and_network_parity_with_3x3_kernels_forced():
+def test_block_and_network_parity_with_3x3_kernels_gemm256_and_deep_rings_forced():
+    """THREE disjoint kernel selections in one child (r05: each child run of the per-block / whole-network / per-node suites costs the GPU suite
+    ~25 s; until r04 these were three runs): RYOLO_GEMM_PIPE=0x601 + RYOLO_W3_FORCE=1 — every 3x3 stride-1 layer on the halo-patch kernel and the
+    ring weight gradients (8-wave form where Cin % 64 == 0) on the small grids of those tests; RYOLO_GEMM_256=2 — every pointwise layer with
+    Cin >= 512 on the 256-wide kernel; RYOLO_GEMM_DEEP=6 — the 6-stage ring on every remaining launch of the generic 128 x 128 tile (tapped /
+    strided layers, short-K pointwise layers).  No launch is claimed by two of them."""
     import gc
     import torch
     gc.collect()
     torch.cuda.empty_cache()                       # the child process cannot reuse this process's cached blocks
-    env = dict(os.environ, RYOLO_GEMM_PIPE="0x601", RYOLO_W3_FORCE="1")           # 0x200 patch kernel, 0x400 also for small grids
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "-q", "-m", "gpu", "-x",
-                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    env = dict(os.environ, RYOLO_GEMM_PIPE="0x601", RYOLO_W3_FORCE="1", RYOLO_GEMM_256="2", RYOLO_GEMM_DEEP="6")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py", "-q", "-m", "gpu",
+                        "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
 
-def test_block_and_network_parity_with_wide_64_column_tile_forced():
+def test_block_and_network_parity_with_wide_64_column_tile_and_persistent_3x3_forced():
     """RYOLO_GEMM_N64=2: the 256 x 64 tile of the generic kernel (layers with 33..64 output columns, by default only when the grid has
-    >= 1536 such tiles) on the small grids of the block / network parity tests, batch-statistics epilogue included."""
+    >= 1536 such tiles) on the small grids of the block / network parity tests, batch-statistics epilogue included; in the same child (r05)
+    RYOLO_P3_WS64=2: the persistent weight-stationary 3x3 kernel on every 64 -> <= 64 channel 3x3 stride-1 layer (those never reach the generic
+    kernel's tiles: disjoint launches).  Its direct C-ABI cases: tests/test_gpu_conv3x3_ws.py."""
     import gc
     import torch
     gc.collect()
     torch.cuda.empty_cache()
-    env = dict(os.environ, RYOLO_GEMM_N64="2")
+    env = dict(os.environ, RYOLO_GEMM_N64="2", RYOLO_P3_WS64="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py", "-q", "-m", "gpu",
                         "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -53,16 +60,15 @@ def test_block_and_network_parity_with_persistent_1x1_kernel_forced():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("depth", ["4", "6"])
-def test_block_and_network_parity_with_deep_ring_forced(depth):
-    """RYOLO_GEMM_DEEP=4 / 6: the deep-ring instantiations of the generic 128 x 128 tile (by default chosen for grids of <= 512 / <= 256
-    tiles) on every eligible launch of the block / network / per-node parity tests."""
+def test_block_and_network_parity_with_deep_ring_4_forced():
+    """RYOLO_GEMM_DEEP=4: the 4-stage instantiation of the generic 128 x 128 tile (by default chosen for grids of <= 512 tiles) on every eligible
+    launch of the block / network parity tests (the 6-stage one runs in the merged child above, per-node suite included)."""
     import gc
     import torch
     gc.collect()
     torch.cuda.empty_cache()
-    env = dict(os.environ, RYOLO_GEMM_DEEP=depth)
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py",
+    env = dict(os.environ, RYOLO_GEMM_DEEP="4")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py",
                         "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

@@ -1,6 +1,6 @@
 """The 256-wide pointwise GEMM for long reductions (csrc/gemm256.hip): in-process at the sizes its default dispatch takes (Cin >= 512, >= 600
-tiles), and FORCED (RYOLO_GEMM_256=2, read once per process: child processes) onto small / ragged problems and onto every eligible 1x1 layer of
-the block / network / per-node parity tests."""
+tiles), and FORCED (RYOLO_GEMM_256=2, read once per process: child process) onto small / ragged problems; forced onto every eligible 1x1 layer of
+the block / network / per-node parity tests in tests/test_gpu_forced_kernels.py."""
 import os
 import subprocess
 import sys
@@ -36,5 +36,4 @@ def test_direct_cases_forced():
     _child(["tests/gemm256_cases.py"], 900)
 
 
-def test_block_and_network_parity_forced():
-    _child(["tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py"], 1800)
+# (the block / network / per-node suites with RYOLO_GEMM_256=2: tests/test_gpu_forced_kernels.py, merged child of r05)
