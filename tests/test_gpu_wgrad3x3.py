@@ -1,8 +1,9 @@
-"""The 3x3 stride-1 halo-ring weight-gradient kernel (csrc/conv3x3.hip) through the C ABI against torch's fp32 conv weight
-gradient on the same bf16 operands: both variants (128-channel tiles; <= 64 output channels with split K halves), channel
+"""The 3x3 stride-1 halo-ring weight-gradient kernel (csrc/conv3x3.hip) through the C ABI against a float64 weight gradient
+(tests/wgrad_ref.py) on the same bf16 operands: both variants (128-channel tiles; <= 64 output channels with split K halves), channel
 strides wider than the tensors (concat slices), Cout that is not a multiple of 32, odd map sizes, accumulation into an existing
-gradient.  Sizes are chosen so the library's own dispatch picks the ring kernel (asserted).  Tolerance 2e-3 relative (bf16
-operands, fp32 accumulation in a different order).
+gradient.  Sizes are chosen so the library's own dispatch picks the ring kernel (asserted).  Tolerance 2e-5 relative: the operands are the same bf16 values, so what remains is fp32
+accumulation against float64 — measured 2e-7 ... 4e-7 on every case (r05; against torch's fp32 MIOpen gradient, whose solver and rounding vary from box
+to box, the tests had to allow 2e-3 and still failed once on a cold box).
 
 Round 5: layers with Cin % 64 == 0 run on the 8-wave form (csrc/conv3x3_wgrad8.hip: 2 x (5 | 4) accumulator blocks per wave, rings of any
 length with a mirrored head) by default — the cases below with Cin 64 / 128 / 192 / 256 exercise both of its instantiations (<= 64 output
@@ -48,13 +49,11 @@ def _run(B, H, W, Cin, Cout, ldx_extra=0, ldy_extra=0, seed=0):
     p.partial = work.data_ptr()
     hip.call("ryolo_conv_wgrad", p, hip.stream())
     torch.cuda.synchronize()
-    xr = x[:, :Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
-    w0 = torch.zeros(Cout, Cin, 3, 3, device=dev, requires_grad=True)
-    torch.nn.functional.conv2d(xr, w0, padding=1).backward(dy[:, :Cout].float().view(B, H, W, Cout).permute(0, 3, 1, 2))
-    ref = w0.grad.reshape(Cout, Cin, 9)
+    from tests.wgrad_ref import wgrad_fp64
+    ref = wgrad_fp64(x, dy, B, H, W, Cin, Cout, 3, 3, 1, 1, 1).float()            # float64 products on the same bf16 operands (tests/wgrad_ref.py)
     got = dw - dw0                                                    # the kernel ACCUMULATES into the gradient
     err = float((got - ref).norm() / ref.norm())
-    assert err < 2e-3, f"relative error {err:.3e} (max abs {float((got - ref).abs().max()):.3e}, reference norm {float(ref.norm()):.3e})"
+    assert err < 2e-5, f"relative error {err:.3e} (max abs {float((got - ref).abs().max()):.3e}, reference norm {float(ref.norm()):.3e})"
     assert bool(torch.isfinite(dw).all())
 
 

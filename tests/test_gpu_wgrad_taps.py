@@ -2,8 +2,9 @@
 layer with more than 64 output channels that the halo-ring kernel does not take) through the C ABI against torch's fp32 conv weight gradient
 on the same bf16 operands (model/utils.py:6-32 Conv with stride 2; model/utils.py:146-160 MaxConv's strided branch).  Odd maps (the last
 output row / column reads padding), Cin = 32 / 64 (two or four taps per 128-column tile), Cout not a multiple of 32, channel strides
-wider than the tensors, accumulation into an existing gradient, a 1x3 tap row.  Dispatch is asserted.  Tolerance 2e-3 relative (bf16
-operands, fp32 accumulation in a different order)."""
+wider than the tensors, accumulation into an existing gradient, a 1x3 tap row.  Dispatch is asserted.  Tolerance 2e-5 relative: the operands are the same bf16 values, so what remains is fp32
+accumulation against float64 — measured 2e-7 ... 4e-7 on every case (r05; against torch's fp32 MIOpen gradient, whose solver and rounding vary from box
+to box, the tests had to allow 2e-3 and still failed once on a cold box)."""
 import pytest
 import torch
 
@@ -46,16 +47,14 @@ def _run(B, H, W, Cin, Cout, k=(3, 3), stride=2, ldx_extra=0, ldy_extra=0, seed=
     p.partial = work.data_ptr()
     hip.call("ryolo_conv_wgrad", p, hip.stream())
     torch.cuda.synchronize()
-    xr = x[:, :Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
-    w0 = torch.zeros(Cout, Cin, kh, kw, device=dev, requires_grad=True)
-    torch.nn.functional.conv2d(xr, w0, stride=stride, padding=(ph, pw)).backward(dy[:, :Cout].float().view(B, OH, OW, Cout).permute(0, 3, 1, 2))
-    ref = w0.grad.reshape(Cout, Cin, kh * kw)
+    from tests.wgrad_ref import wgrad_fp64
+    ref = wgrad_fp64(x, dy, B, H, W, Cin, Cout, kh, kw, stride, ph, pw).float()    # float64 products on the same bf16 operands (tests/wgrad_ref.py)
     got = dw - dw0                                                    # the kernel ACCUMULATES into the gradient
     err = float((got - ref).norm() / ref.norm())
-    assert err < 2e-3, f"relative error {err:.3e} (max abs {float((got - ref).abs().max()):.3e}, reference norm {float(ref.norm()):.3e})"
+    assert err < 2e-5, f"relative error {err:.3e} (max abs {float((got - ref).abs().max()):.3e}, reference norm {float(ref.norm()):.3e})"
     # per-tap check: a wrong tap offset on one tap hides inside a norm over nine
     for t in range(kh * kw):
-        assert float((got[:, :, t] - ref[:, :, t]).norm() / ref[:, :, t].norm()) < 4e-3, f"tap {t}"
+        assert float((got[:, :, t] - ref[:, :, t]).norm() / ref[:, :, t].norm()) < 4e-5, f"tap {t}"
     assert bool(torch.isfinite(dw).all())
 
 
