@@ -208,6 +208,16 @@ int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, in
  * (>= na*attrs) must be pre-zeroed by the caller */
 int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
                           bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, ryolo_stream_t stream);
+/* the same over the sparse description of dout that ryolo_loss leaves (LossParams.objgrad, ryolo_loss_owner_grids): only the dense rows of matched cells
+ * (owner[cell] >= 0) are read from dout, every other cell is zero except its objectness element objgrad[cell] at index och.  preobj (may be null) =
+ * the compact objectness column of pre written by ryolo_head_finish_fwd_obj: with it, pre is read at matched cells only.  Bit-identical results.
+ * (the reference has no counterpart: autograd walks the dense maps, lib/loss.py:282-331 -> model/yololayer.py:25) */
+int ryolo_head_finish_bwd_sparse(const float* dout, const float* objgrad, const int* owner, int och, const float* preobj, const float* pre, int ldp,
+                                 const float* mul, int B, int gs, int na, int attrs, bf16_t* dpre, int ldd, float* dbias, float* dmul,
+                                 float* scratch, ryolo_stream_t stream);
+/* ryolo_head_finish_fwd + preobj [B, na, gs, gs] fp32 = pre[.., a*attrs + och] (och: 4 csl, 5 kfiou) */
+int ryolo_head_finish_fwd_obj(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, int och, float* preobj,
+                              ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
 /* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= (ceil(M/256) + 64)*C floats */
 int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);
@@ -267,6 +277,9 @@ int ryolo_struct_sizes(int* sizes /* [11] */);
  * ------------------------------------------------------------------------------------------------------------ */
 int ryolo_loss_workspace_bytes(const LossParams* p, size_t* bytes);
 int ryolo_loss(const LossParams* p, ryolo_stream_t stream);
+/* owner grids of the last ryolo_loss call with THESE params on this workspace: owner[i][cell] >= 0 iff cell of scale i was matched to a target (valid until
+ * the next ryolo_loss on the workspace) */
+int ryolo_loss_owner_grids(const LossParams* p, const int** owner);
 /* autograd chain rule of the loss node (lib/loss.py:256,414 return a [1] tensor; `loss.backward()` hands back d(out)/d(loss) as a
  * device scalar): grad[0..n) *= *scale, skipped ON THE DEVICE when *scale == 1.0f (the usual case) — no host read, capturable */
 int ryolo_loss_grad_scale(float* grad, int64_t n, const float* scale, ryolo_stream_t stream);

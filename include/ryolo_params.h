@@ -159,6 +159,9 @@ typedef struct LossParams {
     float* items;             // [6] device: reg, conf, cls, theta, total, number of target rows dropped because their image index is outside [0, batch)
     int compute_grad;
     float fl_gamma, fl_alpha; // FocalLoss (lib/loss.py:10-33) around every BCE term when fl_gamma > 0 (hyp['fl_gamma']); alpha = 0.25 in the reference
+    float* objgrad[3];        // optional (compute_grad): the objectness gradient of every cell ALSO as a compact [B, na, gs, gs] array — with the owner
+                              // grids (ryolo_loss_owner_grids) the sparse description of grad[]: unmatched cells are zero except their objectness
+                              // element.  ryolo_head_finish_bwd_sparse reads that instead of the dense 88-byte rows (r05)
 } LossParams;
 
 #endif /* RYOLO_PARAMS_H */

@@ -862,32 +862,44 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access at 4-byte alignment (runs start at odd offsets)
 static int head_tile_cells(int C) { int tc = 32; while (tc > 1 && ((size_t)tc * (C + 1) + C) * 4 > 60u * 1024u) tc >>= 1; return tc; }
 
+template <bool OBJ>
 __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs,
-                                                              int na, int attrs, int TC, float* __restrict__ out)
+                                                              int na, int attrs, int TC, float* __restrict__ out, float* __restrict__ preobj, int och)
 {
-    extern __shared__ float hl[];                              // t[TC][C + 1]
+    extern __shared__ float hl[];                              // t[TC][C + 1], mulv[C]
     const int cells = gs * gs, C = na * attrs, LD = C + 1;
     const int ncb = (cells + TC - 1) / TC;
     const int b = blockIdx.x / ncb, cb = blockIdx.x - b * ncb;
     const int c0 = cb * TC;
     const int ncell = min(TC, cells - c0);
     const float* src = pre + ((int64_t)b * cells + c0) * ldp;
+    // OBJ (r05, ryolo_head_finish_fwd_obj): the tile is staged UNSCALED and ImplicitM is applied on the way out, so that the objectness column of
+    // every (anchor, cell) BEFORE ImplicitM can be copied out of the tile as a compact [B, na, cells] array — what the sparse head backward
+    // (head_bwd_sparse_kernel) multiplies the objectness gradients with for the ImplicitM gradient, instead of re-reading all of `pre`.
+    float* const mulv = hl + TC * LD;
+    const bool late = OBJ && mul;
+    if (late) for (int ch = threadIdx.x; ch < C; ch += 256) mulv[ch] = mul[ch];
     if (((C | ldp) & 3) == 0 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0) {
         const int c4n = C >> 2;
         for (int i = threadIdx.x; i < ncell * c4n; i += 256) {
             const int cell = i / c4n, c4 = i - cell * c4n;
             float4 v = *reinterpret_cast<const float4*>(src + (int64_t)cell * ldp + c4 * 4);
-            if (mul) { const float4 m = *reinterpret_cast<const float4*>(mul + c4 * 4); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+            if (mul && !late) { const float4 m = *reinterpret_cast<const float4*>(mul + c4 * 4); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
             float* t = hl + cell * LD + c4 * 4;
             t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
         }
     } else {
         for (int i = threadIdx.x; i < ncell * C; i += 256) {
             const int cell = i / C, ch = i - cell * C;
-            hl[cell * LD + ch] = src[(int64_t)cell * ldp + ch] * (mul ? mul[ch] : 1.f);
+            hl[cell * LD + ch] = src[(int64_t)cell * ldp + ch] * ((mul && !late) ? mul[ch] : 1.f);
         }
     }
     __syncthreads();
+    if (OBJ)
+        for (int i = threadIdx.x; i < na * ncell; i += 256) {
+            const int a = i / ncell, cell = i - a * ncell;
+            preobj[((int64_t)b * na + a) * cells + c0 + cell] = hl[cell * LD + a * attrs + och];
+        }
     const int run = ncell * attrs, nq = (run + 3) >> 2;
     const float rattrs = 1.0f / (float)attrs;
     for (int i = threadIdx.x; i < na * nq; i += 256) {
@@ -902,6 +914,7 @@ __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             v[k] = (e0 + k < run) ? hl[cell * LD + a * attrs + at] : 0.f;
+            if (late) v[k] *= mulv[a * attrs + at];
             if (++at == attrs) { at = 0; cell++; }
         }
         if (e0 + 3 < run) { const f4u w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4u*>(dst) = w; }
@@ -917,7 +930,8 @@ __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __res
 template <int MAXQ>                                           // channel quads per thread of the column sums: 1 (C <= 512: every head of the reference) or 4 (C <= 2048)
 __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, int ldp,
                                                               const float* __restrict__ mul, int B, int gs, int na, int attrs, int TC,
-                                                              bf16_t* __restrict__ dpre, int ldd, float* __restrict__ partial /*[nblk][2][C]*/)
+                                                              bf16_t* __restrict__ dpre, int ldd, float* __restrict__ partial /*[nblk][2][C]*/,
+                                                              const float* __restrict__ objgrad, const int* __restrict__ owner, int och)
 {
     extern __shared__ float hl[];                              // t[TC][C + 1], then mulv[C]
     const int cells = gs * gs, C = na * attrs, LD = C + 1;
@@ -942,6 +956,24 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
         const int64_t m0 = (int64_t)b * cells + c0;
         __syncthreads();                                          // previous sub-tile fully consumed (and mulv visible)
         const int run = ncell * attrs, nq = (run + 3) >> 2;
+        if (objgrad) {
+            // r05, SPARSE description of dout (ryolo_head_finish_bwd_sparse): a cell no target was matched to is zero except its objectness
+            // element, which the loss also leaves in the compact [B, na, cells] array `objgrad`; matched cells (owner >= 0: a few thousand of
+            // 15 M) keep their dense 88-byte rows.  8 bytes read per (anchor, cell) instead of 4 * attrs.
+            for (int i = threadIdx.x; i < ncell * LD; i += 256) hl[i] = 0.f;
+            __syncthreads();
+            for (int i = threadIdx.x; i < na * ncell; i += 256) {
+                const int a = i / ncell, cell = i - a * ncell;
+                const int64_t idx = ((int64_t)b * na + a) * cells + c0 + cell;
+                float* row = hl + cell * LD + a * attrs;
+                row[och] = objgrad[idx];
+                if (owner[idx] >= 0) {
+                    const float* src = dout + idx * attrs;
+                    for (int e = 0; e < attrs; e++)
+                        if (e != och) row[e] = src[e];
+                }
+            }
+        } else
         // four 16-byte loads of a thread are requested before the first one is scattered: with one load per loop trip every trip paid its
         // own memory round trip, and the few workgroups of the small scales (40 at 8 images x 25^2) made that the launch time
         for (int i0 = threadIdx.x; i0 < na * nq; i0 += 256 * 4) {
@@ -1021,7 +1053,7 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
                         if (c4 * 4 + k < C) {
                             const float d = t[k];
                             sb[j][k] += bf2f(f2bf(d * mulv[c4 * 4 + k]));      // bias gradient = column sum of the bf16 operand the wgrad GEMM reads
-                            sm[j][k] += d * pv[u][k];
+                            sm[j][k] = fmaf(d, pv[u][k], sm[j][k]);               // (explicit: the sparse kernel must round the same way)
                         }
                     }
                 }
@@ -1041,6 +1073,138 @@ __global__ __launch_bounds__(256) void head_finish_bwd_kernel(const float* __res
                 partial[((int64_t)blockIdx.x * 2 + 1) * C + c4 * 4 + k] = a1;
             }
         }
+    }
+}
+
+// r05: the head backward over the SPARSE description of dout the fused loss leaves behind (ryolo_head_finish_bwd_sparse) without staging dense
+// tiles: an unmatched cell's row of dout is zero except its objectness element, so its dpre row is a constant pattern with one value per anchor,
+// the bias / ImplicitM column sums of the objectness columns run over the compact arrays (objgrad, preobj: [B, na, cells]) and every other column
+// only sees the matched cells (owner >= 0; bit masks per anchor).  HBM per row of dpre: its 16-byte stores + 12 bytes per anchor, instead of the
+// 4 * C bytes of dout and 4 * ldp bytes of pre.  Same workgroup -> cells mapping (HEAD_CPB), same partial rows, same summation order per column
+// (cells of one parity ascending, the two parities added last) as head_finish_bwd_kernel: results are bit-identical to the dense pass.
+// Needs C <= 512 (one 8-channel chunk per lane) and na <= HS_MAXNA; anything else takes the dense kernel's sparse fill.
+#define HS_MAXNA 32
+#define HS_LDA (HEAD_CPB + 1)
+__global__ __launch_bounds__(256) void head_bwd_sparse_kernel(const float* __restrict__ dout, const float* __restrict__ objgrad,
+                                                              const float* __restrict__ preobj, const int* __restrict__ owner, int och,
+                                                              const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs, int na,
+                                                              int attrs, bf16_t* __restrict__ dpre, int ldd, float* __restrict__ partial /*[nblk][2][C]*/)
+{
+    extern __shared__ float hl[];                              // og[na][HS_LDA], po[na][HS_LDA], mulv[C], rw[4][C], mask[na][2] (64-bit)
+    const int cells = gs * gs, C = na * attrs;
+    float* const og = hl;
+    float* const po = og + na * HS_LDA;
+    float* const mulv = po + na * HS_LDA;
+    float* const rw = mulv + C;
+    unsigned long long* const mask = reinterpret_cast<unsigned long long*>(rw + 4 * C + ((na * 2 * HS_LDA + 5 * C) & 1));   // (8-byte aligned)
+    const int ncb = (cells + HEAD_CPB - 1) / HEAD_CPB;
+    const int b = blockIdx.x / ncb, cb = blockIdx.x - b * ncb;
+    const int cbase = cb * HEAD_CPB;
+    const int nblock = min(HEAD_CPB, cells - cbase);
+    const int64_t m0 = (int64_t)b * cells + cbase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ch = threadIdx.x; ch < C; ch += 256) mulv[ch] = mul ? mul[ch] : 1.f;
+    for (int it = wave; it < na * 2; it += 4) {
+        const int a = it >> 1, cell = (it & 1) * 64 + lane;
+        const bool valid = cell < nblock;
+        const int64_t idx = ((int64_t)b * na + a) * cells + cbase + cell;
+        og[a * HS_LDA + cell] = valid ? objgrad[idx] : 0.f;
+        po[a * HS_LDA + cell] = (valid && mul) ? preobj[idx] : 0.f;
+        const unsigned long long m = __ballot(valid && owner[idx] >= 0);
+        if (lane == 0) mask[it] = m;
+    }
+    __syncthreads();
+    unsigned long long cm0 = 0, cm1 = 0;                        // cells of this block with a matched anchor
+    for (int a = 0; a < na; a++) { cm0 |= mask[2 * a]; cm1 |= mask[2 * a + 1]; }
+
+    // ---- dpre rows: lane = 8-channel chunk, a wave walks every 4th cell
+    const int c8n = (C + 7) >> 3;
+    {
+        const int c8 = lane;
+        float zf[8], m1 = 0.f, m2 = 0.f;                          // this chunk of an unmatched row with the objectness gradients at zero; the (<= 2: attrs >= 7)
+        int k1 = -1, k2 = -1, a1 = 0, a2 = 0;                     // objectness columns inside the chunk
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int col = c8 * 8 + k;
+            zf[k] = 0.f;
+            if (c8 < c8n && col < C) {
+                zf[k] = 0.f * mulv[col];                          // (the dense pass multiplies its zeros too: -0 where ImplicitM is negative)
+                const int a = col / attrs;
+                if (col - a * attrs == och) {
+                    if (k1 < 0) { k1 = k; a1 = a; m1 = mulv[col]; } else { k2 = k; a2 = a; m2 = mulv[col]; }
+                }
+            }
+        }
+        float* const row = rw + wave * C;
+        for (int cell = wave; cell < nblock; cell += 4) {
+            const bool matched = ((cell < 64 ? cm0 >> cell : cm1 >> (cell - 64)) & 1ull) != 0;      // (wave-uniform)
+            float g[8];
+            if (!matched) {
+                const float v1 = k1 >= 0 ? og[a1 * HS_LDA + cell] * m1 : 0.f;
+                const float v2 = k2 >= 0 ? og[a2 * HS_LDA + cell] * m2 : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) g[k] = k == k1 ? v1 : (k == k2 ? v2 : zf[k]);
+            } else {
+                // a matched anchor's row comes from dout, the other anchors of the cell from the compact array
+                for (int col = lane; col < C; col += 64) {
+                    const int a = col / attrs, e = col - a * attrs;
+                    const bool dense = ((mask[2 * a + (cell >> 6)] >> (cell & 63)) & 1ull) != 0;
+                    float v = e == och ? og[a * HS_LDA + cell] : 0.f;
+                    if (dense && e != och) v = dout[(((int64_t)b * na + a) * cells + cbase + cell) * attrs + e];
+                    row[col] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 8; k++) g[k] = (c8 < c8n && c8 * 8 + k < C) ? row[c8 * 8 + k] * mulv[c8 * 8 + k] : 0.f;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (c8 < c8n) {
+                const uint4 w = make_uint4(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]), pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7]));
+                bf16_t* o = dpre + (m0 + cell) * ldd + c8 * 8;
+                if (c8 * 8 + 8 <= ldd && (reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<uint4*>(o) = w;
+                else for (int k = 0; k < 8 && c8 * 8 + k < C; k++) o[k] = f2bf(g[k]);
+            }
+        }
+    }
+
+    // ---- column sums.  Objectness columns: thread (anchor, parity) over the compact arrays (matched cells carry the same objectness element)
+    float* const p0 = partial + (int64_t)blockIdx.x * 2 * C;
+    if ((int)threadIdx.x < 2 * na) {                              // (2 * na <= 64: adjacent lanes of one wave hold the two parities)
+        const int a = threadIdx.x >> 1, par = threadIdx.x & 1;
+        const int col = a * attrs + och;
+        const float mv = mulv[col];
+        float sb = 0.f, sm = 0.f;
+        for (int cell = par; cell < nblock; cell += 2) {
+            const float d = og[a * HS_LDA + cell];
+            sb += bf2f(f2bf(d * mv));
+            sm = fmaf(d, po[a * HS_LDA + cell], sm);
+        }
+        const float a0 = sb + __shfl_xor(sb, 1, 64);
+        const float a1 = sm + __shfl_xor(sm, 1, 64);
+        if (par == 0) { p0[col] = a0; p0[C + col] = a1; }
+    }
+    // every other column: the matched cells of its anchor, ascending per parity (none in most blocks: zeros)
+    for (int col = threadIdx.x; col < C; col += 256) {
+        const int a = col / attrs, e = col - a * attrs;
+        if (e == och) continue;
+        float sb[2] = {0.f, 0.f}, sm[2] = {0.f, 0.f};
+        const float mv = mulv[col];
+        for (int h = 0; h < 2; h++) {
+            unsigned long long m = mask[2 * a + h];
+            while (m) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int cell = h * 64 + bit;
+                const float d = dout[(((int64_t)b * na + a) * cells + cbase + cell) * attrs + e];
+                const float pv = mul ? pre[(m0 + cell) * ldp + col] : 0.f;
+                sb[cell & 1] += bf2f(f2bf(d * mv));
+                sm[cell & 1] = fmaf(d, pv, sm[cell & 1]);
+            }
+        }
+        p0[col] = sb[0] + sb[1];
+        p0[C + col] = sm[0] + sm[1];
     }
 }
 
@@ -1452,26 +1616,43 @@ extern "C" int ryolo_im2col(const float* img, int NB, int Cin, int H, int W, int
     return RY_OK;
 }
 
-extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
-                                     hipStream_t stream)
+static int head_finish_fwd_impl(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, float* preobj, int och,
+                                hipStream_t stream)
 {
     if (!pre || !out) return RY_ERR_ARG;
     const int64_t total = (int64_t)B * na * gs * gs * attrs;
     if (total == 0) return RY_OK;
     const int TC = head_tile_cells(na * attrs);
     const size_t lds = ((size_t)TC * (na * attrs + 1) + na * attrs) * sizeof(float);
-    hipLaunchKernelGGL(head_finish_fwd_kernel, dim3((unsigned)(B * ry_cdiv((int64_t)gs * gs, TC))), dim3(256), lds, stream, pre, ldp, mul, B, gs, na,
-                       attrs, TC, out);
+    const dim3 grid((unsigned)(B * ry_cdiv((int64_t)gs * gs, TC)));
+    if (preobj) hipLaunchKernelGGL(head_finish_fwd_kernel<true>, grid, dim3(256), lds, stream, pre, ldp, mul, B, gs, na, attrs, TC, out, preobj, och);
+    else hipLaunchKernelGGL(head_finish_fwd_kernel<false>, grid, dim3(256), lds, stream, pre, ldp, mul, B, gs, na, attrs, TC, out, preobj, och);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
 
+extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
+                                     hipStream_t stream)
+{
+    return head_finish_fwd_impl(pre, ldp, mul, B, gs, na, attrs, out, nullptr, 0, stream);
+}
+
+// the same pass + preobj [B, na, gs, gs] fp32 = pre[.., a * attrs + och] (the objectness column before ImplicitM) for ryolo_head_finish_bwd_sparse
+extern "C" int ryolo_head_finish_fwd_obj(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, int och,
+                                         float* preobj, hipStream_t stream)
+{
+    if (!preobj || och < 0 || och >= attrs) return RY_ERR_ARG;
+    return head_finish_fwd_impl(pre, ldp, mul, B, gs, na, attrs, out, preobj, och, stream);
+}
+
 // dbias (conv bias gradient) and dmul (ImplicitM gradient, with mul) are ACCUMULATED; scratch needs
 // (B*ceil(gs*gs/128) + 64) * 2 * na*attrs floats; dpre columns >= na*attrs must have been zeroed once by the caller
-extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
-                                     bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, hipStream_t stream)
+static int head_finish_bwd_impl(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
+                                bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, const float* objgrad, const int* owner, int och,
+                                const float* preobj, hipStream_t stream)
 {
     if (!dout || !pre || !dpre || !scratch || (mul && !dmul)) return RY_ERR_ARG;
+    if (objgrad && (!owner || och < 0 || och >= attrs)) return RY_ERR_ARG;
     if ((int64_t)B * gs * gs == 0) return RY_OK;
     const int C = na * attrs;
     const int ncb = (int)ry_cdiv((int64_t)gs * gs, HEAD_CPB);
@@ -1480,12 +1661,36 @@ extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ld
     const int TC = head_tile_cells(C);
     const size_t lds = ((size_t)TC * (C + 1) + C) * sizeof(float);
     // (with four quads per thread compiled in for every C the kernel held 179 VGPRs = 2 waves per SIMD)
-    if (C <= 512) hipLaunchKernelGGL(head_finish_bwd_kernel<1>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch);
-    else hipLaunchKernelGGL(head_finish_bwd_kernel<4>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch);
+    static const int direct = getenv("RYOLO_HEAD_SPARSE_DIRECT") ? atoi(getenv("RYOLO_HEAD_SPARSE_DIRECT")) : 1;      // 0: the dense kernel's sparse tile fill (what larger heads take)
+    if (objgrad && direct && C <= 512 && na <= HS_MAXNA && (preobj || !mul)) {
+        const size_t l2 = ((size_t)na * 2 * HS_LDA + 5 * C + 1) * sizeof(float) + (size_t)na * 2 * sizeof(unsigned long long);
+        hipLaunchKernelGGL(head_bwd_sparse_kernel, dim3(rows), dim3(256), l2, stream, dout, objgrad, preobj, owner, och, pre, ldp, mul, B, gs, na, attrs,
+                           dpre, ldd, scratch);
+    } else if (C <= 512) hipLaunchKernelGGL(head_finish_bwd_kernel<1>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch, objgrad, owner, och);
+    else hipLaunchKernelGGL(head_finish_bwd_kernel<4>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch, objgrad, owner, och);
     const float* part = fold_rows(scratch, rows, 2 * C, scratch + (int64_t)rows * 2 * C, stream);
     hipLaunchKernelGGL(head_grad_rows_kernel, dim3((unsigned)ry_cdiv(2 * C, 256)), dim3(256), 0, stream, part, rows, C, dbias, mul ? dmul : nullptr);
     RY_CHECK_LAUNCH();
     return RY_OK;
+}
+
+extern "C" int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs,
+                                     bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, hipStream_t stream)
+{
+    return head_finish_bwd_impl(dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd, dbias, dmul, scratch, nullptr, nullptr, 0, nullptr, stream);
+}
+
+// the same pass over the SPARSE description of dout the fused loss leaves behind (LossParams.objgrad + ryolo_loss_owner_grids): objgrad
+// [B, na, gs, gs] = the objectness element of every cell, owner[cell] >= 0 = the cell's dense row of dout is to be read (matched cells), every
+// other element of dout is zero and is NOT read.  och = index of the objectness element inside a row (4 csl, 5 kfiou).  preobj (optional; from
+// ryolo_head_finish_fwd_obj) = the objectness column of pre as a compact [B, na, gs, gs] array: with it (and na * attrs <= 512, na <= 32) `pre` is
+// read at matched cells only.  Same results bit for bit.
+extern "C" int ryolo_head_finish_bwd_sparse(const float* dout, const float* objgrad, const int* owner, int och, const float* preobj, const float* pre,
+                                            int ldp, const float* mul, int B, int gs, int na, int attrs, bf16_t* dpre, int ldd, float* dbias,
+                                            float* dmul, float* scratch, hipStream_t stream)
+{
+    if (!objgrad || !owner) return RY_ERR_ARG;
+    return head_finish_bwd_impl(dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd, dbias, dmul, scratch, objgrad, owner, och, preobj, stream);
 }
 
 extern "C" int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, hipStream_t stream)

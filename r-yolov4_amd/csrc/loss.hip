@@ -547,7 +547,10 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
             const float x = p.head[scale][(int64_t)i * attrs + och];
             const float t = s.tconf[i];
             acc += fl_val(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
-            if (p.compute_grad) g = kg * fl_grad(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
+            if (p.compute_grad) {
+                g = kg * fl_grad(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
+                if (p.objgrad[scale]) p.objgrad[scale][i] = g;
+            }
         }
         if (!p.compute_grad) continue;
         const int w0 = ib + (int)(threadIdx.x & ~63u);                              // first cell of this wave's run
@@ -688,6 +691,20 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
         hipLaunchKernelGGL(loss_obj_kernel, dim3(s[i].nblk_obj), dim3(256), 0, stream, p, s[i], i);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, p, s[0], s[1], s[2]);
     RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+// the owner grids of the last ryolo_loss call on this workspace: owner[i][cell] >= 0 iff the cell of scale i was matched (its grad[] row is dense);
+// valid until the next ryolo_loss on the same workspace
+extern "C" int ryolo_loss_owner_grids(const LossParams* pp, const int** owner)
+{
+    if (!pp || !owner || !pp->ws) return RY_ERR_ARG;
+    LossParams p = *pp;
+    ScaleWs s[3];
+    size_t need;
+    carve(p, s, &need);
+    if (p.ws_bytes < need) return RY_ERR_WORKSPACE;
+    for (int i = 0; i < 3; i++) owner[i] = s[i].owner;
     return RY_OK;
 }
 

@@ -22,6 +22,7 @@ from . import structs as S
 BF16 = torch.bfloat16
 
 
+_HEAD_SPARSE = os.environ.get("RYOLO_HEAD_SPARSE", "1") != "0"
 _DEBUG_SKIP_SIDE = os.environ.get("RYOLO_DEBUG_SKIP_SIDE") == "1"     # tools only: never set in a run that reports numbers
 
 class Buf:
@@ -1021,8 +1022,14 @@ class Graph:
                    pre.data_ptr(), coutp, bias=conv.bias.data_ptr())
         out = self.f32(x.N, na, x.H, x.W, attrs)
         mptr = implicit_m.data_ptr() if implicit_m is not None else None
-        self._call(self.fwd, "ryolo_head_finish_fwd", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr())
-        rec = dict(out=out, dout=None)
+        preobj, och = None, (4 if getattr(rt.model, "mode", None) == "csl" else 5)        # objectness element of a head row (lib/loss.py:216, :411)
+        if self.training and _HEAD_SPARSE:
+            # compact copy of the objectness column for the sparse head backward (set_head_grad)
+            preobj = self.f32(x.N, na, x.H, x.W)
+            self._call(self.fwd, "ryolo_head_finish_fwd_obj", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr(), och, preobj.data_ptr())
+        else:
+            self._call(self.fwd, "ryolo_head_finish_fwd", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr())
+        rec = dict(out=out, dout=None, preobj=preobj, och=och)
         self.heads.append(rec)
         if self.training:
             dout = self.f32(x.N, na, x.H, x.W, attrs)
@@ -1060,10 +1067,20 @@ class Graph:
             st.img = imgs.data_ptr()
         self._img_ref = imgs                        # keep alive until the next call
 
-    def set_head_grad(self, rec, grad):
+    def set_head_grad(self, rec, grad, compact=None):
+        """Point the head backward at `grad`.  compact = (objgrad, owner pointer, objectness channel, keep-alive) from
+        lib/loss.py compact_head_grad(): the sparse entry point rebuilds unmatched rows from the compact objectness gradients."""
         fn, args, name = self.bwd[rec["dout_slot"]]
-        self.bwd[rec["dout_slot"]] = (fn, (grad.data_ptr(),) + args[1:], name)
-        rec["dout_ref"] = grad
+        tail = args[5:] if name == "ryolo_head_finish_bwd_sparse" else args[1:]
+        if compact is not None:
+            objgrad, owner, och, keep = compact
+            preobj = rec["preobj"].data_ptr() if rec.get("preobj") is not None and rec["och"] == och else None
+            self.bwd[rec["dout_slot"]] = (hip.lib().ryolo_head_finish_bwd_sparse, (grad.data_ptr(), objgrad.data_ptr(), owner, och, preobj) + tail,
+                                          "ryolo_head_finish_bwd_sparse")
+            rec["dout_ref"] = (grad, objgrad, keep)
+        else:
+            self.bwd[rec["dout_slot"]] = (hip.lib().ryolo_head_finish_bwd, (grad.data_ptr(),) + tail, "ryolo_head_finish_bwd")
+            rec["dout_ref"] = grad
 
     # ------------------------------------------------------------------ plan assembly
     def begin(self):

@@ -11,6 +11,11 @@ from . import structs as S
 from .graph import Graph
 
 
+def _compact_head_grad(t):
+    from ..lib.loss import compact_head_grad        # (lazy: lib/ imports the engine)
+    return compact_head_grad(t)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -292,7 +297,7 @@ class NetFunction(torch.autograd.Function):
                 h["dout"].zero_()
                 g.set_head_grad(h, h["dout"])
             elif go.dtype == torch.float32 and go.is_contiguous() and go.shape == h["dout"].shape:
-                g.set_head_grad(h, go)                    # read the loss gradient in place
+                g.set_head_grad(h, go, _compact_head_grad(go))   # read the loss gradient in place (compact form if it is the fused loss's own map)
             else:
                 h["dout"].copy_(go)
                 g.set_head_grad(h, h["dout"])

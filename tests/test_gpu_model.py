@@ -437,3 +437,87 @@ def test_loss_gradient_with_many_duplicate_cells_vs_oracle_autograd(mode):
     assert abs(items["total_loss"] - float(items_o["total_loss"])) < 1e-4 * abs(float(items_o["total_loss"]))
     for a, b in zip(outs, outs_o):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-7)
+
+
+@pytest.mark.parametrize("ver,mode,scale", [("yolov7", "kfiou", 1.0), ("yolov7", "csl", 1.0), ("yolov4", "kfiou", 3.0)])
+def test_compact_head_gradient_handoff_is_bit_identical_and_used(ver, mode, scale, monkeypatch):
+    """r05: the engine's head backward takes the fused loss's gradient in compact form (objectness gradients + owner grid + dense rows of matched
+    cells only, lib/loss.py compact_head_grad).  Same parameter gradients bit for bit as the dense hand-over (RYOLO_HEAD_SPARSE=0), also with
+    a scaled loss; the tape must show the sparse entry point when the loss's own tensors arrive and the dense one otherwise."""
+    from ryolov4_amd.lib import loss as L
+    from ryolov4_amd.model.yolo import Yolo
+    nc = 16
+    net = Yolo(nc, CFG, mode, ver)
+    net.load_state_dict(fill_state(net.state_dict()))
+    net.to(DEV).train()
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(11)).to(DEV)
+    tg = synth_targets(2, 8, nc, mode == "csl", seed=5, img_size=96).to(DEV)
+    crit = (L.ComputeCSLLoss if mode == "csl" else L.ComputeKFIoULoss)(net, HYP)
+    flat, names = [], []
+    for sparse in (True, False, True):
+        monkeypatch.setattr(L, "_HEAD_SPARSE", sparse)
+        net.zero_grad(set_to_none=False)
+        for p in net.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        outs = net(x, training=True)
+        loss, _ = crit(outs, tg)
+        (loss * scale).backward() if scale != 1.0 else loss.backward()
+        flat.append(torch.cat([p.grad.flatten() for p in net.parameters()]).clone())
+        names.append(sorted({n for _f, _a, n in _last_plan(net).bwd if n.startswith("ryolo_head_finish_bwd")}))
+    assert names[0] == ["ryolo_head_finish_bwd_sparse"] and names[1] == ["ryolo_head_finish_bwd"], names
+    assert flat[0].abs().sum() > 0 and torch.isfinite(flat[0]).all()
+    assert torch.equal(flat[0], flat[1])
+    assert torch.equal(flat[0], flat[2])
+
+
+def test_compact_head_gradient_is_dropped_when_the_criterion_ran_again_or_the_gradient_was_touched(monkeypatch):
+    """The owner grids live in the criterion's workspace: a second call of the criterion before backward invalidates them, and a gradient that
+    reaches the engine as another tensor (here: outputs used twice, autograd sums two maps) is not the loss's map.  Both fall back to the
+    dense hand-over and give the right gradients."""
+    from ryolov4_amd.lib import loss as L
+    from ryolov4_amd.model.yolo import Yolo
+    nc, mode = 2, "kfiou"
+    net = Yolo(nc, CFG, mode, "yolov7")
+    net.load_state_dict(fill_state(net.state_dict()))
+    net.to(DEV).train()
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(12)).to(DEV)
+    tg = synth_targets(2, 8, nc, False, seed=6, img_size=96).to(DEV)
+    crit = L.ComputeKFIoULoss(net, HYP)
+
+    def grads():
+        return torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+
+    def zero():
+        for p in net.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+    monkeypatch.setattr(L, "_HEAD_SPARSE", False)
+    outs = net(x, training=True)
+    loss, _ = crit(outs, tg)
+    loss.backward()
+    want = grads()
+    monkeypatch.setattr(L, "_HEAD_SPARSE", True)
+    # (1) criterion called again (other targets) between forward and backward of the first loss
+    zero()
+    outs = net(x, training=True)
+    loss, _ = crit(outs, tg)
+    with torch.no_grad():
+        crit([o.detach() for o in outs], tg[:3])
+    loss.backward()
+    assert {n for _f, _a, n in _last_plan(net).bwd if n.startswith("ryolo_head_finish_bwd")} == {"ryolo_head_finish_bwd"}
+    assert torch.equal(grads(), want)
+    # (2) two losses on the same outputs: the engine receives the SUM of two maps, a tensor the loss does not know
+    zero()
+    outs = net(x, training=True)
+    l1, _ = crit(outs, tg)
+    l2, _ = L.ComputeKFIoULoss(net, HYP)(outs, tg)
+    (0.5 * l1 + 0.5 * l2).backward()
+    assert {n for _f, _a, n in _last_plan(net).bwd if n.startswith("ryolo_head_finish_bwd")} == {"ryolo_head_finish_bwd"}
+    torch.testing.assert_close(grads(), want, rtol=1e-5, atol=1e-7)
+
+
+def _last_plan(net):
+    graphs = [g for k, g in net.runtime()._graphs.items() if k[3]]         # the (one) training plan
+    assert len(graphs) == 1
+    return graphs[0]
