@@ -7,11 +7,11 @@
 // O(n^2) broadcast + batched 2x2 LU in KFLoss per step.  Here the whole loss is 7 kernels (15 launches: K2, K2b, K3, K4 once per scale) with no host round trip:
 //   K1 loss_targets_*        32 workgroups per scale, two launches (count, then place): candidate (offset, anchor, target) triples
 //                            are tested and compacted IN THE REFERENCE'S ORDER with ballot/popcount prefix sums (bit-exact indices);
-//   K2 loss_match_kernel     one wavefront per match: lane 0 differentiates the box term with forward-mode dual numbers
-//                            (CIoU with constant alpha / KFIoU closed form), all 64 lanes run the class / 180-bin CSL
-//                            BCE with wave64 shuffle reductions; the box-term gradient of the match is parked for K2b;
-//                            duplicate cells are resolved last-writer-wins via an atomicMax owner grid and linked
-//                            into a per-cell chain;
+//   K2a loss_match_box_kernel  one THREAD per match (r05; lane 0 of a wave per match before): differentiates the box term with
+//                            forward-mode dual numbers (CIoU with constant alpha / KFIoU closed form); the box-term gradient of the
+//                            match is parked for K2b; duplicate cells are resolved last-writer-wins via an atomicMax owner grid
+//                             and linked into a per-cell chain;
+//   K2 loss_match_kernel     one wavefront per match: the class / 180-bin CSL BCE with wave64 shuffle reductions, partial sums;
 //   K2b loss_match_grad_kernel  the owner of every matched cell sums the gradient terms of the cell's matches in ascending match
 //                            order (what autograd's index_put_(accumulate=True) does, in a FIXED order) and stores them;
 //   K3 loss_tconf_kernel     owners scatter their IoU score into the objectness target grid;
@@ -329,121 +329,147 @@ __device__ void kf_dual(Dual<5> x, Dual<5> y, Dual<5> w, Dual<5> h, Dual<5> r, c
 }
 
 // ------------------------------------------------------------------------------------------------ K2 per-match
-__global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, ScaleWs s, int scale)
+// K2a, box terms: ONE THREAD per match (r05).  The regression loss and its five derivatives are a few thousand dependent scalar operations per
+// match (dual numbers through the CIoU / KFIoU formulas); with one WAVE per match and this block under `lane == 0` — the r02-r04 form — the 30 k
+// matches of a benchmark-size scale were 30 k single-lane waves and the kernel was bound by instruction issue (121 us per scale).  Same arithmetic
+// per match, so every record is bit-identical; reg_a / reg_b travel to K2b's partial sums through the two spare slots of the match record.
+__global__ __launch_bounds__(256) void loss_match_box_kernel(const LossParams p, ScaleWs s, int scale)
 {
-    __shared__ float blk[4][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 4 + wave;
+    const int e = blockIdx.x * 256 + threadIdx.x;
     const int n = *s.count;
+    if (e >= n) return;
+    const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
+    float reg_a = 0.f, reg_b = 0.f;
+    const int* r = s.rec + (int64_t)e * 8;
+    float* f = s.frec + (int64_t)e * 8;
+    const int a = r[1], cell = r[6];
+    const float* ps = p.head[scale] + (int64_t)cell * attrs;
+    const float inv_n = 1.0f / (float)n;
+    {
+        const float aw = p.anchors[scale][a][0], ah = p.anchors[scale][a][1];
+        const float sx = sigm(ps[0]), sy = sigm(ps[1]), sw = sigm(ps[2]), sh = sigm(ps[3]);
+        float score, g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.mode == 0) {
+            const Dual<4> c = ciou_dual(dvar<4>(sx * 2.f - 0.5f, 0), dvar<4>(sy * 2.f - 0.5f, 1),
+                                        dvar<4>((sw * 2.f) * (sw * 2.f) * aw, 2), dvar<4>((sh * 2.f) * (sh * 2.f) * ah, 3),
+                                        f[0], f[1], f[2], f[3]);
+            reg_a = 1.0f - c.v;                                              // (1 - ciou).mean()  lib/loss.py:218
+            score = fmaxf(c.v, 0.f);
+            const float k = -p.box * inv_n;
+            g[0] = k * c.d[0] * 2.f * sx * (1.f - sx);
+            g[1] = k * c.d[1] * 2.f * sy * (1.f - sy);
+            g[2] = k * c.d[2] * 8.f * sw * sw * (1.f - sw) * aw;
+            g[3] = k * c.d[3] * 8.f * sh * sh * (1.f - sh) * ah;
+        } else if (p.mode == 2) {
+            // smooth-L1-IoU regression (EXTRA mode: the reference names it, Readme.md:4,12-13, but ships no code for it; the
+            // definition is this build's): per match  (L_sl1 / |L_sl1|) * |-log(SkewIoU)|  (R3Det, arXiv 1908.05612
+            // eq. 5): the smooth-L1 of (x, y, w, h, theta) gives the DIRECTION, the exact rotated IoU of the decoded box against
+            // its target (detached) the magnitude; the objectness target is that IoU.
+            const float sa = sigm(ps[4]);
+            float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];
+            const float hpi = (float)(3.14159265358979323846 / 2);
+            if (pa >= hpi) pa = pa - PI_F;
+            if (pa < -hpi) pa = pa + PI_F;
+            const float pv[5] = {sx * 2.f - 0.5f, sy * 2.f - 0.5f, (sw * 2.f) * (sw * 2.f) * aw, (sh * 2.f) * (sh * 2.f) * ah, pa};
+            float S = 0.f, dS[5];
+            for (int j = 0; j < 5; j++) {
+                const float d = pv[j] - f[j], ad = fabsf(d);
+                S += ad < 1.f ? 0.5f * d * d : ad - 0.5f;                    // smooth L1, beta = 1
+                dS[j] = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+            }
+            const float bp[5] = {pv[0], pv[1], pv[2], pv[3], pv[4] * 57.29577951308232f};
+            const float bt[5] = {f[0], f[1], f[2], f[3], f[4] * 57.29577951308232f};
+            BoxPrep A, Bx;
+            box_prep(bp, A);
+            box_prep(bt, Bx);
+            const float iou = rotated_iou_pair(A, Bx);
+            const float w = -logf(fmaxf(iou, 1e-6f));
+            reg_a = S > 0.f ? w : 0.f;
+            score = fmaxf(iou, 0.f);
+            const float k = S > 0.f ? p.box * inv_n * w / S : 0.f;
+            g[0] = k * dS[0] * 2.f * sx * (1.f - sx);
+            g[1] = k * dS[1] * 2.f * sy * (1.f - sy);
+            g[2] = k * dS[2] * 8.f * sw * sw * (1.f - sw) * aw;
+            g[3] = k * dS[3] * 8.f * sh * sh * (1.f - sh) * ah;
+            g[4] = k * dS[4] * 1.1f * sa * (1.f - sa);
+        } else {
+            const float sa = sigm(ps[4]);
+            float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];          // lib/loss.py:390
+            const float hp = (float)(3.14159265358979323846 / 2);
+            if (pa >= hp) pa = pa - PI_F;                                    // norm_angle, lib/general.py:14-15
+            if (pa < -hp) pa = pa + PI_F;
+            Dual<5> xy, kf;
+            float kfiou;
+            kf_dual(dvar<5>(sx * 2.f - 0.5f, 0), dvar<5>(sy * 2.f - 0.5f, 1), dvar<5>((sw * 2.f) * (sw * 2.f) * aw, 2),
+                    dvar<5>((sh * 2.f) * (sh * 2.f) * ah, 3), dvar<5>(pa, 4), f, xy, kf, kfiou);
+            reg_a = fmaxf(xy.v, 0.f);
+            reg_b = fmaxf(kf.v, 0.f);
+            score = fmaxf(kfiou, 0.f);
+            const float k = p.box * inv_n;
+            const float d0 = xy.d[0] + kf.d[0], d1 = xy.d[1] + kf.d[1], d2 = xy.d[2] + kf.d[2], d3 = xy.d[3] + kf.d[3],
+                        d4 = xy.d[4] + kf.d[4];
+            g[0] = k * d0 * 2.f * sx * (1.f - sx);
+            g[1] = k * d1 * 2.f * sy * (1.f - sy);
+            g[2] = k * d2 * 8.f * sw * sw * (1.f - sw) * aw;
+            g[3] = k * d3 * 8.f * sh * sh * (1.f - sh) * ah;
+            g[4] = k * d4 * 1.1f * sa * (1.f - sa);
+        }
+        f[5] = score;
+        atomicMax(&s.owner[cell], e);                                        // last writer (largest e) wins
+        if (p.compute_grad) {
+            float* gb = s.gbox + (int64_t)e * 8;
+            for (int k = 0; k < 5; k++) gb[k] = g[k];
+            s.next[e] = atomicExch(&s.head[cell], e);                        // link into the cell's chain (any order: K2b sorts)
+        }
+    }
+    f[6] = reg_a;
+    f[7] = reg_b;
+}
+
+// K2b, class / angle-bin BCE terms: G lanes per match — 64 (a wave per match), or 16 when the classes fit (nc <= 16, no angle bins: four matches
+// per wave; the xor butterfly over 16 lanes adds the same values in the same order as the 64-lane one did, whose upper lanes held zeros) — and
+// folds the match's box terms into the partial sums: one row of part_match per FOUR consecutive matches, as before.
+__global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, ScaleWs s, int scale, int G)
+{
+    __shared__ float blk[16][4];
+    const int per = 256 / G;                                                      // matches per workgroup: 4 or 16
+    const int n = *s.count;
+    if ((int)blockIdx.x * per >= n) return;                                          // (the grid covers the CAPACITY; finalize reads ceil(n / 4) rows)
+    const int sub = threadIdx.x / G, lane = threadIdx.x - sub * G;
+    const int e = blockIdx.x * per + sub;
     const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
     float reg_a = 0.f, reg_b = 0.f, clsl = 0.f, thl = 0.f;
     if (e < n) {
         const int* r = s.rec + (int64_t)e * 8;
-        float* f = s.frec + (int64_t)e * 8;
-        const int a = r[1], cell = r[6];
+        const float* f = s.frec + (int64_t)e * 8;
+        const int cell = r[6];
         const float* ps = p.head[scale] + (int64_t)cell * attrs;
-        const float inv_n = 1.0f / (float)n;
-        if (lane == 0) {
-            const float aw = p.anchors[scale][a][0], ah = p.anchors[scale][a][1];
-            const float sx = sigm(ps[0]), sy = sigm(ps[1]), sw = sigm(ps[2]), sh = sigm(ps[3]);
-            float score, g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            if (p.mode == 0) {
-                const Dual<4> c = ciou_dual(dvar<4>(sx * 2.f - 0.5f, 0), dvar<4>(sy * 2.f - 0.5f, 1),
-                                            dvar<4>((sw * 2.f) * (sw * 2.f) * aw, 2), dvar<4>((sh * 2.f) * (sh * 2.f) * ah, 3),
-                                            f[0], f[1], f[2], f[3]);
-                reg_a = 1.0f - c.v;                                              // (1 - ciou).mean()  lib/loss.py:218
-                score = fmaxf(c.v, 0.f);
-                const float k = -p.box * inv_n;
-                g[0] = k * c.d[0] * 2.f * sx * (1.f - sx);
-                g[1] = k * c.d[1] * 2.f * sy * (1.f - sy);
-                g[2] = k * c.d[2] * 8.f * sw * sw * (1.f - sw) * aw;
-                g[3] = k * c.d[3] * 8.f * sh * sh * (1.f - sh) * ah;
-            } else if (p.mode == 2) {
-                // smooth-L1-IoU regression (EXTRA mode: the reference names it, Readme.md:4,12-13, but ships no code for it; the
-                // definition is this build's): per match  (L_sl1 / |L_sl1|) * |-log(SkewIoU)|  (R3Det, arXiv 1908.05612
-                // eq. 5): the smooth-L1 of (x, y, w, h, theta) gives the DIRECTION, the exact rotated IoU of the decoded box against
-                // its target (detached) the magnitude; the objectness target is that IoU.
-                const float sa = sigm(ps[4]);
-                float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];
-                const float hpi = (float)(3.14159265358979323846 / 2);
-                if (pa >= hpi) pa = pa - PI_F;
-                if (pa < -hpi) pa = pa + PI_F;
-                const float pv[5] = {sx * 2.f - 0.5f, sy * 2.f - 0.5f, (sw * 2.f) * (sw * 2.f) * aw, (sh * 2.f) * (sh * 2.f) * ah, pa};
-                float S = 0.f, dS[5];
-                for (int j = 0; j < 5; j++) {
-                    const float d = pv[j] - f[j], ad = fabsf(d);
-                    S += ad < 1.f ? 0.5f * d * d : ad - 0.5f;                    // smooth L1, beta = 1
-                    dS[j] = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
-                }
-                const float bp[5] = {pv[0], pv[1], pv[2], pv[3], pv[4] * 57.29577951308232f};
-                const float bt[5] = {f[0], f[1], f[2], f[3], f[4] * 57.29577951308232f};
-                BoxPrep A, Bx;
-                box_prep(bp, A);
-                box_prep(bt, Bx);
-                const float iou = rotated_iou_pair(A, Bx);
-                const float w = -logf(fmaxf(iou, 1e-6f));
-                reg_a = S > 0.f ? w : 0.f;
-                score = fmaxf(iou, 0.f);
-                const float k = S > 0.f ? p.box * inv_n * w / S : 0.f;
-                g[0] = k * dS[0] * 2.f * sx * (1.f - sx);
-                g[1] = k * dS[1] * 2.f * sy * (1.f - sy);
-                g[2] = k * dS[2] * 8.f * sw * sw * (1.f - sw) * aw;
-                g[3] = k * dS[3] * 8.f * sh * sh * (1.f - sh) * ah;
-                g[4] = k * dS[4] * 1.1f * sa * (1.f - sa);
-            } else {
-                const float sa = sigm(ps[4]);
-                float pa = (sa - 0.5f) * 1.1f + p.anchors[scale][a][2];          // lib/loss.py:390
-                const float hp = (float)(3.14159265358979323846 / 2);
-                if (pa >= hp) pa = pa - PI_F;                                    // norm_angle, lib/general.py:14-15
-                if (pa < -hp) pa = pa + PI_F;
-                Dual<5> xy, kf;
-                float kfiou;
-                kf_dual(dvar<5>(sx * 2.f - 0.5f, 0), dvar<5>(sy * 2.f - 0.5f, 1), dvar<5>((sw * 2.f) * (sw * 2.f) * aw, 2),
-                        dvar<5>((sh * 2.f) * (sh * 2.f) * ah, 3), dvar<5>(pa, 4), f, xy, kf, kfiou);
-                reg_a = fmaxf(xy.v, 0.f);
-                reg_b = fmaxf(kf.v, 0.f);
-                score = fmaxf(kfiou, 0.f);
-                const float k = p.box * inv_n;
-                const float d0 = xy.d[0] + kf.d[0], d1 = xy.d[1] + kf.d[1], d2 = xy.d[2] + kf.d[2], d3 = xy.d[3] + kf.d[3],
-                            d4 = xy.d[4] + kf.d[4];
-                g[0] = k * d0 * 2.f * sx * (1.f - sx);
-                g[1] = k * d1 * 2.f * sy * (1.f - sy);
-                g[2] = k * d2 * 8.f * sw * sw * (1.f - sw) * aw;
-                g[3] = k * d3 * 8.f * sh * sh * (1.f - sh) * ah;
-                g[4] = k * d4 * 1.1f * sa * (1.f - sa);
-            }
-            f[5] = score;
-            atomicMax(&s.owner[cell], e);                                        // last writer (largest e) wins
-            if (p.compute_grad) {
-                float* gb = s.gbox + (int64_t)e * 8;
-                for (int k = 0; k < 5; k++) gb[k] = g[k];
-                s.next[e] = atomicExch(&s.head[cell], e);                        // link into the cell's chain (any order: K2b sorts)
-            }
-        }
+        if (lane == 0) { reg_a = f[6]; reg_b = f[7]; }
         // class BCE (nc > 1 only, lib/loss.py:223 / :399)
         const int c0 = p.mode == 0 ? 5 : 6;
         if (p.nc > 1) {
             const int tc = r[4];
-            for (int k = lane; k < p.nc; k += 64) {
+            for (int k = lane; k < p.nc; k += G) {
                 const float x = ps[c0 + k], t = (k == tc) ? 1.f : 0.f;
                 clsl += fl_val(x, t, p.cls_pw, p.fl_gamma, p.fl_alpha);
             }
         }
-        if (p.mode == 0) {                                                       // CSL theta BCE, lib/loss.py:231
+        if (p.mode == 0) {                                                       // CSL theta BCE, lib/loss.py:231  (G = 64)
             const float* tg = p.targets + (int64_t)r[5] * p.tcols + 7;
-            for (int k = lane; k < 180; k += 64) {
+            for (int k = lane; k < 180; k += G) {
                 const float x = ps[5 + p.nc + k], t = tg[k];
                 thl += fl_val(x, t, 1.0f, p.fl_gamma, p.fl_alpha);
             }
         }
     }
-    clsl = wave_sum(clsl);
-    thl = wave_sum(thl);
-    if (lane == 0) { blk[wave][0] = reg_a; blk[wave][1] = reg_b; blk[wave][2] = clsl; blk[wave][3] = thl; }
+    for (int o = G >> 1; o > 0; o >>= 1) { clsl += __shfl_xor(clsl, o, 64); thl += __shfl_xor(thl, o, 64); }
+    if (lane == 0) { blk[sub][0] = reg_a; blk[sub][1] = reg_b; blk[sub][2] = clsl; blk[sub][3] = thl; }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const float v = blk[0][threadIdx.x] + blk[1][threadIdx.x] + blk[2][threadIdx.x] + blk[3][threadIdx.x];
-        s.part_match[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
+    if ((int)threadIdx.x < per) {                                                     // thread (row j, item q)
+        const int j = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const float v = blk[4 * j][q] + blk[4 * j + 1][q] + blk[4 * j + 2][q] + blk[4 * j + 3][q];
+        const int row = blockIdx.x * (per >> 2) + j;
+        if (row < s.nblk_match) s.part_match[(int64_t)row * 4 + q] = v;
     }
 }
 
@@ -597,54 +623,64 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
 }
 
 // ------------------------------------------------------------------------------------------------ K5 finalize
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
+// (r05: 1024 threads, 16-byte loads of the partial rows and shuffle reductions — the 256-thread form walked ~30 dependent global loads per thread
+// and 135 barriers: 72 us at the benchmark size for a few kilobytes of sums)
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
 {
-    __shared__ double red[256];
-    double tot[4] = {0.0, 0.0, 0.0, 0.0};       // reg, conf, cls, theta (unscaled, summed over scales)
+    __shared__ double red[16][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double part[3][5];                            // per scale: reg_a, reg_b, cls, theta (per-match sums), objectness
+    int nn[3];
     for (int i = 0; i < 3; i++) {
         const ScaleWs s = i == 0 ? s0 : (i == 1 ? s1 : s2);
         const int n = *s.count;
+        nn[i] = n;
         const int nb = (n + 3) / 4;
-        double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int b = threadIdx.x; b < nb; b += 256)
-            for (int q = 0; q < 4; q++) part[q] += (double)s.part_match[(int64_t)b * 4 + q];
-        for (int b = threadIdx.x; b < s.nblk_obj; b += 256) part[4] += (double)s.part_obj[b];
-        for (int q = 0; q < 5; q++) {
-            red[threadIdx.x] = part[q];
-            __syncthreads();
-            for (int st = 128; st > 0; st >>= 1) {
-                if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-                __syncthreads();
-            }
-            part[q] = red[0];
-            __syncthreads();
+        for (int q = 0; q < 5; q++) part[i][q] = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(s.part_match + (int64_t)b * 4);
+            part[i][0] += (double)v.x; part[i][1] += (double)v.y; part[i][2] += (double)v.z; part[i][3] += (double)v.w;
         }
-        if (n > 0) {
-            tot[0] += (part[0] + part[1]) / (double)n;
-            if (p.nc > 1) tot[2] += part[2] / ((double)n * p.nc);
-            if (p.mode == 0) tot[3] += part[3] / ((double)n * 180.0);
-        }
-        tot[1] += part[4] / (double)s.cells;
+        for (int b = threadIdx.x; b < s.nblk_obj; b += 1024) part[i][4] += (double)s.part_obj[b];
     }
-    // target rows whose image index is outside [0, batch): the reference raises IndexError at pi[b, ...] (lib/loss.py:209,385); the
-    // assignment kernels drop such rows instead of indexing out of bounds, and the count is reported so the host can raise
     int bad = 0;
-    for (int t = threadIdx.x; t < p.nt; t += 256) {
+    for (int t = threadIdx.x; t < p.nt; t += 1024) {
         const int tb = (int)p.targets[(int64_t)t * p.tcols];
         bad += (tb < 0 || tb >= p.batch) ? 1 : 0;
     }
-    red[threadIdx.x] = (double)bad;
+    for (int i = 0; i < 3; i++)
+        for (int q = 0; q < 5; q++) {
+            const double v = wave_sum_d(part[i][q]);
+            if (lane == 0) red[wave][i * 5 + q] = v;
+        }
+    {
+        const double v = wave_sum_d((double)bad);
+        if (lane == 0) red[wave][15] = v;
+    }
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
+    if (threadIdx.x < 16) {
+        double v = 0.0;
+        for (int w = 0; w < 16; w++) v += red[w][threadIdx.x];
+        red[0][threadIdx.x] = v;                  // (thread q only touches column q)
+    }
+    __syncthreads();
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};       // reg, conf, cls, theta (unscaled, summed over scales)
+    for (int i = 0; i < 3; i++) {
+        const ScaleWs s = i == 0 ? s0 : (i == 1 ? s1 : s2);
+        const int n = nn[i];
+        if (n > 0) {
+            tot[0] += (red[0][i * 5 + 0] + red[0][i * 5 + 1]) / (double)n;
+            if (p.nc > 1) tot[2] += red[0][i * 5 + 2] / ((double)n * p.nc);
+            if (p.mode == 0) tot[3] += red[0][i * 5 + 3] / ((double)n * 180.0);
+        }
+        tot[1] += red[0][i * 5 + 4] / (double)s.cells;
     }
     if (threadIdx.x == 0) {
         const float reg = p.box * (float)tot[0], conf = p.obj * (float)tot[1], cls = p.cls * (float)tot[2],
                     th = p.theta_gain * (float)tot[3];
         p.items[0] = reg; p.items[1] = conf; p.items[2] = cls; p.items[3] = th;
         p.items[4] = reg + conf + cls + th;
-        p.items[5] = (float)red[0];
+        p.items[5] = (float)red[0][15];
     }
 }
 
@@ -682,14 +718,16 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
         hipLaunchKernelGGL(loss_targets_count_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
         hipLaunchKernelGGL(loss_targets_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
         for (int i = 0; i < 3; i++) {
-            hipLaunchKernelGGL(loss_match_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
+            hipLaunchKernelGGL(loss_match_box_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, p, s[i], i);
+            const int G = (p.mode != 0 && p.nc <= 16) ? 16 : 64;
+            hipLaunchKernelGGL(loss_match_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256 / G)), dim3(256), 0, stream, p, s[i], i, G);
             if (p.compute_grad) hipLaunchKernelGGL(loss_match_grad_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
             hipLaunchKernelGGL(loss_tconf_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, s[i]);
         }
     }
     for (int i = 0; i < 3; i++)
         hipLaunchKernelGGL(loss_obj_kernel, dim3(s[i].nblk_obj), dim3(256), 0, stream, p, s[i], i);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, p, s[0], s[1], s[2]);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
