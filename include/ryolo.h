@@ -215,9 +215,10 @@ int ryolo_head_finish_bwd(const float* dout, const float* pre, int ldp, const fl
 int ryolo_head_finish_bwd_sparse(const float* dout, const float* objgrad, const int* owner, int och, const float* preobj, const float* pre, int ldp,
                                  const float* mul, int B, int gs, int na, int attrs, bf16_t* dpre, int ldd, float* dbias, float* dmul,
                                  float* scratch, ryolo_stream_t stream);
-/* ryolo_head_finish_fwd + preobj [B, na, gs, gs] fp32 = pre[.., a*attrs + och] (och: 4 csl, 5 kfiou) */
+/* ryolo_head_finish_fwd + preobj [B, na, gs, gs] fp32 = pre[.., a*attrs + och] (och: 4 csl, 5 kfiou) and, if xobj is given, the same column of
+ * out (after ImplicitM) — LossParams.headobj */
 int ryolo_head_finish_fwd_obj(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, int och, float* preobj,
-                              ryolo_stream_t stream);
+                              float* xobj, ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
 /* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= (ceil(M/256) + 64)*C floats */
 int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);

@@ -162,6 +162,9 @@ typedef struct LossParams {
     float* objgrad[3];        // optional (compute_grad): the objectness gradient of every cell ALSO as a compact [B, na, gs, gs] array — with the owner
                               // grids (ryolo_loss_owner_grids) the sparse description of grad[]: unmatched cells are zero except their objectness
                               // element.  ryolo_head_finish_bwd_sparse reads that instead of the dense 88-byte rows (r05)
+    const float* headobj[3];  // optional: the objectness logit of every cell (head[i][cell * attrs + och]) as a compact [B, na, gs, gs] array, as
+                              // ryolo_head_finish_fwd_obj leaves it; the objectness pass then reads 4 bytes per cell instead of one strided element
+                              // of every row (= the whole map through the cache).  Must hold exactly the head maps' values.
 } LossParams;
 
 #endif /* RYOLO_PARAMS_H */

@@ -864,7 +864,8 @@ static int head_tile_cells(int C) { int tc = 32; while (tc > 1 && ((size_t)tc * 
 
 template <bool OBJ>
 __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ mul, int B, int gs,
-                                                              int na, int attrs, int TC, float* __restrict__ out, float* __restrict__ preobj, int och)
+                                                              int na, int attrs, int TC, float* __restrict__ out, float* __restrict__ preobj, int och,
+                                                              float* __restrict__ xobj)
 {
     extern __shared__ float hl[];                              // t[TC][C + 1], mulv[C]
     const int cells = gs * gs, C = na * attrs, LD = C + 1;
@@ -898,7 +899,9 @@ __global__ __launch_bounds__(256) void head_finish_fwd_kernel(const float* __res
     if (OBJ)
         for (int i = threadIdx.x; i < na * ncell; i += 256) {
             const int a = i / ncell, cell = i - a * ncell;
-            preobj[((int64_t)b * na + a) * cells + c0 + cell] = hl[cell * LD + a * attrs + och];
+            const float v = hl[cell * LD + a * attrs + och];
+            preobj[((int64_t)b * na + a) * cells + c0 + cell] = v;
+            if (xobj) xobj[((int64_t)b * na + a) * cells + c0 + cell] = late ? v * mulv[a * attrs + och] : v;     // = out's element, same product
         }
     const int run = ncell * attrs, nq = (run + 3) >> 2;
     const float rattrs = 1.0f / (float)attrs;
@@ -1617,7 +1620,7 @@ extern "C" int ryolo_im2col(const float* img, int NB, int Cin, int H, int W, int
 }
 
 static int head_finish_fwd_impl(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, float* preobj, int och,
-                                hipStream_t stream)
+                                float* xobj, hipStream_t stream)
 {
     if (!pre || !out) return RY_ERR_ARG;
     const int64_t total = (int64_t)B * na * gs * gs * attrs;
@@ -1625,8 +1628,8 @@ static int head_finish_fwd_impl(const float* pre, int ldp, const float* mul, int
     const int TC = head_tile_cells(na * attrs);
     const size_t lds = ((size_t)TC * (na * attrs + 1) + na * attrs) * sizeof(float);
     const dim3 grid((unsigned)(B * ry_cdiv((int64_t)gs * gs, TC)));
-    if (preobj) hipLaunchKernelGGL(head_finish_fwd_kernel<true>, grid, dim3(256), lds, stream, pre, ldp, mul, B, gs, na, attrs, TC, out, preobj, och);
-    else hipLaunchKernelGGL(head_finish_fwd_kernel<false>, grid, dim3(256), lds, stream, pre, ldp, mul, B, gs, na, attrs, TC, out, preobj, och);
+    if (preobj) hipLaunchKernelGGL(head_finish_fwd_kernel<true>, grid, dim3(256), lds, stream, pre, ldp, mul, B, gs, na, attrs, TC, out, preobj, och, xobj);
+    else hipLaunchKernelGGL(head_finish_fwd_kernel<false>, grid, dim3(256), lds, stream, pre, ldp, mul, B, gs, na, attrs, TC, out, preobj, och, xobj);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -1634,15 +1637,15 @@ static int head_finish_fwd_impl(const float* pre, int ldp, const float* mul, int
 extern "C" int ryolo_head_finish_fwd(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out,
                                      hipStream_t stream)
 {
-    return head_finish_fwd_impl(pre, ldp, mul, B, gs, na, attrs, out, nullptr, 0, stream);
+    return head_finish_fwd_impl(pre, ldp, mul, B, gs, na, attrs, out, nullptr, 0, nullptr, stream);
 }
 
 // the same pass + preobj [B, na, gs, gs] fp32 = pre[.., a * attrs + och] (the objectness column before ImplicitM) for ryolo_head_finish_bwd_sparse
 extern "C" int ryolo_head_finish_fwd_obj(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, int och,
-                                         float* preobj, hipStream_t stream)
+                                         float* preobj, float* xobj, hipStream_t stream)
 {
     if (!preobj || och < 0 || och >= attrs) return RY_ERR_ARG;
-    return head_finish_fwd_impl(pre, ldp, mul, B, gs, na, attrs, out, preobj, och, stream);
+    return head_finish_fwd_impl(pre, ldp, mul, B, gs, na, attrs, out, preobj, och, xobj, stream);
 }
 
 // dbias (conv bias gradient) and dmul (ImplicitM gradient, with mul) are ACCUMULATED; scratch needs

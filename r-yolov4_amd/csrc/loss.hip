@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
         const bool valid = i < s.cells;
         float g = 0.f;
         if (valid) {
-            const float x = p.head[scale][(int64_t)i * attrs + och];
+            const float x = p.headobj[scale] ? p.headobj[scale][i] : p.head[scale][(int64_t)i * attrs + och];
             const float t = s.tconf[i];
             acc += fl_val(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
             if (p.compute_grad) {

@@ -1025,11 +1025,15 @@ class Graph:
         preobj, och = None, (4 if getattr(rt.model, "mode", None) == "csl" else 5)        # objectness element of a head row (lib/loss.py:216, :411)
         if self.training and _HEAD_SPARSE:
             # compact copy of the objectness column for the sparse head backward (set_head_grad)
+            # and of the objectness logits for the fused loss (lib/loss.py head_obj_logits: 4 bytes per cell instead of a strided walk of the map)
             preobj = self.f32(x.N, na, x.H, x.W)
-            self._call(self.fwd, "ryolo_head_finish_fwd_obj", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr(), och, preobj.data_ptr())
+            xobj = self.f32(x.N, na, x.H, x.W) if mptr is not None else preobj        # (no ImplicitM: the same values)
+            self._call(self.fwd, "ryolo_head_finish_fwd_obj", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr(), och, preobj.data_ptr(),
+                       xobj.data_ptr() if mptr is not None else None)
         else:
+            xobj = None
             self._call(self.fwd, "ryolo_head_finish_fwd", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr())
-        rec = dict(out=out, dout=None, preobj=preobj, och=och)
+        rec = dict(out=out, dout=None, preobj=preobj, och=och, xobj=xobj)
         self.heads.append(rec)
         if self.training:
             dout = self.f32(x.N, na, x.H, x.W, attrs)

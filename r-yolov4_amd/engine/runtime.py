@@ -16,6 +16,13 @@ def _compact_head_grad(t):
     return compact_head_grad(t)
 
 
+def _register_head_obj(heads):
+    from ..lib.loss import register_head_obj
+    for h in heads:
+        if h.get("xobj") is not None and not isinstance(h["xobj"], int):
+            register_head_obj(h["out"], h["xobj"], h["och"])
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -282,6 +289,7 @@ class NetFunction(torch.autograd.Function):
         # the plan's buffers hold THIS forward's activations until its backward ran: a later forward of the same plan overwrites them
         g.generation = getattr(g, "generation", 0) + 1
         ctx.rt, ctx.g, ctx.generation = rt, g, g.generation
+        _register_head_obj(g.heads)
         return tuple(h["out"].detach() for h in g.heads)      # fresh tensor objects over the plan's output buffers
 
     @staticmethod

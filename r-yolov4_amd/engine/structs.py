@@ -78,7 +78,7 @@ class LossParams(C.Structure):
     _fields_ = [("mode", I), ("nc", I), ("na", I), ("batch", I), ("nt", I), ("tcols", I), ("targets", P),
                 ("head", P * 3), ("grad", P * 3), ("gs", I * 3), ("anchors", (F * 3 * 18) * 3),
                 ("box", F), ("obj", F), ("cls", F), ("theta_gain", F), ("obj_pw", F), ("cls_pw", F),
-                ("ws", P), ("ws_bytes", Z), ("items", P), ("compute_grad", I), ("fl_gamma", F), ("fl_alpha", F), ("objgrad", P * 3)]
+                ("ws", P), ("ws_bytes", Z), ("items", P), ("compute_grad", I), ("fl_gamma", F), ("fl_alpha", F), ("objgrad", P * 3), ("headobj", P * 3)]
 
 
 _PTR = C.POINTER
@@ -110,7 +110,7 @@ for _name, _sig in {
     "ryolo_head_finish_fwd": [P, I, P, I, I, I, I, P, P],
     "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P, P],
     "ryolo_head_finish_bwd_sparse": [P, P, P, I, P, P, I, P, I, I, I, I, P, I, P, P, P, P],
-    "ryolo_head_finish_fwd_obj": [P, I, P, I, I, I, I, P, I, P, P],
+    "ryolo_head_finish_fwd_obj": [P, I, P, I, I, I, I, P, I, P, P, P],
     "ryolo_chan_add": [P, I, P, L, I, P, I, P],
     "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],

@@ -24,6 +24,26 @@ _HANDOFF = {}
 _HEAD_SPARSE = os.environ.get("RYOLO_HEAD_SPARSE", "1") != "0"
 
 
+_HEAD_OBJ = {}
+
+
+def register_head_obj(out, xobj, och):
+    """Engine side (engine/runtime.py, after every training forward): `xobj` [B, na, gs, gs] holds out[..., och] — written by the same kernel
+    as `out` (ryolo_head_finish_fwd_obj), so the two always describe the same forward."""
+    if len(_HEAD_OBJ) > 64:                         # (plans come and go with batch sizes; entries are a pointer and two tensor handles)
+        _HEAD_OBJ.clear()
+    _HEAD_OBJ[out.data_ptr()] = (out, xobj, och, out._version)
+
+
+def head_obj_logits(o, och):
+    """The compact objectness logits of head map `o` if `o` is — same storage, not modified through torch since — an output buffer of the
+    engine, else None (the objectness pass then reads the strided elements of the map itself)."""
+    h = _HEAD_OBJ.get(o.data_ptr())
+    if h is None or not _HEAD_SPARSE or h[2] != och or o.shape[:4] != h[1].shape or o._version != h[3] or h[0]._version != h[3]:
+        return None
+    return h[1]
+
+
 def compact_head_grad(t):
     """(objgrad tensor, owner-grid pointer, objectness channel) of the dense gradient map `t` if `t` is — same storage, untouched — one of the
     maps the last loss call produced, else None."""
@@ -133,6 +153,10 @@ class _ComputeLossBase:
         if objgrad is not None:
             for i in range(3):
                 p.objgrad[i] = objgrad[i].data_ptr()
+        xobj = [head_obj_logits(o, 4 if self.MODE == 0 else 5) for o in outs]     # (kept alive until the launch below is enqueued)
+        for i in range(3):
+            p.headobj[i] = xobj[i].data_ptr() if xobj[i] is not None else None
+        self._used_head_obj = [x is not None for x in xobj]
         hip.call("ryolo_loss", p, hip.stream())
         if objgrad is not None:
             own = (S.P * 3)()

@@ -83,10 +83,12 @@ def test_head_finish_backward_sparse_form_is_bit_identical(B, gs, na, attrs, och
     if with_preobj:
         out = torch.empty(B, na, gs, gs, attrs, device=DEV)
         preobj = torch.empty(B, na, gs, gs, device=DEV)
+        xobj = torch.empty(B, na, gs, gs, device=DEV)
         hip.call("ryolo_head_finish_fwd_obj", pre.data_ptr(), ldp, mul.data_ptr() if with_mul else None, B, gs, na, attrs, out.data_ptr(), och,
-                 preobj.data_ptr(), hip.stream())
+                 preobj.data_ptr(), xobj.data_ptr(), hip.stream())
         v = pre[:, :C] * mul if with_mul else pre[:, :C]
         assert torch.equal(out, v.view(B, gs, gs, na, attrs).permute(0, 3, 1, 2, 4).contiguous())
+        assert torch.equal(xobj, out[..., och])
         assert torch.equal(preobj, pre[:, :C].view(B, gs, gs, na, attrs)[..., och].permute(0, 3, 1, 2).contiguous())
     res = []
     for sparse in (False, True):
@@ -115,4 +117,4 @@ def test_head_finish_backward_sparse_rejects_bad_arguments():
         hip.call("ryolo_head_finish_bwd_sparse", t.data_ptr(), None, None, 5, None, t.data_ptr(), 32, None, 1, 1, 1, 8, t.data_ptr(), 32, t.data_ptr(), None,
                  t.data_ptr(), hip.stream())
     with pytest.raises(RuntimeError):
-        hip.call("ryolo_head_finish_fwd_obj", t.data_ptr(), 32, None, 1, 1, 1, 8, t.data_ptr(), 8, t.data_ptr(), hip.stream())   # och outside the row
+        hip.call("ryolo_head_finish_fwd_obj", t.data_ptr(), 32, None, 1, 1, 1, 8, t.data_ptr(), 8, t.data_ptr(), None, hip.stream())   # och outside the row

@@ -453,7 +453,7 @@ def test_compact_head_gradient_handoff_is_bit_identical_and_used(ver, mode, scal
     x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(11)).to(DEV)
     tg = synth_targets(2, 8, nc, mode == "csl", seed=5, img_size=96).to(DEV)
     crit = (L.ComputeCSLLoss if mode == "csl" else L.ComputeKFIoULoss)(net, HYP)
-    flat, names = [], []
+    flat, names, items = [], [], []
     for sparse in (True, False, True):
         monkeypatch.setattr(L, "_HEAD_SPARSE", sparse)
         net.zero_grad(set_to_none=False)
@@ -464,11 +464,14 @@ def test_compact_head_gradient_handoff_is_bit_identical_and_used(ver, mode, scal
         loss, _ = crit(outs, tg)
         (loss * scale).backward() if scale != 1.0 else loss.backward()
         flat.append(torch.cat([p.grad.flatten() for p in net.parameters()]).clone())
+        items.append((float(loss), list(crit._used_head_obj)))
         names.append(sorted({n for _f, _a, n in _last_plan(net).bwd if n.startswith("ryolo_head_finish_bwd")}))
     assert names[0] == ["ryolo_head_finish_bwd_sparse"] and names[1] == ["ryolo_head_finish_bwd"], names
     assert flat[0].abs().sum() > 0 and torch.isfinite(flat[0]).all()
     assert torch.equal(flat[0], flat[1])
     assert torch.equal(flat[0], flat[2])
+    # the objectness pass of the loss read the engine's compact logits (same values: same loss, bit for bit) / the maps themselves
+    assert items[0][1] == [True] * 3 and items[1][1] == [False] * 3 and items[0][0] == items[1][0] == items[2][0], items
 
 
 def test_compact_head_gradient_is_dropped_when_the_criterion_ran_again_or_the_gradient_was_touched(monkeypatch):
@@ -506,6 +509,16 @@ def test_compact_head_gradient_is_dropped_when_the_criterion_ran_again_or_the_gr
         crit([o.detach() for o in outs], tg[:3])
     loss.backward()
     assert {n for _f, _a, n in _last_plan(net).bwd if n.startswith("ryolo_head_finish_bwd")} == {"ryolo_head_finish_bwd"}
+    assert torch.equal(grads(), want)
+    assert crit._used_head_obj == [True] * 3
+    # (1b) an output edited in place through torch is no longer what the engine's compact copy describes
+    zero()
+    outs = net(x, training=True)
+    with torch.no_grad():
+        outs[1].mul_(1.0)
+    loss, _ = crit(outs, tg)
+    assert crit._used_head_obj == [True, False, True]
+    loss.backward()
     assert torch.equal(grads(), want)
     # (2) two losses on the same outputs: the engine receives the SUM of two maps, a tensor the loss does not know
     zero()
