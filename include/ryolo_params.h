@@ -56,6 +56,12 @@ typedef struct ConvGemmParams {
                                                     // ryolo_pack_s2d): column n of row (img, a, b) goes to pixel (2a + ph, 2b + pw), channel n % s2d_cin —
                                                     // every store instruction writes whole 128-byte pixel pairs (oh_mul = ow_mul = 2, bf16 epilogues only)
     int nbstat; BwdStat bstat[RY_MAX_BSTAT];        // bf16 epilogues with the identity output grid only (generic and halo-patch kernels)
+    int head_attrs, head_och;                       // head_attrs > 0 (EPI_F32_BIAS, 1x1 stride 1, LDS-DMA mainloop; else RY_ERR_UNSUPPORTED): the output is a
+                                                    // detection head written in its FINAL layout — column n = anchor n / head_attrs, attribute n % head_attrs
+                                                    // of GEMM row (image b, cell) goes to out[b][anchor][cell][attribute] (fp32 [NB, na, OH, OW, attrs]:
+                                                    // model/yololayer.py:25) after the bias and, if `scale` is set, the per-column ImplicitM factor
+                                                    // (model/neck.py:186); `stats`, if set, receives the objectness logit (attribute head_och) of every
+                                                    // (anchor, cell) as a compact [NB, na, OH, OW] array (LossParams.headobj).  ldC is ignored.
 } ConvGemmParams;
 
 typedef struct WgradParams {
@@ -144,7 +150,10 @@ typedef struct UpParams { const bf16_t* x; int ldx; bf16_t* z; int ldz; int NB, 
 
 /* ldWd: row length of the [Cin][taps][...] data-gradient image (0 = CoutP); larger when sibling convolutions share one image and
  * this entry owns a column range of it (wd then points at its first column) */
-typedef struct PackEntry { const float* src; bf16_t* wf; bf16_t* wd; int Cout, Cin, taps, CinP, CoutP, ldWd; int64_t start; } PackEntry;
+typedef struct PackEntry { const float* src; bf16_t* wf; bf16_t* wd; int Cout, Cin, taps, CinP, CoutP, ldWd; int64_t start;
+                           const float* wd_scale;   /* optional [Cout]: the data-gradient image holds W[co] * wd_scale[co] (detection heads with ImplicitM:
+                                                       dx = dout . (W * m), model/neck.py:186) */
+} PackEntry;
 
 typedef struct LossParams {
     int mode;                 // 0 csl, 1 kfiou

@@ -432,7 +432,101 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
         return ((int64_t)(e_img + wi) * p.OHf + (oh * p.oh_mul + tc.oh_add)) * p.OWf + (ow * p.ow_mul + tc.ow_add);
     };
 
-    if (p.epi == EPI_F32_BIAS) {
+    if constexpr (EP == 3) {
+        // Detection head written in its FINAL layout (r05, ConvGemmParams.head_attrs): column n = anchor a, attribute e of GEMM row (image b, cell)
+        // goes to out[b][a][cell][e] — the view / permute of model/yololayer.py:25 — after the bias and ImplicitM (p.scale; model/neck.py:186), with
+        // the objectness logit of every (anchor, cell) copied to the compact array p.stats for the fused loss.  Replaces the row-major fp32
+        // intermediate and the pass that re-read it (ryolo_head_finish_fwd).  Each wave stages 32 pixels x its 64 columns in LDS (fp32) and writes
+        // them out ANCHOR BY ANCHOR: for one anchor, consecutive cells are consecutive attrs-float rows, so an anchor that lies inside the wave's
+        // columns is one contiguous run of 32 * attrs floats.  Measured on the 100^2 head (64 images, K = 256; tools/bench_head.py): row-major GEMM
+        // 540 us + finish pass 470 us -> 583 us in one launch; direct stores from the accumulator layout (16 bytes per lane, 4 * attrs bytes apart)
+        // 830 us; and with bias / ImplicitM fetched per element from global memory instead of from LDS 1 000 us.
+        typedef float hf4 __attribute__((ext_vector_type(4), aligned(4)));
+        static_assert(WTN == 64, "head epilogue: 64 columns per wave");
+        constexpr int SLD = WTN + 4;                           // (16-byte aligned rows: the accumulator quads are staged as one ds_write_b128 each)
+        const int attrs = p.head_attrs, och = p.head_och, na = p.Nout / attrs;
+        const int cells = p.OH * p.OW;
+        const float rattrs = 1.0f / (float)attrs, rcells = 1.0f / (float)cells;
+        float* const outf = reinterpret_cast<float*>(p.out);
+        __syncthreads();                                       // every wave is done reading the operand tiles
+        float* const stg = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
+        // bias and ImplicitM of the tile's 128 columns: once per workgroup into LDS (read per element from global memory they were 128 VMEM
+        // instructions per lane and 32-pixel group)
+        float* const sbias = reinterpret_cast<float*>(smem) + 4 * 32 * SLD;
+        float* const sscale = sbias + BN;
+        if (tid < BN) {
+            const int n = n0 + tid;
+            sbias[tid] = (p.bias && n < p.Nout) ? p.bias[n] : 0.f;
+            sscale[tid] = (p.scale && n < p.Nout) ? p.scale[n] : 1.f;
+        }
+        __syncthreads();
+        const int nw0 = n0 + wn * WTN, nw1 = min(nw0 + WTN, p.Nout);
+        if (nw0 < p.Nout) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int64_t mrow0 = m0 + wm * WTM + i * 32;      // (wave-uniform)
+                if (mrow0 >= M) break;
+                const int npix = (int)min((int64_t)32, M - mrow0);
+#pragma unroll
+                for (int jj = 0; jj < TN; jj++)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; g4++) {
+                        const int c0 = jj * 32 + 8 * g4 + 4 * h;
+                        const float4 bq = *reinterpret_cast<const float4*>(sbias + wn * WTN + c0);
+                        const float4 sq = *reinterpret_cast<const float4*>(sscale + wn * WTN + c0);
+                        float4 v;                                          // (acc + bias) * ImplicitM: the two fp32 operations of the two-pass form
+                        v.x = (acc[i][jj][4 * g4 + 0] + bq.x) * sq.x;
+                        v.y = (acc[i][jj][4 * g4 + 1] + bq.y) * sq.y;
+                        v.z = (acc[i][jj][4 * g4 + 2] + bq.z) * sq.z;
+                        v.w = (acc[i][jj][4 * g4 + 3] + bq.w) * sq.w;
+                        *reinterpret_cast<float4*>(stg + (lane & 31) * SLD + c0) = v;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int b0 = (int)(mrow0 / cells), cell0 = (int)(mrow0 - (int64_t)b0 * cells);
+                const bool one_img = cell0 + npix <= cells;
+                const int a_lo = small_div(nw0, attrs, rattrs), a_hi = small_div(nw1 - 1, attrs, rattrs);
+                for (int a = a_lo; a <= a_hi; a++) {
+                    const int c_lo = max(a * attrs, nw0), c_hi = min((a + 1) * attrs, nw1);
+                    const int len = c_hi - c_lo, e_lo = c_lo - a * attrs, scol = c_lo - nw0;
+                    if (one_img && len == attrs) {
+                        float* const dst = outf + (((int64_t)b0 * na + a) * cells + cell0) * attrs;
+                        const int total = npix * attrs;
+                        for (int f0 = lane * 4; f0 < total; f0 += 256) {
+                            int pix = small_div(f0, attrs, rattrs), e = f0 - pix * attrs;
+                            float v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                v[k] = f0 + k < total ? stg[pix * SLD + scol + e] : 0.f;
+                                if (++e == attrs) { e = 0; pix++; }
+                            }
+                            if (f0 + 3 < total) { const hf4 w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<hf4*>(dst + f0) = w; }
+                            else for (int k = 0; f0 + k < total; k++) dst[f0 + k] = v[k];
+                        }
+                    } else {
+                        // part of an anchor (it straddles the wave's column range) or pixels of two images: rows of `len` floats; the pixel's
+                        // (image, cell) from the group's first one (cell0 + pix < cells + 32: exact small division, no 64-bit arithmetic)
+                        const float rlen = 1.0f / (float)len;
+                        const int total = npix * len;
+                        for (int f = lane; f < total; f += 64) {
+                            const int pix = small_div(f, len, rlen), k = f - pix * len;
+                            const int wr = small_div(cell0 + pix, cells, rcells);
+                            const int b = b0 + wr, cell = cell0 + pix - wr * cells;
+                            outf[(((int64_t)b * na + a) * cells + cell) * attrs + e_lo + k] = stg[pix * SLD + scol + k];
+                        }
+                    }
+                    const int oc = a * attrs + och;
+                    if (p.stats && oc >= c_lo && oc < c_hi && lane < npix) {
+                        const int wr = small_div(cell0 + lane, cells, rcells);
+                        const int b = b0 + wr, cell = cell0 + lane - wr * cells;
+                        p.stats[((int64_t)b * na + a) * cells + cell] = stg[lane * SLD + oc - nw0];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else if (p.epi == EPI_F32_BIAS) {
         // small outputs (detection heads): direct fp32 stores, 4 consecutive channels per lane
         const bool vec4 = (p.ldC & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
 #pragma unroll
@@ -1416,6 +1510,10 @@ static int gemm_check(const ConvGemmParams& p)
         return RY_ERR_ARG;
     if (!p.A || !p.W || !p.out || p.Cin <= 0 || p.Cin % BK || p.ldA % 8 || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4)
         return RY_ERR_ARG;
+    if (p.head_attrs) {
+        if (p.head_attrs < 7 || p.Nout % p.head_attrs || p.head_och < 0 || p.head_och >= p.head_attrs || p.epi != EPI_F32_BIAS || p.nbstat) return RY_ERR_ARG;
+        if (!gemm_is_t1(p)) return RY_ERR_UNSUPPORTED;        // (the caller falls back to the row-major form + ryolo_head_finish_fwd)
+    }
     if (p.nbstat) {
         if (p.nbstat < 0 || p.nbstat > RY_MAX_BSTAT || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.s2d_cin || p.nclasses != 1 || p.oh_mul != 1 ||
             p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || p.cls[0].oh_add || p.cls[0].ow_add)
@@ -1440,6 +1538,13 @@ extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, i
     if (!pp || !stats_rows) return RY_ERR_ARG;
     const ConvGemmParams& p = *pp;
     if (p.Cin <= 0 || p.Cin % BK || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4) return RY_ERR_ARG;
+    if (p.head_attrs) {                                       // detection head in its final layout: the 128 x 128 1x1 instantiation or nothing
+        if (p.head_attrs < 7 || p.Nout % p.head_attrs || p.epi != EPI_F32_BIAS || p.nbstat) return RY_ERR_ARG;
+        if (!gemm_is_t1(p) || (int64_t)p.NB * p.OH * p.OW > 0x7fffffff) return RY_ERR_UNSUPPORTED;
+        *stats_rows = (int)ry_cdiv((int64_t)p.NB * p.OH * p.OW, 128);
+        if (kernel) *kernel = 0 | 0x100 | (2 << 12) | (4 << 16);
+        return RY_OK;
+    }
     Ws3Geom w3;
     if ((p.pipe & 0x200) && ws3_geometry(p, w3)) {                 // persistent weight-stationary 3x3 (conv3x3_ws.hip): one statistics row per workgroup
         *stats_rows = w3.nwg;
@@ -1488,6 +1593,14 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         if (ws3_geometry(p, w3)) return ws3_launch(p, w3, stream);
         P3Geom g;
         if (p3_geometry(p, g)) return p3_launch(p, g, stream);
+    }
+    if (p.head_attrs) {                                       // detection head in its final layout: the 1x1 instantiation of the generic kernel only
+        if (!p.zeros) return RY_ERR_ARG;
+        const int64_t M = (int64_t)p.NB * p.OH * p.OW;
+        const int64_t gm = ry_cdiv(M, 128), gn = ry_cdiv(p.Nout, 128);
+        if (gm * gn > 0x7fffffff || M > 0x7fffffff) return RY_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 2, 2, 1, 32, 3, true, true>), dim3((unsigned)(gm * gn)), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
     }
     if (p.pipe & 0xff) {
         if (!p.zeros) return RY_ERR_ARG;

@@ -1334,7 +1334,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
         if (e.wd)
             for (int i = threadIdx.x; i < 32 * run; i += 256) {      // Wd[c][t][co]: co fastest
                 const int r = i & 31, tp = (i >> 5) % e.taps, c = i / run;
-                if (co0 + r < e.Cout) e.wd[((int64_t)(c0 + c) * e.taps + tp) * (e.ldWd ? e.ldWd : e.CoutP) + co0 + r] = f2bf(tile[r][c * e.taps + tp]);
+                if (co0 + r < e.Cout)
+                    e.wd[((int64_t)(c0 + c) * e.taps + tp) * (e.ldWd ? e.ldWd : e.CoutP) + co0 + r] =
+                        f2bf(e.wd_scale ? tile[r][c * e.taps + tp] * e.wd_scale[co0 + r] : tile[r][c * e.taps + tp]);
             }
     }
 }
@@ -1654,7 +1656,7 @@ static int head_finish_bwd_impl(const float* dout, const float* pre, int ldp, co
                                 bf16_t* dpre, int ldd, float* dbias, float* dmul, float* scratch, const float* objgrad, const int* owner, int och,
                                 const float* preobj, hipStream_t stream)
 {
-    if (!dout || !pre || !dpre || !scratch || (mul && !dmul)) return RY_ERR_ARG;
+    if (!dout || !dpre || !scratch || (mul && (!dmul || !pre))) return RY_ERR_ARG;       // (pre is read for the ImplicitM gradient only)
     if (objgrad && (!owner || och < 0 || och >= attrs)) return RY_ERR_ARG;
     if ((int64_t)B * gs * gs == 0) return RY_OK;
     const int C = na * attrs;
@@ -1694,6 +1696,45 @@ extern "C" int ryolo_head_finish_bwd_sparse(const float* dout, const float* objg
 {
     if (!objgrad || !owner) return RY_ERR_ARG;
     return head_finish_bwd_impl(dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd, dbias, dmul, scratch, objgrad, owner, och, preobj, stream);
+}
+
+// Detection head with ImplicitM written by the GEMM epilogue (ConvGemmParams.head_attrs): out = (x . W + b) * m.  Its backward runs the weight-
+// gradient GEMM on the UNSCALED head gradient, G[c][k] = sum_rows dout[., c] x[., k] (s[c] = sum_rows dout[., c] for the bias), and this pass
+// finishes the three parameter gradients from G without the pre-ImplicitM activations:
+//   dW[c][k] += m[c] G[c][k]     db[c] += m[c] s[c]     dm[c] += sum_k W[c][k] G[c][k] + b[c] s[c]   (= sum_rows dout (x . W + b))
+// and clears G and s for the next step.  One workgroup per output channel.
+__global__ __launch_bounds__(256) void head_wgrad_finish_kernel(float* __restrict__ G, float* __restrict__ s, const float* __restrict__ W,
+                                                                const float* __restrict__ b, const float* __restrict__ m, int K,
+                                                                float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dm)
+{
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const float mc = m[c];
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float g = G[(int64_t)c * K + k];
+        dW[(int64_t)c * K + k] += mc * g;
+        dot = fmaf(W[(int64_t)c * K + k], g, dot);
+        G[(int64_t)c * K + k] = 0.f;
+    }
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sc = s[c];
+        if (db) db[c] += mc * sc;
+        dm[c] += (red[0] + red[1]) + (red[2] + red[3]) + (b ? b[c] * sc : 0.f);
+        s[c] = 0.f;
+    }
+}
+
+extern "C" int ryolo_head_wgrad_finish(float* G, float* s, const float* W, const float* b, const float* m, int Cout, int K, float* dW, float* db,
+                                       float* dm, hipStream_t stream)
+{
+    if (!G || !s || !W || !m || !dW || !dm || Cout <= 0 || K <= 0) return RY_ERR_ARG;
+    hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(Cout), dim3(256), 0, stream, G, s, W, b, m, K, dW, db, dm);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
 }
 
 extern "C" int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, hipStream_t stream)

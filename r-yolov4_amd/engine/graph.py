@@ -23,6 +23,7 @@ BF16 = torch.bfloat16
 
 
 _HEAD_SPARSE = os.environ.get("RYOLO_HEAD_SPARSE", "1") != "0"
+_HEAD_FUSED = os.environ.get("RYOLO_HEAD_FUSED", "1") != "0"
 _DEBUG_SKIP_SIDE = os.environ.get("RYOLO_DEBUG_SKIP_SIDE") == "1"     # tools only: never set in a run that reports numbers
 
 class Buf:
@@ -407,7 +408,7 @@ class Graph:
 
     # ------------------------------------------------------------------ convolution
     def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,
-              coeffs=None, act=0, bias=None, s2d=0, pool=None, bstat=None):
+              coeffs=None, act=0, bias=None, s2d=0, pool=None, bstat=None, head=None):
         """Emit one ryolo_conv_gemm launch.  For epi == EPI_STATS the partial-statistics buffer is sized by the library's plan
         (one [2][Nout] row per M tile of the kernel it will run) and returned."""
         p = S.ConvGemmParams()
@@ -431,6 +432,8 @@ class Graph:
         p.a_bytes, p.w_bytes = A.span_bytes, W.numel() * 2
         p.pipe = self.rt.gemm_pipe
         p.s2d_cin = s2d
+        if head is not None:                            # (attrs, och, ImplicitM pointer or None, compact objectness pointer or None)
+            p.head_attrs, p.head_och, p.scale, p.stats = head
         if pool is not None:
             p.pool_idx, p.pool_dz, p.pool_ldi, p.pool_ld = pool
         if bstat:
@@ -481,7 +484,7 @@ class Graph:
                 pl = (pool["idx"].data_ptr(), pool["z"].gptr(), x.C, pool["z"].ld)
             self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld, pool=pl,
                        bstat=self._bstat_for(x))
-        elif (self.rt.s2d_dgrad and k == 3 and pad == 1 and cin <= 32 and cin % 8 == 0 and x.H % 2 == 0 and x.W % 2 == 0
+        elif (self.rt.s2d_dgrad and k == 3 and pad == 1 and cin <= self.rt.s2d_dgrad_maxc and cin % 8 == 0 and x.H % 2 == 0 and x.W % 2 == 0
               and dy_cin % 32 == 0 and dy_cin == conv.out_channels):
             # narrow stride-2 layer: ONE stride-1 GEMM over the dY grid, N = 4 parities x cin, 2x2 taps, depth-to-space store
             taps = [(da, db, 2 * da + db) for da in range(2) for db in range(2)]
@@ -531,7 +534,7 @@ class Graph:
                 res[(k, c0, Cn)] = last
         return res
 
-    def _wgrad(self, conv, dy, dy_ptr, cout_pad, x, x_ptr=None):
+    def _wgrad(self, conv, dy, dy_ptr, cout_pad, x, x_ptr=None, dW=None):
         k, s, pad, OH, OW = self._conv_geom(conv, x)
         p = S.WgradParams()
         p.dY, p.ldY, p.Cout, p.CoutPad = dy_ptr, dy.ld, conv.out_channels, cout_pad
@@ -541,7 +544,7 @@ class Graph:
         p.ntaps = len(taps)
         for i, (dh, dw, _) in enumerate(taps):
             p.dh[i], p.dw[i] = dh, dw
-        p.dW = self.rt.grad_ptr(conv.weight)
+        p.dW = dW if dW is not None else self.rt.grad_ptr(conv.weight)
         self._emit_wgrad(p, side=True)
 
     def _emit_wgrad(self, p, side=False):
@@ -1017,13 +1020,18 @@ class Graph:
             xin = self.new(x.N, x.H, x.W, x.C)
             self._call(self.fwd, "ryolo_chan_add", x.ptr(), x.ld, implicit_a.data_ptr(), x.M, x.C, xin.ptr(), xin.ld)
         M = x.M
+        och = 4 if getattr(rt.model, "mode", None) == "csl" else 5         # objectness element of a head row (lib/loss.py:216, :411)
+        mptr = implicit_m.data_ptr() if implicit_m is not None else None
+        sparse = self.training and _HEAD_SPARSE
+        if _HEAD_FUSED and rt.wgrad_lanes <= 1 and self._head_fused_ok(xin, pk, cout, conv, x, attrs, och):
+            return self._head_fused(conv, pk, x, xin, na, attrs, och, implicit_a, implicit_m, sparse)
+        assert pk.get("wd_scale") is None, "head planned both with and without the ImplicitM-carrying data-gradient image"
         pre = self.f32(M, coutp)
         self._gemm(self.fwd, xin, xin.ptr(), pk["wf"], cout, 1, conv.in_channels, x.H, x.W, 1, [([(0, 0, 0)], 0, 0)], S.EPI_F32_BIAS,
                    pre.data_ptr(), coutp, bias=conv.bias.data_ptr())
         out = self.f32(x.N, na, x.H, x.W, attrs)
-        mptr = implicit_m.data_ptr() if implicit_m is not None else None
-        preobj, och = None, (4 if getattr(rt.model, "mode", None) == "csl" else 5)        # objectness element of a head row (lib/loss.py:216, :411)
-        if self.training and _HEAD_SPARSE:
+        preobj = xobj = None
+        if sparse:
             # compact copy of the objectness column for the sparse head backward (set_head_grad)
             # and of the objectness logits for the fused loss (lib/loss.py head_obj_logits: 4 bytes per cell instead of a strided walk of the map)
             preobj = self.f32(x.N, na, x.H, x.W)
@@ -1031,7 +1039,6 @@ class Graph:
             self._call(self.fwd, "ryolo_head_finish_fwd_obj", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr(), och, preobj.data_ptr(),
                        xobj.data_ptr() if mptr is not None else None)
         else:
-            xobj = None
             self._call(self.fwd, "ryolo_head_finish_fwd", pre.data_ptr(), coutp, mptr, x.N, x.H, na, attrs, out.data_ptr())
         rec = dict(out=out, dout=None, preobj=preobj, och=och, xobj=xobj)
         self.heads.append(rec)
@@ -1057,6 +1064,75 @@ class Graph:
                 # ImplicitA: d(x + a)/dx = 1, so the data gradient is written straight into x's gradient (no buffer for xin's, no copy)
                 # and d/da is its column sum
                 self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, x)
+                if implicit_a is not None:
+                    self._call(self.bwd, "ryolo_colsum_bf16", x.gptr(), x.ld, M, x.C, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
+            self._pending_bwd.append(backward)
+        return out
+
+    def _head_fused_ok(self, xin, pk, cout, conv, x, attrs, och):
+        """Does the library write this head in its final layout from the GEMM epilogue (ConvGemmParams.head_attrs)?"""
+        if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or attrs < 7:
+            return False
+        p = S.ConvGemmParams()
+        p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = xin.ptr(), x.N, x.H, x.W, conv.in_channels, xin.ld
+        p.W, p.Nout, p.wtaps = pk["wf"].data_ptr(), cout, 1
+        p.OH, p.OW, p.sh, p.sw = x.H, x.W, 1, 1
+        p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, x.H, x.W
+        p.nclasses = 1
+        _fill_class(p.cls[0], [(0, 0, 0)], 0, 0)
+        p.epi, p.pipe, p.head_attrs, p.head_och = S.EPI_F32_BIAS, self.rt.gemm_pipe, attrs, och
+        try:
+            hip.call("ryolo_conv_gemm_plan", p, S.I(), S.I())
+        except RuntimeError:
+            return False
+        return True
+
+    def _head_fused(self, conv, pk, x, xin, na, attrs, och, implicit_a, implicit_m, sparse):
+        """r05: the head GEMM writes [B, na, gs, gs, attrs] itself — bias, ImplicitM and the permute in its epilogue, the compact objectness
+        logits for the fused loss beside it; no row-major fp32 intermediate, no ryolo_head_finish_fwd pass.  Backward without the
+        pre-ImplicitM activations: the GEMMs run on the UNSCALED head gradient (dx through a data-gradient image that carries ImplicitM,
+        PackEntry.wd_scale; the weight gradient into a scratch G) and ryolo_head_wgrad_finish forms dW = m G, db = m s and
+        dm = rowdot(W, G) + b s  (= sum dout (x . W + b): the chain through the multiply of model/neck.py:186)."""
+        rt = self.rt
+        cout, coutp, M = conv.out_channels, pk["CoutP"], x.M
+        mptr = implicit_m.data_ptr() if implicit_m is not None else None
+        out = self.f32(x.N, na, x.H, x.W, attrs)
+        xobj = self.f32(x.N, na, x.H, x.W) if sparse else None
+        self._gemm(self.fwd, xin, xin.ptr(), pk["wf"], cout, 1, conv.in_channels, x.H, x.W, 1, [([(0, 0, 0)], 0, 0)], S.EPI_F32_BIAS,
+                   out.data_ptr(), attrs, bias=conv.bias.data_ptr(), head=(attrs, och, mptr, xobj.data_ptr() if xobj is not None else None))
+        rec = dict(out=out, dout=None, preobj=None, och=och, xobj=xobj)
+        self.heads.append(rec)
+        if self.training:
+            if implicit_m is not None and pk.get("wd_scale") is None:
+                pk["wd_scale"] = implicit_m
+                rt._pack_table = None
+            dout = self.f32(x.N, na, x.H, x.W, attrs)
+            rec["dout"] = dout
+            dpre = torch.zeros((M, coutp), dtype=BF16, device=self.adev)       # pad columns stay zero
+            self.keep.append(dpre)
+            nblk = x.N * ((x.H * x.W + 127) // 128)
+            scratch = self.f32(max((nblk + 64) * 2 * cout, ((M + 255) // 256 + 64) * max(coutp, x.C)))
+            G = s = None
+            if implicit_m is not None:
+                G = self.f32(cout, conv.in_channels, zero=True)                # (ryolo_head_wgrad_finish clears both again)
+                s = self.f32(cout, zero=True)
+
+            class _G:                      # geometry shim so dpre can be used as a gathered operand
+                N, H, W, ld = x.N, x.H, x.W, coutp
+                span_bytes = M * coutp * 2
+
+            def backward():
+                # dpre = bf16(dout) and its column sums (the bias gradient, or s with ImplicitM) in one pass over dout
+                self._call(self.bwd, "ryolo_head_finish_bwd", dout.data_ptr(), None, coutp, None, x.N, x.H, na, attrs, dpre.data_ptr(), coutp,
+                           s.data_ptr() if s is not None else rt.grad_ptr(conv.bias), None, scratch.data_ptr())
+                rec["dout_slot"] = len(self.bwd) - 1
+                self._wgrad(conv, _G, dpre.data_ptr(), coutp, xin, dW=G.data_ptr() if G is not None else None)
+                self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, x)
+                if implicit_m is not None:
+                    self._call(self.bwd, "ryolo_head_wgrad_finish", G.data_ptr(), s.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
+                               mptr, cout, conv.in_channels, rt.grad_ptr(conv.weight), rt.grad_ptr(conv.bias), rt.grad_ptr(implicit_m))
+                    if self.rt.wgrad_stream:
+                        self.side_idx.add(len(self.bwd) - 1)       # behind its weight gradient on the side stream
                 if implicit_a is not None:
                     self._call(self.bwd, "ryolo_colsum_bf16", x.gptr(), x.ld, M, x.C, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
             self._pending_bwd.append(backward)

@@ -51,6 +51,7 @@ class Runtime:
         self.stem_recompute = os.environ.get("RYOLO_STEM_RECOMPUTE", "1") != "0"
         # narrow stride-2 data gradients (<= 32 input channels: the second conv of yolov4 / yolov7) as one space-to-depth GEMM
         self.s2d_dgrad = os.environ.get("RYOLO_S2D_DGRAD", "1") != "0"
+        self.s2d_dgrad_maxc = int(os.environ.get("RYOLO_S2D_DGRAD_MAXC", "32"))     # widest input of a stride-2 3x3 layer that takes this form
         # MaxConv (model/utils.py:146-160): the MaxPool2d(2, 2) gradient is added inside the store of the sibling 1x1 conv's data
         # gradient (same input tensor) instead of a read-modify-write pass over the full-resolution gradient
         self.fuse_pool_grad = os.environ.get("RYOLO_FUSE_POOL_GRAD", "1") != "0"
@@ -203,6 +204,7 @@ class Runtime:
                 e.wd = pk["wd"].data_ptr() if pk["wd"] is not None else None
                 e.Cout, e.Cin, e.taps, e.CinP, e.CoutP, e.start = pk["Cout"], pk["Cin"], pk["taps"], pk["CinP"], pk["CoutP"], start
                 e.ldWd = pk.get("ldWd", 0)
+                e.wd_scale = pk["wd_scale"].data_ptr() if pk.get("wd_scale") is not None else None
                 if pk["CinP"] != pk["Cin"]:
                     start += (pk["Cout"] * pk["CinP"] + 255) // 256          # stem: 256-element tiles
                 else:

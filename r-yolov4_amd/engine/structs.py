@@ -27,7 +27,7 @@ class ConvGemmParams(C.Structure):
                 ("W", P), ("Nout", I), ("wtaps", I), ("OH", I), ("OW", I), ("sh", I), ("sw", I),
                 ("oh_mul", I), ("ow_mul", I), ("OHf", I), ("OWf", I), ("nclasses", I), ("cls", TapClass * 4),
                 ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint),
-                ("pool_idx", P), ("pool_dz", P), ("pool_ldi", I), ("pool_ld", I), ("s2d_cin", I), ("nbstat", I), ("bstat", BwdStat * MAX_BSTAT)]
+                ("pool_idx", P), ("pool_dz", P), ("pool_ldi", I), ("pool_ld", I), ("s2d_cin", I), ("nbstat", I), ("bstat", BwdStat * MAX_BSTAT), ("head_attrs", I), ("head_och", I)]
 
 
 class WgradParams(C.Structure):
@@ -71,7 +71,7 @@ class UpParams(C.Structure):
 
 class PackEntry(C.Structure):
     _fields_ = [("src", P), ("wf", P), ("wd", P), ("Cout", I), ("Cin", I), ("taps", I), ("CinP", I), ("CoutP", I), ("ldWd", I),
-                ("start", L)]
+                ("start", L), ("wd_scale", P)]
 
 
 class LossParams(C.Structure):
@@ -111,6 +111,7 @@ for _name, _sig in {
     "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P, P],
     "ryolo_head_finish_bwd_sparse": [P, P, P, I, P, P, I, P, I, I, I, I, P, I, P, P, P, P],
     "ryolo_head_finish_fwd_obj": [P, I, P, I, I, I, I, P, I, P, P, P],
+    "ryolo_head_wgrad_finish": [P, P, P, P, P, I, I, P, P, P, P],
     "ryolo_chan_add": [P, I, P, L, I, P, I, P],
     "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],

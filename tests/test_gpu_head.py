@@ -118,3 +118,106 @@ def test_head_finish_backward_sparse_rejects_bad_arguments():
                  t.data_ptr(), hip.stream())
     with pytest.raises(RuntimeError):
         hip.call("ryolo_head_finish_fwd_obj", t.data_ptr(), 32, None, 1, 1, 1, 8, t.data_ptr(), 8, t.data_ptr(), None, hip.stream())   # och outside the row
+
+
+def _head_gemm(x, w, bias, mul, B, gs, na, attrs, och, fused, xobj=None):
+    """The detection head's 1x1 GEMM through ryolo_conv_gemm: row-major fp32 [M][ldC] + ryolo_head_finish_fwd (the r01-r04 form), or the
+    final layout from the GEMM's own epilogue (ConvGemmParams.head_attrs)."""
+    M, Cin, C = B * gs * gs, x.shape[1], na * attrs
+    ldp = (C + 31) // 32 * 32
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    p = S.ConvGemmParams()
+    p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = x.data_ptr(), B, gs, gs, Cin, Cin
+    p.W, p.Nout, p.wtaps = w.data_ptr(), C, 1
+    p.OH, p.OW, p.sh, p.sw = gs, gs, 1, 1
+    p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, gs, gs
+    p.nclasses = 1
+    p.cls[0].ntaps = 1
+    p.epi, p.bias = S.EPI_F32_BIAS, bias.data_ptr()
+    p.zeros, p.pipe = zeros.data_ptr(), 0x301
+    out = torch.full((B, na, gs, gs, attrs), float("nan"), device=DEV)
+    if fused:
+        p.out, p.ldC = out.data_ptr(), attrs
+        p.head_attrs, p.head_och = attrs, och
+        p.scale = mul.data_ptr() if mul is not None else None
+        p.stats = xobj.data_ptr() if xobj is not None else None
+        hip.call("ryolo_conv_gemm", p, hip.stream())
+    else:
+        pre = torch.zeros(M, ldp, device=DEV)
+        p.out, p.ldC = pre.data_ptr(), ldp
+        hip.call("ryolo_conv_gemm", p, hip.stream())
+        hip.call("ryolo_head_finish_fwd", pre.data_ptr(), ldp, mul.data_ptr() if mul is not None else None, B, gs, na, attrs, out.data_ptr(), hip.stream())
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("B,gs,na,attrs,och,Cin,with_mul", [(2, 25, 18, 22, 5, 256, True), (3, 13, 18, 8, 5, 64, False), (2, 10, 3, 201, 4, 128, True),
+                                                            (1, 50, 18, 22, 5, 512, True), (2, 7, 18, 7, 5, 32, True), (1, 20, 3, 187, 4, 1024, False)])
+def test_head_gemm_writes_the_final_layout_bit_identically(B, gs, na, attrs, och, Cin, with_mul):
+    """ConvGemmParams.head_attrs: bias, ImplicitM and the [B, na, gs, gs, attrs] permute in the epilogue of the head's GEMM.  Same accumulators, same
+    two fp32 operations per element as the row-major GEMM + ryolo_head_finish_fwd: equal bit for bit; the compact objectness logits equal the
+    map's column.  Shapes: ragged last M tile, quads that straddle an anchor boundary (attrs = 22, 7, 201, 187 are not multiples of 4), a last
+    N tile that is mostly masked (C = 396, 144, 603, 126, 561)."""
+    g = torch.Generator().manual_seed(B * 131 + gs)
+    M, C = B * gs * gs, na * attrs
+    x = torch.randn(M, Cin, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(C, Cin, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    mul = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV) if with_mul else None
+    ref = _head_gemm(x, w, bias, mul, B, gs, na, attrs, och, fused=False)
+    xobj = torch.full((B, na, gs, gs), float("nan"), device=DEV)
+    got = _head_gemm(x, w, bias, mul, B, gs, na, attrs, och, fused=True, xobj=xobj)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)
+    assert torch.equal(xobj, ref[..., och])
+    # and against plain torch (fp32 accumulate of the same bf16 operands)
+    t = (x.float() @ w.float().t() + bias)
+    if with_mul:
+        t = t * mul
+    torch.testing.assert_close(got, t.view(B, gs, gs, na, attrs).permute(0, 3, 1, 2, 4).contiguous(), rtol=2e-4, atol=2e-3)
+    got2 = _head_gemm(x, w, bias, mul, B, gs, na, attrs, och, fused=True)             # (the compact copy is optional)
+    assert torch.equal(got2, ref)
+
+
+def test_head_gemm_final_layout_rejects_what_it_cannot_run():
+    x = torch.zeros(64, 32, dtype=torch.bfloat16, device=DEV)
+    p = S.ConvGemmParams()
+    p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = x.data_ptr(), 1, 8, 8, 32, 32
+    p.W, p.Nout, p.wtaps = x.data_ptr(), 24, 1
+    p.OH, p.OW, p.sh, p.sw = 8, 8, 1, 1
+    p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, 8, 8
+    p.nclasses = 1
+    p.cls[0].ntaps = 1
+    p.epi, p.out, p.zeros, p.pipe = S.EPI_F32_BIAS, x.data_ptr(), x.data_ptr(), 0x301
+    p.head_attrs, p.head_och = 8, 5
+    rows, kern = S.I(), S.I()
+    hip.call("ryolo_conv_gemm_plan", p, rows, kern)                       # fine
+    p.pipe = 0x300                                                        # register-staged mainloop: no 1x1 instantiation
+    with pytest.raises(RuntimeError, match="unsupported|UNSUPPORTED|-"):
+        hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+    p.pipe, p.head_attrs = 0x301, 5                                       # 24 columns are not whole rows of 5; rows shorter than 7
+    with pytest.raises(RuntimeError):
+        hip.call("ryolo_conv_gemm", p, hip.stream())
+
+
+@pytest.mark.parametrize("Cout,K,with_bias", [(396, 256, True), (54, 1024, True), (24, 32, False)])
+def test_head_wgrad_finish(Cout, K, with_bias):
+    """dW += m G, db += m s, dm += rowdot(W, G) + b s, G and s cleared (ryolo_head_wgrad_finish) against torch in double."""
+    g = torch.Generator().manual_seed(Cout + K)
+    G = torch.randn(Cout, K, generator=g).to(DEV)
+    s = torch.randn(Cout, generator=g).to(DEV)
+    W = torch.randn(Cout, K, generator=g).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    m = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    dW = torch.randn(Cout, K, generator=g).to(DEV)
+    db = torch.randn(Cout, generator=g).to(DEV)
+    dm = torch.randn(Cout, generator=g).to(DEV)
+    e_dW = dW.double() + m.double()[:, None] * G.double()
+    e_db = db.double() + m.double() * s.double()
+    e_dm = dm.double() + (W.double() * G.double()).sum(1) + (b.double() * s.double() if with_bias else 0)
+    hip.call("ryolo_head_wgrad_finish", G.data_ptr(), s.data_ptr(), W.data_ptr(), b.data_ptr() if with_bias else None, m.data_ptr(), Cout, K,
+             dW.data_ptr(), db.data_ptr(), dm.data_ptr(), hip.stream())
+    torch.testing.assert_close(dW.double(), e_dW, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(db.double(), e_db, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(dm.double(), e_dm, rtol=1e-5, atol=1e-4)
+    assert not G.abs().any() and not s.abs().any()

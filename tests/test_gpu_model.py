@@ -467,6 +467,12 @@ def test_compact_head_gradient_handoff_is_bit_identical_and_used(ver, mode, scal
         items.append((float(loss), list(crit._used_head_obj)))
         names.append(sorted({n for _f, _a, n in _last_plan(net).bwd if n.startswith("ryolo_head_finish_bwd")}))
     assert names[0] == ["ryolo_head_finish_bwd_sparse"] and names[1] == ["ryolo_head_finish_bwd"], names
+    # r05 default: the head GEMM writes the final layout itself (no finish pass in the forward tape); ImplicitM heads finish their parameter
+    # gradients behind the weight gradient
+    fwd_names = [n for _f, _a, n in _last_plan(net).fwd]
+    bwd_names = [n for _f, _a, n in _last_plan(net).bwd]
+    assert not any(n.startswith("ryolo_head_finish_fwd") for n in fwd_names)
+    assert bwd_names.count("ryolo_head_wgrad_finish") == (3 if ver == "yolov7" else 0)
     assert flat[0].abs().sum() > 0 and torch.isfinite(flat[0]).all()
     assert torch.equal(flat[0], flat[1])
     assert torch.equal(flat[0], flat[2])

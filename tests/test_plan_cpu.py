@@ -111,8 +111,10 @@ def test_stream_plan_of_yolov7(training):
         assert first or ((i - 1) in g.fwd_side and g.fwd_side[i - 1][1] == lane)
     if training:
         names = [n for _, _, n in g.bwd]
-        assert g.side_idx and all(names[i] == "ryolo_conv_wgrad" for i in g.side_idx)
-        assert len(g.side_idx) == names.count("ryolo_conv_wgrad")          # yolov7's stem runs the direct kernel: every conv_wgrad is regular
+        # side stream: the weight gradients and, behind the three detection heads' ones, the pass that finishes their ImplicitM chain rule
+        assert g.side_idx and all(names[i] in ("ryolo_conv_wgrad", "ryolo_head_wgrad_finish") for i in g.side_idx)
+        assert names.count("ryolo_head_wgrad_finish") in (0, 3)
+        assert len(g.side_idx) == names.count("ryolo_conv_wgrad") + names.count("ryolo_head_wgrad_finish")   # yolov7's stem runs the direct kernel: every conv_wgrad is regular
     else:
         assert not g.side_idx
 
