@@ -335,6 +335,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     BsLane bsl;
     if constexpr (BS) bs_lane_init(p, ncol, bsl);
+    // inference: the folded BatchNorm coefficients of the tile's BN columns, once per workgroup into LDS behind the staging rows (inside the dead
+    // patch buffers) instead of two 16-byte global loads per staged quad
+    float* const cscale = reinterpret_cast<float*>(p3_lds + 4 * 64 * EP_LD * 2);
+    float* const cshift = cscale + BN;
+    if constexpr (EPI == EPI_AFFINE_ACT) {
+        if (tid < BN) {
+            const int n = n0 + tid;
+            cscale[tid] = n < p.Nout ? p.scale[n] : 0.f;
+            cshift[tid] = n < p.Nout ? p.shift[n] : 0.f;
+        }
+        __syncthreads();
+    }
     // accumulate epilogue: the old values of the WHOLE tile are requested here, in front of the staging writes — one memory round trip per
     // workgroup, most of it under the staging of the first half (requested per group of 4 rows inside the store loop it was four round trips:
     // 12 k of the epilogue's 13.8 k cycles)
@@ -365,15 +377,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
                     for (int q = 0; q < 4; q++) v[q] = acc[i][j][4 * g4 + q];
                     if constexpr (EPI == EPI_AFFINE_ACT) {
-                        const int n = n0 + wn * WTN + c0;
-                        if (n < p.Nout) {
-                            const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-                            const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
-                            v[0] = act_fwd(v[0] * sc.x + sh.x, p.act);
-                            v[1] = act_fwd(v[1] * sc.y + sh.y, p.act);
-                            v[2] = act_fwd(v[2] * sc.z + sh.z, p.act);
-                            v[3] = act_fwd(v[3] * sc.w + sh.w, p.act);
-                        }
+                        const float4 sc = *reinterpret_cast<const float4*>(cscale + wn * WTN + c0);     // (columns >= Nout are never stored)
+                        const float4 sh = *reinterpret_cast<const float4*>(cshift + wn * WTN + c0);
+                        v[0] = act_fwd(v[0] * sc.x + sh.x, p.act);
+                        v[1] = act_fwd(v[1] * sc.y + sh.y, p.act);
+                        v[2] = act_fwd(v[2] * sc.z + sh.z, p.act);
+                        v[3] = act_fwd(v[3] * sc.w + sh.w, p.act);
                     }
                     const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     *reinterpret_cast<uint2*>(stage + (ii * 32 + (lane & 31)) * EP_LD + c0) = w;
