@@ -219,11 +219,14 @@ int ryolo_head_finish_bwd_sparse(const float* dout, const float* objgrad, const 
  * out (after ImplicitM) — LossParams.headobj */
 int ryolo_head_finish_fwd_obj(const float* pre, int ldp, const float* mul, int B, int gs, int na, int attrs, float* out, int och, float* preobj,
                               float* xobj, ryolo_stream_t stream);
-/* parameter gradients of a detection head whose ImplicitM is applied by the GEMM epilogue (ConvGemmParams.head_attrs): G [Cout][K] = weight gradient
- * of the UNSCALED head gradient, s [Cout] = its column sums; dW += m G, db += m s, dm += rowdot(W, G) + b s; G and s are cleared.
- * (model/neck.py:173-186 ImplicitM; autograd's chain through the multiply) */
-int ryolo_head_wgrad_finish(float* G, float* s, const float* W, const float* b, const float* m, int Cout, int K, float* dW, float* db, float* dm,
-                            ryolo_stream_t stream);
+/* parameter gradients of a detection head whose ImplicitM is applied by the GEMM epilogue (ConvGemmParams.head_attrs), out = (W (x + a) + b) m:
+ * G [Cout][K] = weight gradient of the UNSCALED head gradient against x, s [Cout] = its column sums, a = ImplicitA [K] or null;
+ * Ge = G + s (x) a; dW += m Ge, db += m s, dm += rowdot(W, Ge) + b s, da += W^T (m s); G and s are cleared.
+ * (model/neck.py:173-186 ImplicitA / ImplicitM; autograd's chain through the add and the multiply) */
+int ryolo_head_wgrad_finish(float* G, float* s, const float* W, const float* b, const float* m, const float* a, int Cout, int K, float* dW, float* db,
+                            float* dm, float* da, ryolo_stream_t stream);
+/* out[c] = b[c] + sum_k W[c][k] a[k]: the bias of a head with ImplicitA folded in (W (x + a) + b = W x + out) */
+int ryolo_head_bias_fold(const float* W, const float* b, const float* a, int Cout, int K, float* out, ryolo_stream_t stream);
 int ryolo_chan_add(const bf16_t* x, int ldx, const float* a, int64_t M, int C, bf16_t* z, int ldz, ryolo_stream_t stream);  /* ImplicitA */
 /* out[c] += sum_m x[m][c] for c < Cvalid; C = readable (padded, multiple of 8) width; scratch >= (ceil(M/256) + 64)*C floats */
 int ryolo_colsum_bf16(const bf16_t* x, int ldx, int64_t M, int C, int Cvalid, float* out, float* scratch, ryolo_stream_t stream);

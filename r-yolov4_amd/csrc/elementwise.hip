@@ -1698,21 +1698,35 @@ extern "C" int ryolo_head_finish_bwd_sparse(const float* dout, const float* objg
     return head_finish_bwd_impl(dout, pre, ldp, mul, B, gs, na, attrs, dpre, ldd, dbias, dmul, scratch, objgrad, owner, och, preobj, stream);
 }
 
-// Detection head with ImplicitM written by the GEMM epilogue (ConvGemmParams.head_attrs): out = (x . W + b) * m.  Its backward runs the weight-
-// gradient GEMM on the UNSCALED head gradient, G[c][k] = sum_rows dout[., c] x[., k] (s[c] = sum_rows dout[., c] for the bias), and this pass
-// finishes the three parameter gradients from G without the pre-ImplicitM activations:
-//   dW[c][k] += m[c] G[c][k]     db[c] += m[c] s[c]     dm[c] += sum_k W[c][k] G[c][k] + b[c] s[c]   (= sum_rows dout (x . W + b))
-// and clears G and s for the next step.  One workgroup per output channel.
+// Detection head with ImplicitM written by the GEMM epilogue (ConvGemmParams.head_attrs): out = (W (x + a) + b) * m  (a = ImplicitA or absent).
+// Its backward runs the weight-gradient GEMM on the UNSCALED head gradient and the layer's input x (NOT x + a), G[c][k] = sum_rows dout[., c] x[., k]
+// (s[c] = sum_rows dout[., c] for the bias), and this pass finishes the parameter gradients from G without the pre-ImplicitM activations and without
+// a pass over the input gradient:
+//   Ge = G + s (x) a        (the weight gradient against x + a: a is the same for every row)
+//   dW[c][k] += m[c] Ge[c][k]     db[c] += m[c] s[c]     dm[c] += sum_k W[c][k] Ge[c][k] + b[c] s[c]   (= sum_rows dout (W (x + a) + b))
+//   da[k]    += sum_c m[c] s[c] W[c][k]                  (= column sums of the input gradient: dx = (dout * m) W)
+// and clears G and s for the next step.  One workgroup per output channel; da by a launch of its own in front (fixed summation order).
+__global__ __launch_bounds__(256) void head_da_kernel(const float* __restrict__ s, const float* __restrict__ W, const float* __restrict__ m, int Cout, int K,
+                                                      float* __restrict__ da)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int c = 0; c < Cout; c++) acc = fmaf(m[c] * s[c], W[(int64_t)c * K + k], acc);
+    da[k] += acc;
+}
+
 __global__ __launch_bounds__(256) void head_wgrad_finish_kernel(float* __restrict__ G, float* __restrict__ s, const float* __restrict__ W,
-                                                                const float* __restrict__ b, const float* __restrict__ m, int K,
-                                                                float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dm)
+                                                                const float* __restrict__ b, const float* __restrict__ m, const float* __restrict__ a,
+                                                                int K, float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dm)
 {
     __shared__ float red[4];
     const int c = blockIdx.x;
-    const float mc = m[c];
+    const float mc = m[c], sc = s[c];
     float dot = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
-        const float g = G[(int64_t)c * K + k];
+        float g = G[(int64_t)c * K + k];
+        if (a) g = fmaf(sc, a[k], g);
         dW[(int64_t)c * K + k] += mc * g;
         dot = fmaf(W[(int64_t)c * K + k], g, dot);
         G[(int64_t)c * K + k] = 0.f;
@@ -1721,18 +1735,41 @@ __global__ __launch_bounds__(256) void head_wgrad_finish_kernel(float* __restric
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float sc = s[c];
         if (db) db[c] += mc * sc;
         dm[c] += (red[0] + red[1]) + (red[2] + red[3]) + (b ? b[c] * sc : 0.f);
         s[c] = 0.f;
     }
 }
 
-extern "C" int ryolo_head_wgrad_finish(float* G, float* s, const float* W, const float* b, const float* m, int Cout, int K, float* dW, float* db,
-                                       float* dm, hipStream_t stream)
+extern "C" int ryolo_head_wgrad_finish(float* G, float* s, const float* W, const float* b, const float* m, const float* a, int Cout, int K, float* dW,
+                                       float* db, float* dm, float* da, hipStream_t stream)
 {
-    if (!G || !s || !W || !m || !dW || !dm || Cout <= 0 || K <= 0) return RY_ERR_ARG;
-    hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(Cout), dim3(256), 0, stream, G, s, W, b, m, K, dW, db, dm);
+    if (!G || !s || !W || !m || !dW || !dm || Cout <= 0 || K <= 0 || (a && !da)) return RY_ERR_ARG;
+    if (a) hipLaunchKernelGGL(head_da_kernel, dim3((unsigned)ry_cdiv(K, 256)), dim3(256), 0, stream, s, W, m, Cout, K, da);
+    hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(Cout), dim3(256), 0, stream, G, s, W, b, m, a, K, dW, db, dm);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+// bias of a detection head whose ImplicitA (model/neck.py:173-179: x + a in front of the 1x1 convolution) is folded into it: W (x + a) + b =
+// W x + (b + W a) — out[c] = b[c] + sum_k W[c][k] a[k]; one workgroup per output channel.  Replaces the pass that wrote x + a.
+__global__ __launch_bounds__(256) void head_bias_fold_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ a, int K,
+                                                             float* __restrict__ out)
+{
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) dot = fmaf(W[(int64_t)c * K + k], a[k], dot);
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (b ? b[c] : 0.f) + (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int ryolo_head_bias_fold(const float* W, const float* b, const float* a, int Cout, int K, float* out, hipStream_t stream)
+{
+    if (!W || !a || !out || Cout <= 0 || K <= 0) return RY_ERR_ARG;
+    hipLaunchKernelGGL(head_bias_fold_kernel, dim3(Cout), dim3(256), 0, stream, W, b, a, K, out);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

@@ -24,6 +24,7 @@ BF16 = torch.bfloat16
 
 _HEAD_SPARSE = os.environ.get("RYOLO_HEAD_SPARSE", "1") != "0"
 _HEAD_FUSED = os.environ.get("RYOLO_HEAD_FUSED", "1") != "0"
+_HEAD_FOLD_A = os.environ.get("RYOLO_HEAD_FOLD_A", "1") != "0"
 _DEBUG_SKIP_SIDE = os.environ.get("RYOLO_DEBUG_SKIP_SIDE") == "1"     # tools only: never set in a run that reports numbers
 
 class Buf:
@@ -1015,15 +1016,19 @@ class Graph:
         pk = rt.packed(conv)
         cout, coutp = conv.out_channels, pk["CoutP"]
         assert cout == na * attrs
+        och = 4 if getattr(rt.model, "mode", None) == "csl" else 5         # objectness element of a head row (lib/loss.py:216, :411)
+        mptr = implicit_m.data_ptr() if implicit_m is not None else None
+        sparse = self.training and _HEAD_SPARSE
+        fused = _HEAD_FUSED and rt.wgrad_lanes <= 1 and self._head_fused_ok(x, pk, cout, conv, x, attrs, och)
+        if fused and implicit_a is not None and implicit_m is not None and _HEAD_FOLD_A:
+            # ImplicitA rides in the bias (W (x + a) + b = W x + (b + W a)): no x + a tensor, and its gradient comes out of ryolo_head_wgrad_finish
+            return self._head_fused(conv, pk, x, x, na, attrs, och, implicit_a, implicit_m, sparse, fold_a=True)
         xin = x
         if implicit_a is not None:
             xin = self.new(x.N, x.H, x.W, x.C)
             self._call(self.fwd, "ryolo_chan_add", x.ptr(), x.ld, implicit_a.data_ptr(), x.M, x.C, xin.ptr(), xin.ld)
         M = x.M
-        och = 4 if getattr(rt.model, "mode", None) == "csl" else 5         # objectness element of a head row (lib/loss.py:216, :411)
-        mptr = implicit_m.data_ptr() if implicit_m is not None else None
-        sparse = self.training and _HEAD_SPARSE
-        if _HEAD_FUSED and rt.wgrad_lanes <= 1 and self._head_fused_ok(xin, pk, cout, conv, x, attrs, och):
+        if fused:
             return self._head_fused(conv, pk, x, xin, na, attrs, och, implicit_a, implicit_m, sparse)
         assert pk.get("wd_scale") is None, "head planned both with and without the ImplicitM-carrying data-gradient image"
         pre = self.f32(M, coutp)
@@ -1087,7 +1092,7 @@ class Graph:
             return False
         return True
 
-    def _head_fused(self, conv, pk, x, xin, na, attrs, och, implicit_a, implicit_m, sparse):
+    def _head_fused(self, conv, pk, x, xin, na, attrs, och, implicit_a, implicit_m, sparse, fold_a=False):
         """r05: the head GEMM writes [B, na, gs, gs, attrs] itself — bias, ImplicitM and the permute in its epilogue, the compact objectness
         logits for the fused loss beside it; no row-major fp32 intermediate, no ryolo_head_finish_fwd pass.  Backward without the
         pre-ImplicitM activations: the GEMMs run on the UNSCALED head gradient (dx through a data-gradient image that carries ImplicitM,
@@ -1098,8 +1103,14 @@ class Graph:
         mptr = implicit_m.data_ptr() if implicit_m is not None else None
         out = self.f32(x.N, na, x.H, x.W, attrs)
         xobj = self.f32(x.N, na, x.H, x.W) if sparse else None
+        aptr = implicit_a.data_ptr() if fold_a else None
+        bias_ptr = conv.bias.data_ptr()
+        if fold_a:
+            fbias = self.f32(cout)
+            self._call(self.fwd, "ryolo_head_bias_fold", conv.weight.data_ptr(), conv.bias.data_ptr(), aptr, cout, conv.in_channels, fbias.data_ptr())
+            bias_ptr = fbias.data_ptr()
         self._gemm(self.fwd, xin, xin.ptr(), pk["wf"], cout, 1, conv.in_channels, x.H, x.W, 1, [([(0, 0, 0)], 0, 0)], S.EPI_F32_BIAS,
-                   out.data_ptr(), attrs, bias=conv.bias.data_ptr(), head=(attrs, och, mptr, xobj.data_ptr() if xobj is not None else None))
+                   out.data_ptr(), attrs, bias=bias_ptr, head=(attrs, och, mptr, xobj.data_ptr() if xobj is not None else None))
         rec = dict(out=out, dout=None, preobj=None, och=och, xobj=xobj)
         self.heads.append(rec)
         if self.training:
@@ -1130,10 +1141,11 @@ class Graph:
                 self._dgrad(conv, pk, _G, dpre.data_ptr(), coutp, x)
                 if implicit_m is not None:
                     self._call(self.bwd, "ryolo_head_wgrad_finish", G.data_ptr(), s.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
-                               mptr, cout, conv.in_channels, rt.grad_ptr(conv.weight), rt.grad_ptr(conv.bias), rt.grad_ptr(implicit_m))
+                               mptr, aptr, cout, conv.in_channels, rt.grad_ptr(conv.weight), rt.grad_ptr(conv.bias), rt.grad_ptr(implicit_m),
+                               rt.grad_ptr(implicit_a) if fold_a else None)
                     if self.rt.wgrad_stream:
                         self.side_idx.add(len(self.bwd) - 1)       # behind its weight gradient on the side stream
-                if implicit_a is not None:
+                if implicit_a is not None and not fold_a:
                     self._call(self.bwd, "ryolo_colsum_bf16", x.gptr(), x.ld, M, x.C, x.C, rt.grad_ptr(implicit_a), scratch.data_ptr())
             self._pending_bwd.append(backward)
         return out

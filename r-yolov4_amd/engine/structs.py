@@ -111,7 +111,8 @@ for _name, _sig in {
     "ryolo_head_finish_bwd": [P, P, I, P, I, I, I, I, P, I, P, P, P, P],
     "ryolo_head_finish_bwd_sparse": [P, P, P, I, P, P, I, P, I, I, I, I, P, I, P, P, P, P],
     "ryolo_head_finish_fwd_obj": [P, I, P, I, I, I, I, P, I, P, P, P],
-    "ryolo_head_wgrad_finish": [P, P, P, P, P, I, I, P, P, P, P],
+    "ryolo_head_wgrad_finish": [P, P, P, P, P, P, I, I, P, P, P, P, P],
+    "ryolo_head_bias_fold": [P, P, P, I, I, P, P],
     "ryolo_chan_add": [P, I, P, L, I, P, I, P],
     "ryolo_colsum_bf16": [P, I, L, I, I, P, P, P],
     "ryolo_pack_weights": [P, I, L, P],

@@ -200,24 +200,37 @@ def test_head_gemm_final_layout_rejects_what_it_cannot_run():
         hip.call("ryolo_conv_gemm", p, hip.stream())
 
 
-@pytest.mark.parametrize("Cout,K,with_bias", [(396, 256, True), (54, 1024, True), (24, 32, False)])
-def test_head_wgrad_finish(Cout, K, with_bias):
-    """dW += m G, db += m s, dm += rowdot(W, G) + b s, G and s cleared (ryolo_head_wgrad_finish) against torch in double."""
+@pytest.mark.parametrize("Cout,K,with_bias,with_a", [(396, 256, True, True), (54, 1024, True, False), (24, 32, False, True)])
+def test_head_wgrad_finish(Cout, K, with_bias, with_a):
+    """Ge = G + s (x) a; dW += m Ge, db += m s, dm += rowdot(W, Ge) + b s, da += W^T (m s); G and s cleared (ryolo_head_wgrad_finish) against
+    torch in double; and the folded bias b + W a (ryolo_head_bias_fold)."""
     g = torch.Generator().manual_seed(Cout + K)
     G = torch.randn(Cout, K, generator=g).to(DEV)
     s = torch.randn(Cout, generator=g).to(DEV)
     W = torch.randn(Cout, K, generator=g).to(DEV)
     b = torch.randn(Cout, generator=g).to(DEV)
     m = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    a = (0.1 * torch.randn(K, generator=g)).to(DEV)
     dW = torch.randn(Cout, K, generator=g).to(DEV)
     db = torch.randn(Cout, generator=g).to(DEV)
     dm = torch.randn(Cout, generator=g).to(DEV)
-    e_dW = dW.double() + m.double()[:, None] * G.double()
+    da = torch.randn(K, generator=g).to(DEV)
+    Ge = G.double() + (s.double()[:, None] * a.double()[None, :] if with_a else 0)
+    e_dW = dW.double() + m.double()[:, None] * Ge
     e_db = db.double() + m.double() * s.double()
-    e_dm = dm.double() + (W.double() * G.double()).sum(1) + (b.double() * s.double() if with_bias else 0)
-    hip.call("ryolo_head_wgrad_finish", G.data_ptr(), s.data_ptr(), W.data_ptr(), b.data_ptr() if with_bias else None, m.data_ptr(), Cout, K,
-             dW.data_ptr(), db.data_ptr(), dm.data_ptr(), hip.stream())
+    e_dm = dm.double() + (W.double() * Ge).sum(1) + (b.double() * s.double() if with_bias else 0)
+    e_da = da.double() + W.double().t() @ (m.double() * s.double())
+    da0 = da.clone()
+    fb = torch.empty(Cout, device=DEV)
+    hip.call("ryolo_head_bias_fold", W.data_ptr(), b.data_ptr() if with_bias else None, a.data_ptr(), Cout, K, fb.data_ptr(), hip.stream())
+    torch.testing.assert_close(fb.double(), (b.double() if with_bias else 0) + W.double() @ a.double(), rtol=1e-5, atol=1e-5)
+    hip.call("ryolo_head_wgrad_finish", G.data_ptr(), s.data_ptr(), W.data_ptr(), b.data_ptr() if with_bias else None, m.data_ptr(),
+             a.data_ptr() if with_a else None, Cout, K, dW.data_ptr(), db.data_ptr(), dm.data_ptr(), da.data_ptr() if with_a else None, hip.stream())
     torch.testing.assert_close(dW.double(), e_dW, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(db.double(), e_db, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(dm.double(), e_dm, rtol=1e-5, atol=1e-4)
+    if with_a:
+        torch.testing.assert_close(da.double(), e_da, rtol=1e-5, atol=1e-4)
+    else:
+        assert torch.equal(da, da0)
     assert not G.abs().any() and not s.abs().any()
