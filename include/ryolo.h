@@ -292,6 +292,11 @@ int ryolo_loss_owner_grids(const LossParams* p, const int** owner);
 /* autograd chain rule of the loss node (lib/loss.py:256,414 return a [1] tensor; `loss.backward()` hands back d(out)/d(loss) as a
  * device scalar): grad[0..n) *= *scale, skipped ON THE DEVICE when *scale == 1.0f (the usual case) — no host read, capturable */
 int ryolo_loss_grad_scale(float* grad, int64_t n, const float* scale, ryolo_stream_t stream);
+/* the same for count <= 8 arrays (host arrays of device pointers / lengths) in ONE launch: the three maps and their compact objectness copies */
+int ryolo_loss_grad_scale_multi(float* const* grads, const int64_t* n, int count, const float* scale, ryolo_stream_t stream);
+/* match counters / records of the last ryolo_loss call with THESE params: count[i] -> one int, rec[i] -> [count][8] ints (b, a, gj, gi, cls, target
+ * row, cell, pad) in the reference's enumeration order (lib/loss.py:275-310, :432-471); for tests of the target assignment */
+int ryolo_loss_match_records(const LossParams* p, const int** count, const int** rec);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Data side (SURVEY.md §8(f) N2 slice, N4): the batch-finalisation end of BaseDataset.__getitem__ + collate_fn and the box

@@ -14,8 +14,8 @@
 //   K2 loss_match_kernel     one wavefront per match: the class / 180-bin CSL BCE with wave64 shuffle reductions, partial sums;
 //   K2b loss_match_grad_kernel  the owner of every matched cell sums the gradient terms of the cell's matches in ascending match
 //                            order (what autograd's index_put_(accumulate=True) does, in a FIXED order) and stores them;
-//   K3 loss_tconf_kernel     owners scatter their IoU score into the objectness target grid;
-//   K4 loss_obj_kernel       objectness BCE over every cell (the only HBM-heavy pass: one strided logit per cell);
+//   K4 loss_obj_kernel       objectness BCE over every cell against the owner's IoU score (the only HBM-heavy pass: one logit per cell — from the
+//                            engine's compact copy, LossParams.headobj, else strided out of the map — and the definition of the gradient map);
 //   K5 loss_finalize_kernel  fixed-order sums -> the five loss items, already scaled (lib/loss.py:251-255, :410-413).
 // Compiled with -ffp-contract=off so the float comparisons of target assignment match torch-CPU bit for bit.
 #include "common.h"
@@ -30,8 +30,7 @@ struct ScaleWs {
     int* count;               // [1]
     int* rec;                 // [cap][8]: b, a, gj, gi, cls, tidx, cell, pad
     float* frec;              // [cap][8]: tbox[0..4], score, pad, pad
-    int* owner;               // [cells]
-    float* tconf;             // [cells]
+    int* owner;               // [cells]: largest match index of the cell (last writer wins), -1: no match
     float* part_match;        // [nblk_match][4]: reg_a, reg_b, cls, theta
     float* part_obj;          // [nblk_obj]
     int* head;                // [cells]: most recently linked match of the cell (-1: none) — chains of duplicate matches
@@ -41,7 +40,11 @@ struct ScaleWs {
 };
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__host__ __device__ static inline void carve(const LossParams& p, ScaleWs* s, size_t* total)
+// Layout (r05): [count x 3 | owner x 3, head x 3 | per scale: rec, frec, part_match, part_obj, next, gbox].  Only the first region is cleared (to
+// zero) and the second filled with -1 per call — two fills instead of the seven of r02-r04, which also cleared the whole workspace (190 MB at the
+// benchmark size) although every other array is written before it is read.  (The objectness target grid `tconf` is gone: the objectness pass
+// takes the score from the owner's match record.)
+__host__ __device__ static inline void carve(const LossParams& p, ScaleWs* s, size_t* total, size_t* ff_off = nullptr, size_t* ff_bytes = nullptr)
 {
     size_t off = 0;
     char* base = reinterpret_cast<char*>(p.ws);
@@ -53,13 +56,17 @@ __host__ __device__ static inline void carve(const LossParams& p, ScaleWs* s, si
         s[i].nblk_obj = (cells + 1023) / 1024 > 2048 ? 2048 : (cells + 1023) / 1024;
         if (s[i].nblk_obj < 1) s[i].nblk_obj = 1;
         s[i].count = reinterpret_cast<int*>(base + off); off += 256;
+    }
+    if (ff_off) *ff_off = off;
+    for (int i = 0; i < 3; i++) { s[i].owner = reinterpret_cast<int*>(base + off); off += al256((size_t)s[i].cells * 4); }
+    for (int i = 0; i < 3; i++) { s[i].head = reinterpret_cast<int*>(base + off); off += al256((size_t)s[i].cells * 4); }
+    if (ff_bytes) *ff_bytes = off - 768;
+    for (int i = 0; i < 3; i++) {
+        const int cap = s[i].cap;
         s[i].rec = reinterpret_cast<int*>(base + off); off += al256((size_t)cap * 8 * 4);
         s[i].frec = reinterpret_cast<float*>(base + off); off += al256((size_t)cap * 8 * 4);
-        s[i].owner = reinterpret_cast<int*>(base + off); off += al256((size_t)cells * 4);
-        s[i].tconf = reinterpret_cast<float*>(base + off); off += al256((size_t)cells * 4);
         s[i].part_match = reinterpret_cast<float*>(base + off); off += al256((size_t)(s[i].nblk_match > 0 ? s[i].nblk_match : 1) * 4 * 4);
         s[i].part_obj = reinterpret_cast<float*>(base + off); off += al256((size_t)s[i].nblk_obj * 4);
-        s[i].head = reinterpret_cast<int*>(base + off); off += al256((size_t)cells * 4);
         s[i].next = reinterpret_cast<int*>(base + off); off += al256((size_t)cap * 4);
         s[i].gbox = reinterpret_cast<float*>(base + off); off += al256((size_t)cap * 8 * 4);
     }
@@ -333,8 +340,10 @@ __device__ void kf_dual(Dual<5> x, Dual<5> y, Dual<5> w, Dual<5> h, Dual<5> r, c
 // match (dual numbers through the CIoU / KFIoU formulas); with one WAVE per match and this block under `lane == 0` — the r02-r04 form — the 30 k
 // matches of a benchmark-size scale were 30 k single-lane waves and the kernel was bound by instruction issue (121 us per scale).  Same arithmetic
 // per match, so every record is bit-identical; reg_a / reg_b travel to K2b's partial sums through the two spare slots of the match record.
-__global__ __launch_bounds__(256) void loss_match_box_kernel(const LossParams p, ScaleWs s, int scale)
+__global__ __launch_bounds__(256) void loss_match_box_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
 {
+    const int scale = blockIdx.y;
+    const ScaleWs s = scale == 0 ? s0 : (scale == 1 ? s1 : s2);
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int n = *s.count;
     if (e >= n) return;
@@ -429,8 +438,10 @@ __global__ __launch_bounds__(256) void loss_match_box_kernel(const LossParams p,
 // K2b, class / angle-bin BCE terms: G lanes per match — 64 (a wave per match), or 16 when the classes fit (nc <= 16, no angle bins: four matches
 // per wave; the xor butterfly over 16 lanes adds the same values in the same order as the 64-lane one did, whose upper lanes held zeros) — and
 // folds the match's box terms into the partial sums: one row of part_match per FOUR consecutive matches, as before.
-__global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, ScaleWs s, int scale, int G)
+__global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2, int G)
 {
+    const int scale = blockIdx.y;
+    const ScaleWs s = scale == 0 ? s0 : (scale == 1 ? s1 : s2);
     __shared__ float blk[16][4];
     const int per = 256 / G;                                                      // matches per workgroup: 4 or 16
     const int n = *s.count;
@@ -479,8 +490,10 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossParams p, Sca
 // index) walks the chain K2 linked and adds the members in ASCENDING match order — a fixed order, so the gradient is bitwise
 // reproducible (float atomics in arrival order differed in the last bits whenever three or more targets shared a cell) — and writes
 // plain stores.  Chains are short (1 for almost every cell); the next member is found by selection (O(d^2) walks, no storage bound).
-__global__ __launch_bounds__(256) void loss_match_grad_kernel(const LossParams p, ScaleWs s, int scale)
+__global__ __launch_bounds__(256) void loss_match_grad_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
 {
+    const int scale = blockIdx.y;
+    const ScaleWs s = scale == 0 ? s0 : (scale == 1 ? s1 : s2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 4 + wave;
     const int n = *s.count;
@@ -543,17 +556,12 @@ __global__ __launch_bounds__(256) void loss_match_grad_kernel(const LossParams p
 }
 
 // ------------------------------------------------------------------------------------------------ K3 / K4
-__global__ void loss_tconf_kernel(ScaleWs s)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *s.count) return;
-    const int cell = s.rec[(int64_t)e * 8 + 6];
-    if (s.owner[cell] == e) s.tconf[cell] = s.frec[(int64_t)e * 8 + 5];          // gr = 1.0: tconf = score (lib/loss.py:221)
-}
-
-__global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, ScaleWs s, int scale)
+__global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, ScaleWs s0, ScaleWs s1, ScaleWs s2)
 {
     __shared__ float red[4];
+    const int scale = blockIdx.y;
+    const ScaleWs s = scale == 0 ? s0 : (scale == 1 ? s1 : s2);
+    if ((int)blockIdx.x >= s.nblk_obj) return;                                       // (one launch for the three scales: the grid is the largest one's)
     const int attrs = p.nc + (p.mode == 0 ? 185 : 6);
     const int och = p.mode == 0 ? 4 : 5;
     const float kg = p.obj / (float)s.cells;
@@ -565,13 +573,15 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
     // run — zeros with the objectness gradient in place — as 16-byte stores; rows of MATCHED cells (owner >= 0) keep what loss_match_grad_kernel
     // wrote before this launch, so a run that holds one takes the element-wise path.  Same cell -> thread mapping and summation order as before:
     // loss values are bit-identical.
-    for (int ib = blockIdx.x * 256; ib < s.cells; ib += gridDim.x * 256) {          // (uniform trip count: the shuffles below need every lane)
+    for (int ib = blockIdx.x * 256; ib < s.cells; ib += s.nblk_obj * 256) {         // (uniform trip count: the shuffles below need every lane)
         const int i = ib + threadIdx.x;
         const bool valid = i < s.cells;
         float g = 0.f;
+        int own = -1;
         if (valid) {
             const float x = p.headobj[scale] ? p.headobj[scale][i] : p.head[scale][(int64_t)i * attrs + och];
-            const float t = s.tconf[i];
+            own = s.owner[i];
+            const float t = own >= 0 ? s.frec[(int64_t)own * 8 + 5] : 0.f;           // gr = 1.0: tconf = the owner's score (lib/loss.py:221), else 0
             acc += fl_val(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
             if (p.compute_grad) {
                 g = kg * fl_grad(x, t, p.obj_pw, p.fl_gamma, p.fl_alpha);
@@ -582,7 +592,6 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(const LossParams p, Scale
         const int w0 = ib + (int)(threadIdx.x & ~63u);                              // first cell of this wave's run
         if (w0 >= s.cells) continue;                                                // (wave-uniform)
         const int ncell = min(64, s.cells - w0);
-        const int own = valid ? s.owner[i] : -1;
         const bool plain = __ballot(own >= 0) == 0ull && ncell == 64;
         float* const base = p.grad[scale] + (int64_t)w0 * attrs;
         const int nflo = ncell * attrs;
@@ -703,30 +712,26 @@ extern "C" int ryolo_loss(const LossParams* pp, hipStream_t stream)
     if (p.nt > 0 && !p.targets) return RY_ERR_ARG;
     if (p.tcols < (p.mode == 0 ? 187 : 7) && p.nt > 0) return RY_ERR_ARG;
     ScaleWs s[3];
-    size_t need;
-    carve(p, s, &need);
+    size_t need, ff_off, ff_bytes;
+    carve(p, s, &need, &ff_off, &ff_bytes);
     if (p.ws_bytes < need) return RY_ERR_WORKSPACE;
-    // (attrs: see loss_obj_kernel)
-    if (hipMemsetAsync(p.ws, 0, need, stream) != hipSuccess) return RY_ERR_LAUNCH;
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 3; i++)
         if (!p.head[i] || (p.compute_grad && !p.grad[i])) return RY_ERR_ARG;
-        if (hipMemsetAsync(s[i].owner, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
-        if (p.compute_grad && hipMemsetAsync(s[i].head, 0xff, (size_t)s[i].cells * 4, stream) != hipSuccess) return RY_ERR_LAUNCH;
-        // (p.grad[i] is NOT cleared here any more: loss_match_grad_kernel + loss_obj_kernel define every element, r05)
-    }
-    if (p.nt > 0) {
+    // two fills: the match counters (zero) and the owner / chain-head grids (-1); everything else is written before it is read, and the
+    // gradient maps are defined by loss_match_grad_kernel + loss_obj_kernel
+    if (hipMemsetAsync(p.ws, 0, 768, stream) != hipSuccess) return RY_ERR_LAUNCH;
+    if (hipMemsetAsync(reinterpret_cast<char*>(p.ws) + ff_off, 0xff, p.compute_grad ? ff_bytes : ff_bytes / 2, stream) != hipSuccess) return RY_ERR_LAUNCH;
+    int max_obj = 1;
+    for (int i = 0; i < 3; i++) max_obj = s[i].nblk_obj > max_obj ? s[i].nblk_obj : max_obj;
+    if (p.nt > 0) {                                           // (one launch per pass for the three scales: blockIdx.y; cap is the same for all)
         hipLaunchKernelGGL(loss_targets_count_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
         hipLaunchKernelGGL(loss_targets_kernel, dim3(3, LT_BLOCKS), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
-        for (int i = 0; i < 3; i++) {
-            hipLaunchKernelGGL(loss_match_box_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, p, s[i], i);
-            const int G = (p.mode != 0 && p.nc <= 16) ? 16 : 64;
-            hipLaunchKernelGGL(loss_match_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256 / G)), dim3(256), 0, stream, p, s[i], i, G);
-            if (p.compute_grad) hipLaunchKernelGGL(loss_match_grad_kernel, dim3(s[i].nblk_match), dim3(256), 0, stream, p, s[i], i);
-            hipLaunchKernelGGL(loss_tconf_kernel, dim3((unsigned)ry_cdiv(s[i].cap, 256)), dim3(256), 0, stream, s[i]);
-        }
+        hipLaunchKernelGGL(loss_match_box_kernel, dim3((unsigned)ry_cdiv(s[0].cap, 256), 3), dim3(256), 0, stream, p, s[0], s[1], s[2]);
+        const int G = (p.mode != 0 && p.nc <= 16) ? 16 : 64;
+        hipLaunchKernelGGL(loss_match_kernel, dim3((unsigned)ry_cdiv(s[0].cap, 256 / G), 3), dim3(256), 0, stream, p, s[0], s[1], s[2], G);
+        if (p.compute_grad) hipLaunchKernelGGL(loss_match_grad_kernel, dim3(s[0].nblk_match, 3), dim3(256), 0, stream, p, s[0], s[1], s[2]);
     }
-    for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL(loss_obj_kernel, dim3(s[i].nblk_obj), dim3(256), 0, stream, p, s[i], i);
+    hipLaunchKernelGGL(loss_obj_kernel, dim3(max_obj, 3), dim3(256), 0, stream, p, s[0], s[1], s[2]);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, p, s[0], s[1], s[2]);
     RY_CHECK_LAUNCH();
     return RY_OK;
@@ -746,6 +751,20 @@ extern "C" int ryolo_loss_owner_grids(const LossParams* pp, const int** owner)
     return RY_OK;
 }
 
+// where the match counters and records of the last ryolo_loss call on this workspace live: count[i] -> one int, rec[i] -> [count][8] ints
+// (b, a, gj, gi, cls, target row, cell, pad) in the reference's enumeration order (tests: target-assignment parity)
+extern "C" int ryolo_loss_match_records(const LossParams* pp, const int** count, const int** rec)
+{
+    if (!pp || !count || !rec || !pp->ws) return RY_ERR_ARG;
+    LossParams p = *pp;
+    ScaleWs s[3];
+    size_t need;
+    carve(p, s, &need);
+    if (p.ws_bytes < need) return RY_ERR_WORKSPACE;
+    for (int i = 0; i < 3; i++) { count[i] = s[i].count; rec[i] = s[i].rec; }
+    return RY_OK;
+}
+
 // grad *= *scale unless *scale == 1 (uniform early exit: one scalar load per workgroup)
 __global__ __launch_bounds__(256) void loss_grad_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ scale)
 {
@@ -753,6 +772,35 @@ __global__ __launch_bounds__(256) void loss_grad_scale_kernel(float* __restrict_
     if (s == 1.0f) return;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] *= s;
+}
+
+// the same for up to 8 arrays in ONE launch (the three gradient maps and their compact objectness copies): blockIdx.y = array
+struct GradScaleSet { float* g[8]; int64_t n[8]; };
+__global__ __launch_bounds__(256) void loss_grad_scale_multi_kernel(const GradScaleSet a, const float* __restrict__ scale)
+{
+    const float s = *scale;
+    if (s == 1.0f) return;
+    float* const g = a.g[blockIdx.y];
+    const int64_t n = a.n[blockIdx.y], stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] *= s;
+}
+
+extern "C" int ryolo_loss_grad_scale_multi(float* const* grads, const int64_t* n, int count, const float* scale, hipStream_t stream)
+{
+    if (!scale || !grads || !n || count < 1 || count > 8) return RY_ERR_ARG;
+    GradScaleSet a;
+    int64_t most = 0;
+    for (int i = 0; i < 8; i++) {
+        a.g[i] = i < count ? grads[i] : nullptr;
+        a.n[i] = i < count ? n[i] : 0;
+        if (i < count && (n[i] < 0 || (n[i] > 0 && !grads[i]))) return RY_ERR_ARG;
+        most = a.n[i] > most ? a.n[i] : most;
+    }
+    if (most == 0) return RY_OK;
+    const int64_t blocks = (most + 255) / 256;
+    hipLaunchKernelGGL(loss_grad_scale_multi_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), count), dim3(256), 0, stream, a, scale);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
 }
 
 extern "C" int ryolo_loss_grad_scale(float* grad, int64_t n, const float* scale, hipStream_t stream)

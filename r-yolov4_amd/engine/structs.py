@@ -125,6 +125,8 @@ for _name, _sig in {
     "ryolo_loss": [_PTR(LossParams), P],
     "ryolo_loss_owner_grids": [_PTR(LossParams), _PTR(P * 3)],
     "ryolo_loss_grad_scale": [P, L, P, P],
+    "ryolo_loss_grad_scale_multi": [_PTR(P * 8), _PTR(L * 8), I, P, P],
+    "ryolo_loss_match_records": [_PTR(LossParams), _PTR(P * 3), _PTR(P * 3)],
 }.items():
     hip.register(_name, _sig)
 

@@ -75,14 +75,17 @@ class _LossFn(torch.autograd.Function):
         # d(total)/d(logits) was produced by the fused kernel; chain rule with the incoming gradient (a [1] device tensor, 1.0 after a
         # plain loss.backward()): scaled in place on the device, and skipped there when the scalar is exactly 1 (no host read)
         sc = go.detach().reshape(-1)[:1].to(device=g[0].device, dtype=torch.float32).contiguous()
-        for gi in g:
-            hip.call("ryolo_loss_grad_scale", gi.data_ptr(), gi.numel(), sc.data_ptr(), hip.stream())
         _HANDOFF.clear()
+        arrs = list(g)
         if ctx.compact is not None and ctx.crit._gen == ctx.gen:         # (a later call of the criterion reused the workspace: owner grids gone)
             objgrad, owners, och, ws = ctx.compact
-            for gi, og, ow in zip(g, objgrad, owners):               # same scalar, same multiply: compact and dense forms stay bit-identical
-                hip.call("ryolo_loss_grad_scale", og.data_ptr(), og.numel(), sc.data_ptr(), hip.stream())
+            arrs += list(objgrad)                                         # same scalar, same multiply: compact and dense forms stay bit-identical
+            for gi, og, ow in zip(g, objgrad, owners):
                 _HANDOFF[gi.data_ptr()] = (gi, og, ow, och, ws, gi._version)
+        ptrs, lens = (S.P * 8)(), (S.L * 8)()
+        for k, t in enumerate(arrs):
+            ptrs[k], lens[k] = t.data_ptr(), t.numel()
+        hip.call("ryolo_loss_grad_scale_multi", ptrs, lens, len(arrs), sc.data_ptr(), hip.stream())       # one launch (exits on the device when the scalar is 1)
         return (None, None) + tuple(g)
 
 
@@ -150,6 +153,7 @@ class _ComputeLossBase:
         if self._ws is None or self._ws.numel() < need.value or self._ws.device != dev:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         p.ws, p.ws_bytes, p.items = self._ws.data_ptr(), self._ws.numel(), items.data_ptr()
+        self._last_params = p
         if objgrad is not None:
             for i in range(3):
                 p.objgrad[i] = objgrad[i].data_ptr()
@@ -184,19 +188,15 @@ class _ComputeLossBase:
     def debug_matches(self):
         """Test hook: the (b, a, gj, gi, cls, tidx, cell) records of the last call, per scale, read back from the workspace
         (layout = carve() in csrc/loss.hip)."""
-        al = lambda v: (v + 255) & ~255
-        nt, na, B = self._last_shape
-        out, off = [], 0
-        ws = self._ws.cpu().numpy()
-        for gs in self._last_gs:
-            cap, cells = 5 * na * nt, B * na * gs * gs
-            nbm = (cap + 3) // 4
-            nbo = max(1, min(2048, (cells + 1023) // 1024))
-            cnt = int(ws[off:off + 4].view("int32")[0]); off += 256
-            rec = ws[off:off + cap * 32].view("int32").reshape(-1, 8)[:cnt].copy(); off += al(cap * 32)
-            off += al(cap * 32) + al(cells * 4) * 2 + al(max(nbm, 1) * 16) + al(nbo * 4)
-            off += al(cells * 4) + al(cap * 4) + al(cap * 32)                  # head, next, gbox (duplicate-cell chains)
-            out.append(rec.astype("int64"))
+        cnt_p, rec_p = (S.P * 3)(), (S.P * 3)()
+        hip.call("ryolo_loss_match_records", self._last_params, cnt_p, rec_p)
+        torch.cuda.synchronize()
+        base, ws = self._ws.data_ptr(), self._ws
+        out = []
+        for i in range(3):
+            cnt = int(ws[cnt_p[i] - base:cnt_p[i] - base + 4].view(torch.int32)[0])
+            o = rec_p[i] - base
+            out.append(ws[o:o + cnt * 32].view(torch.int32).reshape(-1, 8).cpu().numpy().astype("int64"))
         return out
 
     def __call__(self, outputs, target, sync_items=True):
