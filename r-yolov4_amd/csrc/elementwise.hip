@@ -1296,6 +1296,43 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 // fp32 master [Cout][Cin][taps] (torch layout) -> Wf bf16 [Cout][taps][CinP] and Wd bf16 [Cin][taps][Cout] (Wd may be null).
 // CinP >= Cin: small-Cin first layers are packed as a single tap with k = tap*Cin + c zero-padded to CinP.
 
+// one (32 output channels x 32 input channels) tile of pack_weights_kernel; TAPS = 0: tap count from the entry
+template <int TAPS>
+__device__ __forceinline__ void pack_tile(const PackEntry& e, float (*tile)[32 * RY_MAX_TAPS + 1], int64_t t)
+{
+    const int taps = TAPS ? TAPS : e.taps;
+    const int nct = e.Cin / 32;
+    const int co0 = (int)(t / nct) * 32, c0 = (int)(t % nct) * 32;
+    const int run = 32 * taps;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int r = i / run, k = i - r * run;
+        tile[r][k] = (co0 + r < e.Cout) ? e.src[((int64_t)(co0 + r) * e.Cin + c0) * taps + k] : 0.f;
+    }
+    __syncthreads();
+    // both images are written as PAIRS (4-byte stores: 16 lanes cover a 64-byte segment; the 2-byte stores of r01-r04 moved 128 bytes per wave
+    // instruction)
+    const int run2 = 16 * taps;
+    for (int i = threadIdx.x; i < 32 * run2; i += 256) {         // Wf[co][t][c]: c fastest
+        const int c = (i & 15) * 2, tp = (i >> 4) % taps, r = i / run2;
+        if (co0 + r < e.Cout)
+            *reinterpret_cast<unsigned*>(e.wf + ((int64_t)(co0 + r) * taps + tp) * e.CinP + c0 + c) = pack_bf2(tile[r][c * taps + tp], tile[r][(c + 1) * taps + tp]);
+    }
+    if (e.wd) {
+        const int ldw = e.ldWd ? e.ldWd : e.CoutP;
+        const bool pairs = ((ldw | e.Cout) & 1) == 0 && (reinterpret_cast<uintptr_t>(e.wd) & 3) == 0;
+        for (int i = threadIdx.x; i < 32 * run2; i += 256) {     // Wd[c][t][co]: co fastest
+            const int r = (i & 15) * 2, tp = (i >> 4) % taps, c = i / run2;
+            if (co0 + r >= e.Cout) continue;
+            float v0 = tile[r][c * taps + tp], v1 = tile[r + 1][c * taps + tp];
+            if (e.wd_scale) { v0 *= e.wd_scale[co0 + r]; if (co0 + r + 1 < e.Cout) v1 *= e.wd_scale[co0 + r + 1]; }
+            bf16_t* o = e.wd + ((int64_t)(c0 + c) * taps + tp) * ldw + co0 + r;
+            if (pairs) *reinterpret_cast<unsigned*>(o) = pack_bf2(v0, v1);
+            else { o[0] = f2bf(v0); if (co0 + r + 1 < e.Cout) o[1] = f2bf(v1); }
+        }
+    }
+}
+
 // Tiled repack: one workgroup per (conv, 32 output channels, 32 input channels).  Reads are whole contiguous runs of
 // 32*taps floats per output channel, the [co][c][t] block is transposed in LDS, and both bf16 images are written as
 // 64-byte segments (Wf along c, Wd along co).  `start` of an entry = index of its first tile.
@@ -1318,26 +1355,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
             }
             continue;
         }
-        const int nct = e.Cin / 32;
-        const int co0 = (int)(t / nct) * 32, c0 = (int)(t % nct) * 32;
-        const int run = 32 * e.taps;
-        __syncthreads();
-        for (int i = threadIdx.x; i < 32 * run; i += 256) {
-            const int r = i / run, k = i - r * run;
-            tile[r][k] = (co0 + r < e.Cout) ? e.src[((int64_t)(co0 + r) * e.Cin + c0) * e.taps + k] : 0.f;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 32 * run; i += 256) {          // Wf[co][t][c]: c fastest
-            const int c = i & 31, tp = (i >> 5) % e.taps, r = i / run;
-            if (co0 + r < e.Cout) e.wf[((int64_t)(co0 + r) * e.taps + tp) * e.CinP + c0 + c] = f2bf(tile[r][c * e.taps + tp]);
-        }
-        if (e.wd)
-            for (int i = threadIdx.x; i < 32 * run; i += 256) {      // Wd[c][t][co]: co fastest
-                const int r = i & 31, tp = (i >> 5) % e.taps, c = i / run;
-                if (co0 + r < e.Cout)
-                    e.wd[((int64_t)(c0 + c) * e.taps + tp) * (e.ldWd ? e.ldWd : e.CoutP) + co0 + r] =
-                        f2bf(e.wd_scale ? tile[r][c * e.taps + tp] * e.wd_scale[co0 + r] : tile[r][c * e.taps + tp]);
-            }
+        if (e.taps == 9) pack_tile<9>(e, tile, t);              // (uniform per tile; with the tap count a runtime value every element paid three
+        else if (e.taps == 1) pack_tile<1>(e, tile, t);         //  integer divisions: the kernel was ALU-bound at 1.5 TB/s)
+        else pack_tile<0>(e, tile, t);
     }
 }
 
