@@ -1212,15 +1212,27 @@ __global__ __launch_bounds__(256) void head_bwd_sparse_kernel(const float* __res
 }
 
 // out0[c] += sum_r partial[r][0][c];  out1[c] += sum_r partial[r][1][c]   (rows already folded to <= 256; double accumulation)
-__global__ void head_grad_rows_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out0, float* __restrict__ out1)
+__global__ __launch_bounds__(256) void head_grad_rows_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out0,
+                                                             float* __restrict__ out1)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
-    float* out = c < C ? out0 : out1;
-    if (!out) return;
+    // 32 columns x 8 row groups per workgroup, groups folded in a fixed order (one thread per column walking all rows: 17-23 us per head for a few
+    // hundred kilobytes — dependent loads)
+    __shared__ double red[8][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float* const out = c < C ? out0 : out1;
+    const bool live = c < 2 * C && out != nullptr;
     double s = 0.0;
-    for (int r = 0; r < rows; r++) s += (double)partial[(int64_t)r * 2 * C + c];
-    out[c < C ? c : c - C] += (float)s;
+    if (live)
+        for (int r = g; r < rows; r += 8) s += (double)partial[(int64_t)r * 2 * C + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && live) {
+        double t = red[0][cl];
+#pragma unroll
+        for (int q = 1; q < 8; q++) t += red[q][cl];
+        out[c < C ? c : c - C] += (float)t;
+    }
 }
 
 __global__ void colsum_rows_kernel(const float* __restrict__ partial, int rows, int C, int Cvalid, float* __restrict__ out)
@@ -1694,7 +1706,7 @@ static int head_finish_bwd_impl(const float* dout, const float* pre, int ldp, co
     } else if (C <= 512) hipLaunchKernelGGL(head_finish_bwd_kernel<1>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch, objgrad, owner, och);
     else hipLaunchKernelGGL(head_finish_bwd_kernel<4>, dim3(rows), dim3(256), lds, stream, dout, pre, ldp, mul, B, gs, na, attrs, TC, dpre, ldd, scratch, objgrad, owner, och);
     const float* part = fold_rows(scratch, rows, 2 * C, scratch + (int64_t)rows * 2 * C, stream);
-    hipLaunchKernelGGL(head_grad_rows_kernel, dim3((unsigned)ry_cdiv(2 * C, 256)), dim3(256), 0, stream, part, rows, C, dbias, mul ? dmul : nullptr);
+    hipLaunchKernelGGL(head_grad_rows_kernel, dim3((unsigned)ry_cdiv(2 * C, 32)), dim3(256), 0, stream, part, rows, C, dbias, mul ? dmul : nullptr);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
@@ -1729,11 +1741,24 @@ extern "C" int ryolo_head_finish_bwd_sparse(const float* dout, const float* objg
 __global__ __launch_bounds__(256) void head_da_kernel(const float* __restrict__ s, const float* __restrict__ W, const float* __restrict__ m, int Cout, int K,
                                                       float* __restrict__ da)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    // 32 input channels x 8 groups of output channels per workgroup (the first cut — one thread per k walking all Cout rows, K / 256 workgroups —
+    // took 152 us per head); groups folded in a fixed order
+    __shared__ float red[8][33];
+    const int kl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kl;
     float acc = 0.f;
-    for (int c = 0; c < Cout; c++) acc = fmaf(m[c] * s[c], W[(int64_t)c * K + k], acc);
-    da[k] += acc;
+    if (k < K) {
+#pragma unroll 8
+        for (int c = g; c < Cout; c += 8) acc = fmaf(m[c] * s[c], W[(int64_t)c * K + k], acc);
+    }
+    red[g][kl] = acc;
+    __syncthreads();
+    if (g == 0 && k < K) {
+        float t = red[0][kl];
+#pragma unroll
+        for (int q = 1; q < 8; q++) t += red[q][kl];
+        da[k] += t;
+    }
 }
 
 __global__ __launch_bounds__(256) void head_wgrad_finish_kernel(float* __restrict__ G, float* __restrict__ s, const float* __restrict__ W,
@@ -1765,7 +1790,7 @@ extern "C" int ryolo_head_wgrad_finish(float* G, float* s, const float* W, const
                                        float* db, float* dm, float* da, hipStream_t stream)
 {
     if (!G || !s || !W || !m || !dW || !dm || Cout <= 0 || K <= 0 || (a && !da)) return RY_ERR_ARG;
-    if (a) hipLaunchKernelGGL(head_da_kernel, dim3((unsigned)ry_cdiv(K, 256)), dim3(256), 0, stream, s, W, m, Cout, K, da);
+    if (a) hipLaunchKernelGGL(head_da_kernel, dim3((unsigned)ry_cdiv(K, 32)), dim3(256), 0, stream, s, W, m, Cout, K, da);
     hipLaunchKernelGGL(head_wgrad_finish_kernel, dim3(Cout), dim3(256), 0, stream, G, s, W, b, m, a, K, dW, db, dm);
     RY_CHECK_LAUNCH();
     return RY_OK;
