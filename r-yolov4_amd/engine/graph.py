@@ -447,7 +447,12 @@ class Graph:
             # deep-ring instantiations do not fold statistics), and `part` is sized by the rows of the kernel that really writes it
             p.nbstat = len(bstat)
             hip.call("ryolo_conv_gemm_plan", p, rows, kern)
-            assert (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1, "BN-statistics fold planned on a kernel family that is masked off"
+            if not (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1:
+                # the launch WITH the fold runs on another kernel family than the one asked about above, and RYOLO_FUSE_BN_KERNELS masks that one:
+                # no fold, the stand-alone reduce pass stays (p.nbstat back to 0 so that the launch is planned as it will run)
+                p.nbstat = 0
+                bstat = None
+        if bstat:
             for i, (n0, (c0_, C_, y_, co_, act_, holder)) in enumerate(bstat):
                 part = self.f32(rows.value + 64, 2, C_)                      # +64 rows: fold scratch of ryolo_bn_act_bwd
                 b = p.bstat[i]
