@@ -78,13 +78,15 @@ def test_block_and_network_parity_with_the_alternatives_of_the_r04_defaults():
     """The instantiations the end-of-r04 defaults moved AWAY from stay covered: 64-channel stages of the generic tapped GEMM (RYOLO_GEMM_PIPE
     without 0x100), 32-pixel steps of the pointwise LDS-DMA weight gradient (RYOLO_WGRAD_P1=3), the register-staged tapped weight gradient
     (RYOLO_WGRAD_TAPS_DMA=0), and (r05) the 4-wave ring weight-gradient kernels that the 8-wave form replaced for Cin % 64 == 0
-    (RYOLO_W3_V8=0; their direct C-ABI cases run here too) and the 4-wave pointwise kernels behind the 8-wave 256 x 256 form (RYOLO_WGRAD_8W=0) — independent kernel selections, selected together in ONE child process (each
+    (RYOLO_W3_V8=0; their direct C-ABI cases run here too), the 4-wave pointwise kernels behind the 8-wave 256 x 256 form (RYOLO_WGRAD_8W=0) and the
+    r01-r04 form of the detection heads (RYOLO_HEAD_FUSED=0: row-major fp32 intermediate + ryolo_head_finish_fwd_obj, ImplicitA as a pass, the ImplicitM
+    gradient from the pre-activations, the sparse head backward WITH its compact pre-activation column) — independent kernel selections, selected together in ONE child process (each
     run of the per-block, whole-network and per-node parity tests costs the GPU suite ~25 s)."""
     import gc
     import torch
     gc.collect()
     torch.cuda.empty_cache()
-    env = dict(os.environ, RYOLO_GEMM_PIPE="0x201", RYOLO_WGRAD_P1="3", RYOLO_WGRAD_TAPS_DMA="0", RYOLO_W3_V8="0", RYOLO_WGRAD_8W="0")
+    env = dict(os.environ, RYOLO_GEMM_PIPE="0x201", RYOLO_WGRAD_P1="3", RYOLO_WGRAD_TAPS_DMA="0", RYOLO_W3_V8="0", RYOLO_WGRAD_8W="0", RYOLO_HEAD_FUSED="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_blocks.py", "tests/test_gpu_model.py", "tests/test_gpu_teacher_forced.py",
                         "tests/test_gpu_wgrad3x3.py", "-q", "-m", "gpu",
                         "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)

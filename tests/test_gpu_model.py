@@ -471,9 +471,12 @@ def test_compact_head_gradient_handoff_is_bit_identical_and_used(ver, mode, scal
     # gradients behind the weight gradient
     fwd_names = [n for _f, _a, n in _last_plan(net).fwd]
     bwd_names = [n for _f, _a, n in _last_plan(net).bwd]
-    assert not any(n.startswith("ryolo_head_finish_fwd") for n in fwd_names)
-    assert "ryolo_chan_add" not in fwd_names and "ryolo_colsum_bf16" not in bwd_names          # ImplicitA folded into the bias / finished from s
-    assert bwd_names.count("ryolo_head_wgrad_finish") == (3 if ver == "yolov7" else 0)
+    if os.environ.get("RYOLO_HEAD_FUSED", "1") != "0":
+        assert not any(n.startswith("ryolo_head_finish_fwd") for n in fwd_names)
+        assert "ryolo_chan_add" not in fwd_names and "ryolo_colsum_bf16" not in bwd_names      # ImplicitA folded into the bias / finished from s
+        assert bwd_names.count("ryolo_head_wgrad_finish") == (3 if ver == "yolov7" else 0)
+    else:       # (tests/test_gpu_forced_kernels.py re-runs this file on the r01-r04 form: row-major intermediate + finish pass with compact copies)
+        assert fwd_names.count("ryolo_head_finish_fwd_obj") == 3 and "ryolo_head_wgrad_finish" not in bwd_names
     assert flat[0].abs().sum() > 0 and torch.isfinite(flat[0]).all()
     assert torch.equal(flat[0], flat[1])
     assert torch.equal(flat[0], flat[2])
