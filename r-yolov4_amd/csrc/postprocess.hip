@@ -10,15 +10,31 @@
 // HBM-bound: algorithmic bytes = 4*B*M*(nc+6) read + 4*B*M*nc written back (the in-place product) + O(K).
 #include "common.h"
 
-__global__ void pp_score_kernel(float* __restrict__ pred /*[B,M,nc+6] mutated*/, int B, int64_t M, int nc, float conf_thres,
-                                float* __restrict__ key /*[B,M]*/, float* __restrict__ cls_out /*[B,M]*/,
-                                int32_t* __restrict__ count /*[B], zeroed by caller*/)
+// r05: a workgroup stages R consecutive rows (one contiguous block of R * (nc + 6) floats) in LDS with coalesced loads, one thread per row works
+// on the LDS copy, and the block goes back with coalesced stores.  (One lane per row on global memory — nc + 1 strided scalar loads and nc strided
+// stores per lane — ran at 0.55 TB/s: 2.4 ms for the 1.33 GB of a batch of 64.)  Same arithmetic per row.
+__global__ __launch_bounds__(256) void pp_score_kernel(float* __restrict__ pred /*[B,M,nc+6] mutated*/, int B, int64_t M, int nc, float conf_thres,
+                                                       float* __restrict__ key /*[B,M]*/, float* __restrict__ cls_out /*[B,M]*/,
+                                                       int32_t* __restrict__ count /*[B], zeroed by caller*/, int R, int LD)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ float ps_rows[];                           // [R][LD], LD odd (conflict-free row walks)
+    const int A = nc + 6;
+    const int64_t i0 = (int64_t)blockIdx.x * R;
     const int b = blockIdx.y;
+    const int nrows = (int)(M - i0 < R ? M - i0 : R);
+    float* const base = pred + ((int64_t)b * M + i0) * A;
+    const int total = nrows * A;
+    const float rA = 1.0f / (float)A;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        int r = (int)((float)e * rA);
+        if (r * A > e) r--;
+        if ((r + 1) * A <= e) r++;
+        ps_rows[r * LD + (e - r * A)] = base[e];
+    }
+    __syncthreads();
     bool pass = false;
-    if (i < M) {
-        float* p = pred + ((int64_t)b * M + i) * (nc + 6);
+    if ((int)threadIdx.x < nrows) {
+        float* p = ps_rows + threadIdx.x * LD;
         const float obj = p[5];
         float best = 0.f;
         int bi = 0;
@@ -28,11 +44,24 @@ __global__ void pp_score_kernel(float* __restrict__ pred /*[B,M,nc+6] mutated*/,
             if (k == 0 || v > best) { best = v; bi = k; }
         }
         pass = nc > 0 && best > conf_thres;
-        key[(int64_t)b * M + i] = pass ? best : -INFINITY;
-        cls_out[(int64_t)b * M + i] = (float)bi;
+        key[(int64_t)b * M + i0 + threadIdx.x] = pass ? best : -INFINITY;
+        cls_out[(int64_t)b * M + i0 + threadIdx.x] = (float)bi;
     }
+    __shared__ int wave_pass[4];
     const unsigned long long m = __ballot(pass);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&count[b], (int)__popcll(m));
+    if ((threadIdx.x & 63) == 0) wave_pass[threadIdx.x >> 6] = (int)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                       // one atomic per workgroup (per wave: 3 700 serialized atomics per image counter)
+        const int n = wave_pass[0] + wave_pass[1] + wave_pass[2] + wave_pass[3];
+        if (n) atomicAdd(&count[b], n);
+    }
+    for (int e = threadIdx.x; e < total; e += 256) {
+        int r = (int)((float)e * rA);
+        if (r * A > e) r--;
+        if ((r + 1) * A <= e) r++;
+        const int k = e - r * A;
+        if (k >= 6) base[e] = ps_rows[r * LD + k];               // (the box / objectness columns are not changed)
+    }
 }
 
 __global__ void pp_gather_kernel(const float* __restrict__ pred, const float* __restrict__ sorted_key /*[B,M] desc*/,
@@ -86,8 +115,12 @@ extern "C" int ryolo_pp_score(float* pred, int batch, int64_t M, int nc, float c
     if (hipMemsetAsync(count, 0, sizeof(int32_t) * batch, stream) != hipSuccess) return RY_ERR_LAUNCH;
     if (M == 0) return RY_OK;
     if (!pred || !key || !cls) return RY_ERR_ARG;
-    hipLaunchKernelGGL(pp_score_kernel, dim3((unsigned)ry_cdiv(M, 256), batch), dim3(256), 0, stream, pred, batch, M, nc, conf_thres,
-                       key, cls, count);
+    const int LD = (nc + 6) | 1;
+    int R = 12288 / LD;                                          // <= 48 KiB of LDS
+    R = R > 256 ? 256 : (R < 1 ? 1 : R);
+    if ((int64_t)R * (nc + 6) >= (1 << 24)) return RY_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pp_score_kernel, dim3((unsigned)ry_cdiv(M, R), batch), dim3(256), (size_t)R * LD * sizeof(float), stream, pred, batch, M, nc,
+                       conf_thres, key, cls, count, R, LD);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }
