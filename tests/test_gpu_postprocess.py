@@ -108,6 +108,40 @@ def test_decode_golden(golden_dir, mode, nc):
     assert isinstance(train_only, list) and len(train_only) == 3
 
 
+@pytest.mark.parametrize("nc,B,img", [(1, 3, 32), (7, 2, 96), (80, 1, 160), (16, 5, 64)])
+def test_decode_kfiou_odd_shapes_vs_oracle(nc, B, img):
+    """The kfiou decode runs one lane per ELEMENT of the contiguous [rows][attrs] array (r05) and decomposes rows inside a 2 048-element
+    workgroup block by small divisions: grids of 1, 2 and 4 cells per side (several image / anchor wraps inside one block), odd row lengths
+    (7, 13, 86 floats), blocks that end inside a row and a ragged last block."""
+    from ryolov4_amd.model import yololayer
+    anchors = ref_ops.make_anchors(CFG, "kfiou")
+    g = torch.Generator().manual_seed(nc * 10 + B)
+    logits = [torch.randn(B, len(anchors[k]) * (nc + 6), img // st, img // st, generator=g) * 2 for k, st in enumerate((8, 16, 32))]
+    layer = yololayer.make_layer("kfiou", nc, anchors, [8, 16, 32])
+    _, infer = layer([l.clone().to(DEV) for l in logits], False)
+    _, exp = ref_ops.decode(logits, anchors, nc, "kfiou")
+    assert infer.shape == exp.shape
+    np.testing.assert_allclose(infer.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("nc,M", [(1, 777), (80, 1000), (200, 300), (16, 257)])
+def test_post_process_score_pass_row_blocks(nc, M):
+    """post_process's score pass stages R rows per workgroup in LDS (R = min(256, 48 KiB / row)): class counts for which R is 256, 141 and 59,
+    row counts that are not multiples of R; same detections as the oracle, and the in-place cls *= obj of lib/general.py:155 kept."""
+    g = _general()
+    gen = torch.Generator().manual_seed(nc + M)
+    pred = torch.rand(2, M, nc + 6, generator=gen)
+    pred[..., 0:2] *= 300; pred[..., 2] = pred[..., 2] * 40 + 4; pred[..., 3] = pred[..., 2] * 3; pred[..., 4] = (pred[..., 4] - 0.5) * 3.1
+    ref = pred.clone()
+    exp = ref_ops.post_process(ref, 0.4, 0.3)
+    dev = pred.clone().to(DEV)
+    got = g.post_process(dev, 0.4, 0.3)
+    torch.testing.assert_close(dev.cpu(), ref, rtol=0, atol=0)                            # both mutate their input the same way
+    for a, b in zip(exp, got):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(b.cpu().numpy(), a.numpy(), atol=1e-5)
+
+
 def test_post_process_golden(golden_dir):
     g = _general()
     gd = np.load(os.path.join(golden_dir, "g7_postprocess.npz"))
