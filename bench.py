@@ -46,17 +46,19 @@ class EventTimer:
         self.used += 2
         return a, b
 
-    def note(self, kind, flops, e0, e1, nbytes=0, sub=None, cus=None):
-        """cus: CUs the launch holds when it runs alone (engine/graph.py _describe; None = the whole chip)."""
-        self.notes.append((kind, flops, e0, e1, nbytes, sub, cus))
+    def note(self, kind, flops, e0, e1, nbytes=0, sub=None, cus=None, fam=None):
+        """cus: CUs the launch holds when it runs alone (engine/graph.py _describe; None = the whole chip); fam: layer family ("3x3s1" /
+        "3x3s2": forward, data-gradient and weight-gradient launches of the 3x3 convolutions, whichever kernel serves them)."""
+        self.notes.append((kind, flops, e0, e1, nbytes, sub, cus, fam))
 
-    def summary(self, by_sub=False):
-        """by_sub: only the launches that carry a sub-class label (engine/graph.py _describe), keyed (class, sub)."""
+    def summary(self, by_sub=False, by_fam=False):
+        """by_sub: only the launches that carry a sub-class label (engine/graph.py _describe), keyed (class, sub); by_fam: only the launches
+        of a layer family, keyed (family, class)."""
         agg = {}
-        for kind, fl, e0, e1, nb, sub, cus in self.notes:
-            if by_sub and sub is None:
+        for kind, fl, e0, e1, nb, sub, cus, fam in self.notes:
+            if (by_sub and sub is None) or (by_fam and fam is None):
                 continue
-            d = agg.setdefault((kind, sub) if by_sub else kind, [0.0, 0.0, 0, 0.0, 0.0])
+            d = agg.setdefault((fam, kind) if by_fam else (kind, sub) if by_sub else kind, [0.0, 0.0, 0, 0.0, 0.0])
             t = e0.elapsed_time(e1) * 1e-3
             d[0] += t
             d[1] += fl
@@ -101,7 +103,9 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
 }
 
 
-PMC_PROFILE = "profiles/r05_pmc_step_traffic.json"        # regenerated by tools/pmc_step.sh whenever a kernel of the step changes
+PMC_PROFILE = "profiles/r06_pmc_step_traffic.json"        # regenerated by tools/pmc_step.sh whenever a kernel of the step changes
+MFMA_BUSY_PROFILE = "profiles/r06_pmc_step_mfma_busy.json"   # whole-step SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel class (tools/pmc_step.sh)
+INFER_GFLOP_PER_IMG = {("yolov7", "kfiou", 800): 166.53, ("yolov7", "kfiou", 1024): 272.84}
 
 
 def source_sha256():
@@ -259,6 +263,87 @@ def nms_block(dev):
     return res
 
 
+def infer_block(args, dev):
+    """Inference in front of the driver (BASELINE config C5 and the eval branch of test.py:188-191 / detect.py:57-61).
+      infer_c5        yolov7 kfiou nc=16, 1024 x 1024, 8 images: the eval forward (folded BatchNorm + activation epilogues, RepConv
+                      re-parameterised) + YoloLayer decode + score filter + radix-select top-K + rotated NMS (lib/general.py:136-183) captured in ONE
+                      hipGraph (conf 0.001 / iou 0.65: test.py:270-271); random-init weights put EVERY row past the confidence filter, so the
+                      top-K and the NMS run at their worst-case sizes (max_nms candidates per image);
+      infer_800_b64   the same network's eager batch-64 forward at 800 x 800 (the training benchmark's shape).
+    Device time by HIP events over n replays; forward-only MFMA fraction from BASELINE.md section 2's GFLOP per image."""
+    import gc
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, synth_batch
+    torch.manual_seed(42)
+    net = Yolo(args.nc, CFG, "kfiou", "yolov7")
+    net.apply(weights_init_normal)
+    net.to(dev).eval()
+
+    def timed(fn, n, skip=3):
+        for _ in range(skip):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    out = {}
+    t_wall = time.perf_counter()
+    # ---- C5: 1024^2 x 8, everything in one captured graph (one live graph at a time: DESIGN.md section 6, "Inference") ---------------------
+    B, SZ, CONF, IOU = 8, 1024, 0.001, 0.65
+    imgs, _ = synth_batch(B, SZ, args.nc, False, seed=42)
+    imgs = imgs.to(dev)
+    cap = net.capture_inference(B, SZ)
+    t_f = timed(lambda: cap(imgs), 20)
+    del cap
+    gc.collect()
+    torch.cuda.synchronize()
+    capp = net.capture_inference(B, SZ, post=(CONF, IOU))
+    t_p = timed(lambda: capp(imgs), 20)
+    _, _, dets, num = capp(imgs)
+    plan = capp.post_plan
+    gf = INFER_GFLOP_PER_IMG[("yolov7", "kfiou", 1024)]
+    out["infer_c5"] = {"workload": f"C5: yolov7 kfiou nc={args.nc} {SZ}x{SZ}, batch {B}, hipGraph-captured eval forward + decode + top-K + rotated NMS "
+                                   f"(conf {CONF}, iou {IOU}); random-init weights: every row passes the confidence filter (worst-case post_process)",
+                       "ms_per_batch": round(t_p, 3), "img_s": round(B / t_p * 1e3, 1), "forward_decode_ms": round(t_f, 3), "forward_img_s": round(B / t_f * 1e3, 1),
+                       "post_process_ms": round(t_p - t_f, 3), "rows_per_image": int(plan.M), "nms_input_cap": int(plan.K),
+                       "detections_per_image": num.cpu().tolist(), "gflop_per_img_forward": gf,
+                       "frac_mfma_forward": round(B / t_f * 1e3 * gf * 1e9 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)}
+    del capp, dets, num, plan, imgs
+    gc.collect()
+    torch.cuda.synchronize()
+    # ---- the training benchmark's shape: batch 64 at 800^2, eager forward (+ eager post_process) --------------------------------------------
+    from ryolov4_amd.lib.general import post_process
+    B, SZ = 64, 800
+    imgs, _ = synth_batch(B, SZ, args.nc, False, seed=42)
+    imgs = imgs.to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            return net(imgs, training=False)
+
+    def full():
+        with torch.no_grad():
+            _, inf = net(imgs, training=False)
+            return post_process(inf, CONF, IOU)
+    t_f = timed(fwd, 8, skip=2)
+    t_a = timed(full, 4, skip=1)
+    gf = INFER_GFLOP_PER_IMG[("yolov7", "kfiou", 800)]
+    out["infer_800_b64"] = {"workload": f"yolov7 kfiou nc={args.nc} {SZ}x{SZ}, batch {B}, eager eval forward (+ decode); forward_post = + post_process at conf {CONF} / iou {IOU}",
+                            "forward_ms": round(t_f, 3), "forward_img_s": round(B / t_f * 1e3, 1), "forward_post_ms": round(t_a, 3),
+                            "forward_post_img_s": round(B / t_a * 1e3, 1), "post_process_ms": round(t_a - t_f, 3), "gflop_per_img_forward": gf,
+                            "frac_mfma_forward": round(B / t_f * 1e3 * gf * 1e9 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)}
+    out["wall_s"] = round(time.perf_counter() - t_wall, 2)
+    del net, imgs
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +358,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-b8", action="store_true", help="skip the second regime (8 images per GPU)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop block (the same step fed by DeviceLoader)")
+    ap.add_argument("--no-infer", action="store_true", help="skip the inference blocks (infer_c5: captured 1024^2 x 8 forward + NMS; infer_800_b64)")
     ap.add_argument("--wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="gradient bucket format on xGMI (bf16: fp32 accumulate on receive); auto = parallel.pick_wire: bf16 for <= 16 images per GPU")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo only for plumbing tests")
@@ -364,6 +450,14 @@ def main():
         dt_rank = time.perf_counter() - t0                    # this rank's own K steps (before it waits for the others)
         barrier()
         dt = time.perf_counter() - t0
+        telemetry = None
+        if world > 1:
+            # clocks / power of this rank's GPU UNDER LOAD, outside the timed region: a few more steps are enqueued (asynchronously) and rocm-smi is
+            # read while they run — eight ~1.3 kW GPUs in one chassis is the first thing a SCALE run tests
+            for _ in range(max(4, min(200, int(1.2 / (dt / steps)) + 1))):      # ~1.2 s of queued work: rocm-smi answers in 0.3-0.8 s
+                step()
+            telemetry = parallel.gpu_telemetry(local)
+            barrier()
         coll_ms = dp._reducer.collective_ms() / steps if world > 1 else None
         # ---- the same K steps again with a HIP-event pair around every conv launch (per-kernel durations for the rooflines).  Kept
         # out of the timed region: ~600 event records per step cost ~3 %, the kernels themselves run unchanged (the durations agree
@@ -392,7 +486,8 @@ def main():
             dist.all_gather(every, mine)
             per_rank = {"ms_per_step": [round(float(e[0]), 3) for e in every], "allreduce_ms_per_step": [round(float(e[1]), 3) for e in every],
                         "wire": dp.wire}
-        return dict(dt=dt, dt_inst=dt_inst, timer=timer, loss_first=loss_first, loss_last=loss_last, batch=batch, steps=steps, per_rank=per_rank)
+        return dict(dt=dt, dt_inst=dt_inst, timer=timer, loss_first=loss_first, loss_last=loss_last, batch=batch, steps=steps, per_rank=per_rank,
+                    telemetry=telemetry)
 
     def loader_fed(batch, steps, warmup, budget_frac=None, npool=256):
         """the SAME training step fed by the device-side loader instead of one resident synthetic batch.  A synthetic
@@ -495,22 +590,43 @@ def main():
             elif "wgrad" in k:
                 out["note"] = "side-stream kernel (RYOLO_WGRAD_BLOCKS=512: two 4-wave workgroups per CU); timed alone here"
             return out
-        # dominant kernel class = the largest share of the CHIP's time (seconds x the fraction of the CUs a launch holds: a kernel that runs on
-        # 96 CUs for 10 ms costs the step what a whole-chip kernel costs in 3.75 ms; for whole-chip kernels this is plain time)
-        res = {"roofline": roof(*max(summ.items(), key=lambda kv: kv[1]["chip_seconds"]))}
+        # dominant kernel class, BOTH ways: `roofline` = the largest share of the CHIP's time (seconds x the
+        # fraction of the CUs a launch holds: a kernel that runs on 96 CUs for 10 ms costs the step what a whole-chip kernel costs in 3.75 ms;
+        # for whole-chip kernels this is plain time) — the r05 definition; `roofline_by_wall_time` = the largest sum of launch durations timed
+        # alone — the r01-r04 definition.  In both objects `frac` / `achieved` are against the WHOLE chip's peak over wall time, as the
+        # contract defines them; the occupied-CU view has its own keys (frac_of_occupied_cus, chip_ms_per_step).
+        res = {"roofline": dict(roof(*max(summ.items(), key=lambda kv: kv[1]["chip_seconds"])), selected_by="largest chip time (seconds x CUs held / 256)"),
+               "roofline_by_wall_time": dict(roof(*max(summ.items(), key=lambda kv: kv[1]["seconds"])), selected_by="largest wall time of its launches timed alone")}
         # BASELINE.json north_star quotes the MFMA fraction of the 3x3 convs separately: the halo-patch kernel (fwd + dgrad)
         k33 = "conv3x3_patch_kernel<256x128>"
         if k33 in summ:
             res["roofline_3x3"] = roof(k33, summ[k33])
         if "conv3x3_ws64_kernel" in summ:                       # the 64 -> 64 channel 3x3 layers on the persistent weight-stationary kernel (r04)
             res["roofline_3x3_ws64"] = roof("conv3x3_ws64_kernel", summ["conv3x3_ws64_kernel"])
-        # ... and all 3x3 stride-1 work together (patch kernels fwd + dgrad, ring weight gradient): FLOP-weighted
-        k3 = [k for k in summ if k.startswith("conv3x3_")]
-        if k3:
-            fl, sec = sum(summ[k]["flops"] for k in k3), sum(summ[k]["chip_seconds"] for k in k3)      # (chip time: see `roofline`)
-            res["roofline_3x3_all"] = {"kernels": k3, "bound": "mfma", "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                       "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                       "ms_per_step": round(sec / steps * 1e3, 3)}
+        # ALL 3x3 work — stride 1 AND stride 2, forward + data gradient + weight gradient, whichever kernel serves it (r05 left the seven
+        # stride-2 layers out and divided by chip time only).  Two denominators, both printed:
+        #   frac_wall_alone  FLOPs / sum of the launch durations timed alone (a 96-CU launch counts its full duration)  = `frac`
+        #   frac_chip_time   FLOPs / sum of duration x CUs held / 256 (what the launches cost the two-stream step's resources)
+        fam = m["timer"].summary(by_fam=True)
+        if fam:
+            def fam_block(keys):
+                fl = sum(fam[k]["flops"] for k in keys)
+                sec = sum(fam[k]["seconds"] for k in keys)
+                cs = sum(fam[k]["chip_seconds"] for k in keys)
+                return {"gflop_per_step": round(fl / steps / 1e9, 1), "ms_per_step": round(sec / steps * 1e3, 3), "chip_ms_per_step": round(cs / steps * 1e3, 3),
+                        "frac_wall_alone": round(fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "frac_chip_time": round(fl / cs / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "launches_per_step": sum(fam[k]["launches"] for k in keys) // steps}
+            k3 = sorted(fam)
+            allb = fam_block(k3)
+            res["roofline_3x3_all"] = {"what": "every 3x3 convolution launch of the step (stride 1 and stride 2; forward, data gradient, weight gradient)",
+                                       "bound": "mfma", "achieved": round(allb["frac_wall_alone"] * MFMA_BF16_PEAK_TFLOPS, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": allb["frac_wall_alone"], **allb,
+                                       "stride1": fam_block([k for k in k3 if k[0] == "3x3s1"]) if any(k[0] == "3x3s1" for k in k3) else None,
+                                       "stride2": fam_block([k for k in k3 if k[0] == "3x3s2"]) if any(k[0] == "3x3s2" for k in k3) else None,
+                                       "kernels": {f"{f}:{k}": {"ms_per_step": round(v["seconds"] / steps * 1e3, 3), "chip_ms_per_step": round(v["chip_seconds"] / steps * 1e3, 3),
+                                                                "tflops": round(v["flops"] / v["seconds"] / 1e12, 1), "launches_per_step": v["launches"] // steps}
+                                                   for (f, k), v in sorted(fam.items())},
+                                       "mfma_busy_counters": MFMA_BUSY_PROFILE if os.path.exists(os.path.join(ROOT, MFMA_BUSY_PROFILE)) else None}
         # the pointwise class by regime: K <= 256 layers are memory streams (HBM roof), K > 256 layers sit on the MFMA side
         split = m["timer"].summary(by_sub=True)
         if split:
@@ -526,12 +642,14 @@ def main():
                                "chip_ms_per_step": round(vv["chip_seconds"] / steps * 1e3, 3), "launches_per_step": vv["launches"] // steps}
                           for kk, vv in summ.items()}
         wg = [kk for kk in summ if "wgrad" in kk]
-        if wg:                                      # all weight gradients together, in chip time (what the class costs the step's resources)
+        if wg:                                      # all weight gradients together: wall time alone (`frac`, the contract's basis) and chip time
             fl, cs = sum(summ[kk]["flops"] for kk in wg), sum(summ[kk]["chip_seconds"] for kk in wg)
-            res["roofline_wgrad_all"] = {"kernels": wg, "bound": "mfma", "achieved": round(fl / cs / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": round(fl / cs / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "chip_ms_per_step": round(cs / steps * 1e3, 3),
-                                         "ms_per_step_alone": round(sum(summ[kk]["seconds"] for kk in wg) / steps * 1e3, 3),
-                                         "what": "FLOPs of every weight-gradient launch over their chip time (seconds x CUs held / 256)"}
+            sec = sum(summ[kk]["seconds"] for kk in wg)
+            res["roofline_wgrad_all"] = {"kernels": wg, "bound": "mfma", "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "ms_per_step": round(sec / steps * 1e3, 3),
+                                         "frac_chip_time": round(fl / cs / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "chip_ms_per_step": round(cs / steps * 1e3, 3),
+                                         "what": "FLOPs of every weight-gradient launch; frac = over their wall time timed alone (whole-chip peak), "
+                                                 "frac_chip_time = over seconds x CUs held / 256 (the side stream's kernels hold part of the chip)"}
         return res
 
     torch.cuda.reset_peak_memory_stats(dev)
@@ -565,6 +683,8 @@ def main():
         dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         affs = [None] * world
         dist.all_gather_object(affs, aff)
+        tele = [None] * world
+        dist.all_gather_object(tele, m.get("telemetry"))
 
         def spread(pr):
             """What the first SCALE run needs to explain itself: every rank's own step time (before it waits for the others) and the time
@@ -580,6 +700,9 @@ def main():
                      "grad_wire": parallel.pick_wire(args.batch, world, args.wire), "grad_wire_rule": args.wire,
                      "per_rank": spread(m["per_rank"]), "per_rank_b8": spread(m8["per_rank"]) if m8 is not None else None,
                      "affinity": [{"rank": r, **a} for r, a in enumerate(affs)], "rccl_env": parallel.rccl_env(),
+                     # how the 256 CUs are shared: weight-gradient side stream (CU-exclusive workgroups) / RCCL channels / main stream (parallel.plan_partition)
+                     "cu_partition": parallel.partition(),
+                     "gpu_telemetry_by_rank": tele,      # rocm-smi clocks + socket power of every rank's GPU, sampled while its steps were running
                      "note": "allreduce_ms = time of the bucket collectives on their side stream (overlapped with backward); the part of it the step "
                              "actually waits for is ms_per_step(N) - ms_per_step(1)"}
     if rank != 0:
@@ -640,6 +763,11 @@ def main():
                                      "on the loader's own stream under the previous step) from a synthetic 256-image 1024x1024 split; `value` above stays the "
                                      "synthetic resident-batch number; image decode is an array lookup here (no files on the GPU box)", **fed}
     # secondary metric of BASELINE.json: rotated-NMS latency at 10k boxes (device time; both sets, both thresholds, with and without the sort)
+    if world == 1 and not args.no_infer and (args.ver, args.mode) == ("yolov7", "kfiou"):
+        try:
+            out.update(infer_block(args, dev))
+        except RuntimeError as e:                     # never lose the training line to the inference block
+            out["infer_c5"] = {"error": str(e)[:300]}
     out["nms"] = nms_block(dev)
     out["nms_ms_10k_boxes"] = out["nms"]["mask_reduce_ms"]["C_0.65"]
     out["nms_ms_10k_boxes_end_to_end_worst"] = max(out["nms"]["end_to_end_ms"].values())

@@ -121,19 +121,26 @@ class BaseDataset:
         self._pool = self._labels = None
         self.pool_budget_bytes, self.pool_slab_bytes, self.decode_workers, self.share_pool = pool_budget_bytes, pool_slab_bytes, decode_workers, share_pool
 
-    def shard(self, rank, world_size):
+    def shard(self, rank, world_size, pad=None):
         """Data parallel: this rank keeps every world_size-th file (and draws its mosaic partners among them), so the pool of a rank holds
-        its shard only.  Call before the first batch."""
+        its shard only.  Call before the first batch.
+        pad (default: self.augment, i.e. TRAINING datasets): every rank gets EXACTLY ceil(n / world) files (torch's DistributedSampler
+        convention: the short shards wrap around to the head of the list): ranks then run the same number of batches of the same sizes — a
+        rank with one batch more would sit in a gradient all-reduce that has no peer (n = 129, world 2, batch 64: 2 batches vs 1), and unequal
+        last batches would be weighted equally by grad_scale = 1 / world.
+        pad=False (EVALUATION datasets, augment=False: test.py:167-222 scores every image once): exact disjoint [rank::world] shards — a
+        wrapped-around image would put its detections and its ground truth into the statistics twice and skew mAP; evaluation has no
+        per-batch collective, so unequal shard lengths are harmless there."""
         if self._pool is not None:
             raise RuntimeError("BaseDataset.shard: call before the first batch is assembled")
-        # every rank gets EXACTLY ceil(n / world) files (torch's DistributedSampler convention: the short shards wrap around to the head of
-        # the list): ranks then run the same number of batches of the same sizes — a rank with one batch more would sit in a gradient
-        # all-reduce that has no peer (n = 129, world 2, batch 64: 2 batches vs 1), and unequal last batches would be weighted equally by
-        # grad_scale = 1 / world
+        pad = self.augment if pad is None else pad
         n = len(self.img_files)
         if n:
-            per = -(-n // world_size)
-            idx = [(rank + k * world_size) % n for k in range(per)]
+            if pad:
+                per = -(-n // world_size)
+                idx = [(rank + k * world_size) % n for k in range(per)]
+            else:
+                idx = list(range(rank, n, world_size))
             self.img_files, self.label_files = [self.img_files[i] for i in idx], [self.label_files[i] for i in idx]
         return self
 
@@ -344,10 +351,10 @@ class DeviceLoader:
     launches run on the side stream WHILE step k occupies the compute stream; the compute stream only waits for the batch's event.
     rank / world_size: data parallel — the rank iterates (and pools) its shard of the files (BaseDataset.shard)."""
 
-    def __init__(self, dataset, batch_size, shuffle, side_stream=True, rank=0, world_size=1):
+    def __init__(self, dataset, batch_size, shuffle, side_stream=True, rank=0, world_size=1, pad_shards=None):
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         if world_size > 1:
-            dataset.shard(rank, world_size)
+            dataset.shard(rank, world_size, pad=pad_shards)      # None: padded for training (augment) datasets, exact for evaluation ones
         self._side = torch.cuda.Stream(device=dataset.device) if side_stream and dataset.device.type == "cuda" and torch.cuda.is_available() else None
 
     def __len__(self):

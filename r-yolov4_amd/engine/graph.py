@@ -12,6 +12,7 @@ PyTorch only owns the memory (torch.empty) and the stream.
 """
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -26,6 +27,11 @@ _HEAD_SPARSE = os.environ.get("RYOLO_HEAD_SPARSE", "1") != "0"
 _HEAD_FUSED = os.environ.get("RYOLO_HEAD_FUSED", "1") != "0"
 _HEAD_FOLD_A = os.environ.get("RYOLO_HEAD_FOLD_A", "1") != "0"
 _DEBUG_SKIP_SIDE = os.environ.get("RYOLO_DEBUG_SKIP_SIDE") == "1"     # tools only: never set in a run that reports numbers
+if _DEBUG_SKIP_SIDE:
+    import warnings
+    warnings.warn("RYOLO_DEBUG_SKIP_SIDE=1: every weight-gradient launch is SKIPPED — gradients of this process are garbage; "
+                  "timing diagnostic only (tools/), never for training or for a reported number", RuntimeWarning, stacklevel=1)
+    print("ryolov4_amd: RYOLO_DEBUG_SKIP_SIDE=1 — weight gradients are NOT computed in this process (diagnostic mode)", file=sys.stderr, flush=True)
 
 class Buf:
     """[N*H*W, C] bf16 activation buffer (NHWC, channel stride = C) and, lazily, its gradient twin."""
@@ -222,8 +228,24 @@ class Graph:
 
     @staticmethod
     def _describe(name, args):
-        """(kernel class, algorithmic FLOPs, algorithmic HBM bytes) of a launch — used by bench.py's live roofline accounting.
-        Bytes = every operand element once: gathered input + weights + output (twice for accumulate epilogues)."""
+        """(kernel class, algorithmic FLOPs, algorithmic HBM bytes, pointwise regime | None, CUs held | None, layer family | None) of a
+        launch — used by bench.py's live roofline accounting.  Bytes = every operand element once: gathered input + weights + output
+        (twice for accumulate epilogues).  Layer family: "3x3s1" / "3x3s2" for the forward, data-gradient and weight-gradient launches of
+        3x3 convolutions (BASELINE's north star prices ALL 3x3 work, whichever kernel serves it)."""
+        d = Graph._describe_kernel(name, args)
+        if len(d) >= 3 and d[1]:
+            fam = None
+            p = args[0]
+            if name == "ryolo_conv_gemm" and (p.wtaps == 9 or p.s2d_cin):
+                # forward: sh == 2; data gradient of a stride-2 layer: four output-parity classes (oh_mul == 2) or the space-to-depth GEMM
+                fam = "3x3s2" if (p.sh == 2 or p.oh_mul == 2 or p.s2d_cin) else "3x3s1"
+            elif name == "ryolo_conv_wgrad" and p.ntaps == 9:
+                fam = "3x3s2" if p.sh == 2 else "3x3s1"
+            d = tuple(d) + (None,) * (5 - len(d)) + (fam,)
+        return d
+
+    @staticmethod
+    def _describe_kernel(name, args):
         if name == "ryolo_conv_gemm":
             p = args[0]
             fl = 0
@@ -1035,7 +1057,11 @@ class Graph:
         M = x.M
         if fused:
             return self._head_fused(conv, pk, x, xin, na, attrs, och, implicit_a, implicit_m, sparse)
-        assert pk.get("wd_scale") is None, "head planned both with and without the ImplicitM-carrying data-gradient image"
+        if self.training and pk.get("wd_scale") is not None:
+            # the packed data-gradient image of this conv already carries ImplicitM (a fused TRAINING plan made it so): the unfused backward
+            # below would apply ImplicitM a second time in ryolo_head_finish_bwd.  Inference plans never read Wd and may mix freely.
+            raise RuntimeError("ryolov4_amd: a detection head was planned for training both with and without the fused (ImplicitM-carrying) "
+                               "data-gradient image; use one RYOLO_HEAD_FUSED setting per runtime")
         pre = self.f32(M, coutp)
         self._gemm(self.fwd, xin, xin.ptr(), pk["wf"], cout, 1, conv.in_channels, x.H, x.W, 1, [([(0, 0, 0)], 0, 0)], S.EPI_F32_BIAS,
                    pre.data_ptr(), coutp, bias=conv.bias.data_ptr())

@@ -16,6 +16,11 @@ def _compact_head_grad(t):
     return compact_head_grad(t)
 
 
+def _clear_handoff():
+    from ..lib.loss import clear_handoff
+    clear_handoff()
+
+
 def _register_head_obj(heads):
     from ..lib.loss import register_head_obj
     for h in heads:
@@ -314,6 +319,7 @@ class NetFunction(torch.autograd.Function):
         hook = rt.model._grad_hook
         after = hook.bucket_hooks(rt, g) if hook is not None and hasattr(hook, "bucket_hooks") else None
         g.run(g.bwd, g.timer, after)
+        _clear_handoff()                                 # (the compact forms were consumed above; nothing keeps last step's gradient maps alive)
         if hook is not None:
             hook(rt)
         return None, None, None, None

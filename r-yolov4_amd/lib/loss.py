@@ -46,11 +46,19 @@ def head_obj_logits(o, och):
 
 def compact_head_grad(t):
     """(objgrad tensor, owner-grid pointer, objectness channel) of the dense gradient map `t` if `t` is — same storage, untouched — one of the
-    maps the last loss call produced, else None."""
-    h = _HANDOFF.get(t.data_ptr())
+    maps the last loss call produced, else None.  The entry is CONSUMED: the table drops its references (dense map, compact arrays, loss
+    workspace — 1.3 GB at the benchmark size) as soon as the one consumer they were left for has taken them, instead of keeping them until
+    the next loss backward.  In-place edits of the map through torch are detected by the version counter; raw-pointer writes into it from
+    outside torch are NOT supported (nothing bumps the counter) — a caller that edits the map that way must pass a different tensor."""
+    h = _HANDOFF.pop(t.data_ptr(), None)
     if h is None or t.shape != h[0].shape or t._version != h[5] or h[0]._version != h[5]:     # (in-place edits through torch bump the version)
         return None
     return h[1], h[2], h[3], h[4]
+
+
+def clear_handoff():
+    """Engine side, at the end of NetFunction.backward: whatever was not consumed (a head whose gradient was None, a foreign consumer) is dropped."""
+    _HANDOFF.clear()
 
 
 class _LossFn(torch.autograd.Function):

@@ -90,10 +90,86 @@ def bind_rank(local_rank, n_local, device_of_rank=None, max_threads=16):
             "host_threads": threads, "decode_threads": max(1, min(8, len(plan["cpus"]) - 1)), "source": plan["source"]}
 
 
+SIDE_CUS_SINGLE = 96            # CUs the CU-exclusive 8-wave weight-gradient kernels hold when no collective runs beside them
+RCCL_CHANNELS_DEFAULT = 8       # one ring channel per XCD: each channel is ONE workgroup of the collective's kernel
+
+
+def plan_partition(world, channels=None, side_cus=None):
+    """How the 256 CUs are shared in a data-parallel step (pure function: every rank computes the same answer without talking).
+
+    Single GPU: the weight-gradient side stream owns SIDE_CUS_SINGLE = 96 CUs (one CU-exclusive 8-wave workgroup each: RYOLO_W3_V8_BLOCKS,
+    RYOLO_WGRAD_8W_BLOCKS), the main stream the other 160.  With world > 1 the bucket all-reduces run on a THIRD stream while backward is
+    still going, and an RCCL channel is a workgroup that needs a CU slot: behind 96 CU-exclusive workgroups + a main stream that fills the
+    other 160 CUs a collective would queue until a weight-gradient launch drains.  So the side partition shrinks by the channel count:
+    side = 96 - channels (88 for the default 8 channels), and the channel count is pinned (NCCL_MIN = NCCL_MAX) so that the sizing holds.
+    Explicit RYOLO_W3_V8_BLOCKS / RYOLO_WGRAD_8W_BLOCKS / RYOLO_RCCL_CHANNELS in the environment win over the rule."""
+    if world <= 1:
+        return {"world": world, "rccl_channels": 0, "side_cus": SIDE_CUS_SINGLE if side_cus is None else int(side_cus),
+                "main_cus": 256 - (SIDE_CUS_SINGLE if side_cus is None else int(side_cus))}
+    ch = RCCL_CHANNELS_DEFAULT if channels is None else max(1, min(32, int(channels)))
+    side = max(32, SIDE_CUS_SINGLE - ch) if side_cus is None else int(side_cus)
+    return {"world": world, "rccl_channels": ch, "side_cus": side, "main_cus": 256 - side - ch}
+
+
+_PARTITION = {}
+
+
+def apply_partition(world):
+    """Put plan_partition(world) into the environment BEFORE the HIP library reads its grid knobs (function-local statics, first plan) and
+    before the communicator exists.  Values already set by the caller are kept and reported as such."""
+    env = os.environ
+    ch_req = env.get("RYOLO_RCCL_CHANNELS")
+    plan = plan_partition(world, channels=int(ch_req) if ch_req else None)
+    src = {}
+    if world > 1:
+        for k in ("RYOLO_W3_V8_BLOCKS", "RYOLO_WGRAD_8W_BLOCKS"):
+            src[k] = "environment" if k in env else "rule"
+            env.setdefault(k, str(plan["side_cus"]))
+        env["RYOLO_RCCL_CHANNELS"] = str(plan["rccl_channels"])
+    w3 = int(env.get("RYOLO_W3_V8_BLOCKS", SIDE_CUS_SINGLE))
+    w1 = int(env.get("RYOLO_WGRAD_8W_BLOCKS", SIDE_CUS_SINGLE))
+    _PARTITION.clear()
+    _PARTITION.update(plan, w3_v8_blocks=w3, wgrad_8w_blocks=w1, set_by=src,
+                      rule="side = 96 - rccl_channels when world > 1 (plan_partition); explicit RYOLO_* values win")
+    return dict(_PARTITION)
+
+
+def partition():
+    """What apply_partition decided for this process (bench.py prints it in the `distributed` block)."""
+    return dict(_PARTITION) if _PARTITION else apply_partition(int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def gpu_telemetry(index=0, timeout=10.0):
+    """Clocks and socket power of one GPU as rocm-smi reports them right now (bench.py samples every rank once, in the middle of a run of
+    steps: eight GPUs in one chassis at ~1.3 kW each is the first thing a SCALE run tests).  Never raises: {"error": ...} when rocm-smi is
+    absent or does not answer in `timeout` seconds."""
+    import json
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "-d", str(index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=timeout)
+        doc = json.loads(r.stdout[r.stdout.index("{"):])
+        card = next(iter(doc.values()))
+        out = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "level" in kl:
+                out["sclk"] = v
+            elif "mclk" in kl and "level" in kl:
+                out["mclk"] = v
+            elif "power" in kl and "(w)" in kl:
+                out["power_w"] = float(v)
+        return out or {"error": "no clock / power fields in rocm-smi --json", "keys": sorted(card)[:12]}
+    except Exception as e:                                                   # noqa: BLE001 (telemetry must never take a bench run down)
+        return {"error": f"{type(e).__name__}: {str(e)[:120]}"}
+
+
 def rccl_env():
     """RCCL knobs that matter beside two compute streams: the channel count bounds how many CUs the collective's kernels occupy while
     backward is still running (each channel is one workgroup).  RYOLO_RCCL_CHANNELS=n sets NCCL_MIN/MAX_NCHANNELS before the communicator
-    exists; whatever is in effect is reported by bench.py."""
+    exists (default when world > 1: 8, with the weight-gradient partition shrunk to match — plan_partition); whatever is in effect is
+    reported by bench.py."""
     n = os.environ.get("RYOLO_RCCL_CHANNELS")
     if n:
         os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(int(n))
@@ -114,6 +190,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    apply_partition(world)                       # CU shares of the two compute streams and the collective (before the library plans anything)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

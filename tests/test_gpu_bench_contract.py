@@ -85,6 +85,14 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
         from ryolov4_amd.parallel import _parse_cpulist
         assert set(_parse_cpulist(af[0]["cpus"])).isdisjoint(_parse_cpulist(af[1]["cpus"]))
     assert isinstance(di["rccl_env"], dict)
+    # round 6: with world > 1 the CU-exclusive weight-gradient partition shrinks by the RCCL channel count, the channel
+    # count is pinned, and every rank's GPU clocks / socket power (rocm-smi, sampled under load) are in the line
+    cp = di["cu_partition"]
+    assert cp["world"] == 2 and cp["rccl_channels"] == 8 and cp["side_cus"] == 88 and cp["w3_v8_blocks"] == 88 and cp["wgrad_8w_blocks"] == 88
+    assert cp["side_cus"] + cp["main_cus"] + cp["rccl_channels"] == 256
+    assert di["rccl_env"].get("NCCL_MIN_NCHANNELS") == di["rccl_env"].get("NCCL_MAX_NCHANNELS") == "8"
+    tele = di["gpu_telemetry_by_rank"]
+    assert len(tele) == 2 and all(isinstance(t, dict) and ("error" in t or "power_w" in t or "sclk" in t) for t in tele), tele
 
 
 def test_bench_gpus_n_without_enough_devices_fails_loudly():

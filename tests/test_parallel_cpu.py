@@ -304,7 +304,7 @@ def test_shards_are_equal_when_the_file_count_does_not_divide():
     for n, world, bs in ((129, 2, 64), (10, 4, 3), (7, 8, 2), (64, 8, 8)):
         lens, seen, nb = [], set(), []
         for rank in range(world):
-            ds = BaseDataset(hyp, 64, False, False, False, device="cpu")
+            ds = BaseDataset(hyp, 64, True, False, False, device="cpu")          # augment=True: a TRAINING dataset
             ds.img_files = [f"img{i}" for i in range(n)]
             ds.label_files = [f"lab{i}" for i in range(n)]
             ld = DeviceLoader(ds, bs, shuffle=False, side_stream=False, rank=rank, world_size=world)
@@ -316,6 +316,26 @@ def test_shards_are_equal_when_the_file_count_does_not_divide():
         assert seen == {f"img{i}" for i in range(n)}
 
 
+def test_evaluation_shards_are_disjoint_and_exact():
+    """a sharded EVALUATION set (augment=False, test.py:167-222) must hold every image exactly once over all ranks — a
+    wrapped-around duplicate would count its detections and ground truth twice in the mAP statistics.  Training sets keep the padding."""
+    from ryolov4_amd.datasets.base_dataset import BaseDataset, DeviceLoader
+    hyp = {"hsv_h": 0, "hsv_s": 0, "hsv_v": 0, "rotate": 0, "translate": 0, "scale": 0, "flipud": 0, "fliplr": 0, "mosaic": 0, "mixup": 0}
+    for n, world in ((129, 2), (10, 4), (7, 8), (64, 8)):
+        files = []
+        for rank in range(world):
+            ds = BaseDataset(hyp, 64, False, False, False, device="cpu")         # augment=False: an evaluation dataset
+            ds.img_files = [f"img{i}" for i in range(n)]
+            ds.label_files = [f"lab{i}" for i in range(n)]
+            DeviceLoader(ds, 4, shuffle=False, side_stream=False, rank=rank, world_size=world)
+            assert [f.replace("img", "lab") for f in ds.img_files] == ds.label_files
+            files += ds.img_files
+        assert sorted(files) == sorted(f"img{i}" for i in range(n)), (n, world)          # every image once, none twice
+    ds = BaseDataset(hyp, 64, False, False, False, device="cpu")
+    ds.img_files, ds.label_files = [f"img{i}" for i in range(5)], [f"lab{i}" for i in range(5)]
+    assert len(ds.shard(1, 2, pad=True)) == 3                                           # the explicit override still pads
+
+
 def _uneven_worker(rank, world, port, q):
     """The loop of train.py over a DeviceLoader-shaped iteration with one all-reduce per batch: with unequal shards this deadlocks."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -323,7 +343,7 @@ def _uneven_worker(rank, world, port, q):
     from ryolov4_amd.datasets.base_dataset import BaseDataset, DeviceLoader
     parallel.init_from_env(backend="gloo")
     hyp = {"hsv_h": 0, "hsv_s": 0, "hsv_v": 0, "rotate": 0, "translate": 0, "scale": 0, "flipud": 0, "fliplr": 0, "mosaic": 0, "mixup": 0}
-    ds = BaseDataset(hyp, 64, False, False, False, device="cpu")
+    ds = BaseDataset(hyp, 64, True, False, False, device="cpu")          # a training dataset (augment=True): padded, equal shards
     ds.img_files = [f"img{i}" for i in range(129)]
     ds.label_files = list(ds.img_files)
     ld = DeviceLoader(ds, 64, shuffle=False, side_stream=False, rank=rank, world_size=world)
@@ -348,3 +368,41 @@ def test_uneven_file_count_does_not_hang_the_allreduce_loop():
         p.join(30)
         assert p.exitcode == 0
     assert res[0] == res[1] == [64, 1]
+
+
+# ---- round 6: the side-stream partition shrinks by the RCCL channel count when world > 1 ----------------------------------
+def test_partition_rule_shrinks_the_side_stream_by_the_channel_count(monkeypatch):
+    from ryolov4_amd import parallel
+    one = parallel.plan_partition(1)
+    assert one["side_cus"] == 96 and one["main_cus"] == 160 and one["rccl_channels"] == 0
+    for world in (2, 4, 8):
+        p = parallel.plan_partition(world)
+        assert p["rccl_channels"] == 8 and p["side_cus"] == 88 and p["main_cus"] == 160
+        assert p["side_cus"] + p["main_cus"] + p["rccl_channels"] == 256                 # collectives never queue behind CU-exclusive workgroups
+    assert parallel.plan_partition(8, channels=16)["side_cus"] == 80
+    assert parallel.plan_partition(8, channels=4)["side_cus"] == 92
+    assert parallel.plan_partition(8, channels=200)["rccl_channels"] == 32              # clamped
+    assert parallel.plan_partition(8, channels=32)["side_cus"] == 64
+    # applied to the environment the HIP library reads its grids from; explicit values win and are reported as such
+    for k in ("RYOLO_W3_V8_BLOCKS", "RYOLO_WGRAD_8W_BLOCKS", "RYOLO_RCCL_CHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    got = parallel.apply_partition(8)
+    assert os.environ["RYOLO_W3_V8_BLOCKS"] == os.environ["RYOLO_WGRAD_8W_BLOCKS"] == "88" and os.environ["RYOLO_RCCL_CHANNELS"] == "8"
+    assert got["w3_v8_blocks"] == got["wgrad_8w_blocks"] == 88 and got["set_by"] == {"RYOLO_W3_V8_BLOCKS": "rule", "RYOLO_WGRAD_8W_BLOCKS": "rule"}
+    assert parallel.rccl_env()["NCCL_MIN_NCHANNELS"] == parallel.rccl_env()["NCCL_MAX_NCHANNELS"] == "8"
+    monkeypatch.setenv("RYOLO_W3_V8_BLOCKS", "64")
+    monkeypatch.delenv("RYOLO_WGRAD_8W_BLOCKS")
+    monkeypatch.setenv("RYOLO_RCCL_CHANNELS", "12")
+    got = parallel.apply_partition(4)
+    assert got["w3_v8_blocks"] == 64 and got["wgrad_8w_blocks"] == 84 and got["rccl_channels"] == 12
+    assert got["set_by"] == {"RYOLO_W3_V8_BLOCKS": "environment", "RYOLO_WGRAD_8W_BLOCKS": "rule"}
+    for k in ("RYOLO_W3_V8_BLOCKS", "RYOLO_WGRAD_8W_BLOCKS", "RYOLO_RCCL_CHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    got = parallel.apply_partition(1)                                                    # single GPU: nothing is written, the library defaults hold
+    assert "RYOLO_W3_V8_BLOCKS" not in os.environ and got["side_cus"] == 96 and got["w3_v8_blocks"] == 96
+
+
+def test_gpu_telemetry_never_raises():
+    from ryolov4_amd import parallel
+    t = parallel.gpu_telemetry(0, timeout=5.0)
+    assert isinstance(t, dict) and (("error" in t) or ("power_w" in t or "sclk" in t))
