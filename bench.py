@@ -98,7 +98,6 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
     "conv_wgrad_kernel<128>": r"conv_wgrad_kernel<128, |wgrad1x1_dma_kernel|wgrad_taps_dma_kernel",   # (register-staged + the LDS-DMA pointwise / tapped forms)
     "conv_wgrad_kernel<64>": r"conv_wgrad_kernel<64, ",
     "wgrad1x1_8w_kernel<256x256>": r"wgrad1x1_8w_kernel",
-    "conv3x3s2_wgrad8_kernel": r"conv3x3s2_wgrad8_kernel",                            # 8-wave parity-plane ring weight gradient of the stride-2 3x3 layers                              # 8-wave pointwise weight gradient (wgrad1x1_8w.hip)
     "conv3x3_wgrad_kernel<128x9x32>": r"conv3x3_wgrad(64|8)?_kernel<",
 }
 
@@ -344,6 +343,26 @@ def infer_block(args, dev):
     return out
 
 
+def infer_child(args, limit=300):
+    """The inference blocks in a process of their own, while this one sits idle (its streams synchronized): a captured hipGraph replays
+    measurably slower beside another runtime's streams in the same process (the training runtime's two side streams + the loader's stream + the
+    inference runtime's own: past the process's hardware queues — first r06 run: C5 9.2 ms per batch in-process, 6.8-7.0 ms alone).  Never
+    loses the training line: errors come back as {"infer_c5": {"error": ...}}."""
+    import subprocess
+    torch.cuda.synchronize()
+    cmd = [sys.executable, os.path.abspath(__file__), "--infer-only", "--nc", str(args.nc), "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=limit)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("INFERBLOCK ")]
+        if r.returncode == 0 and line:
+            d = json.loads(line[-1][len("INFERBLOCK "):])
+            d["infer_process"] = "child process of bench.py (python bench.py --infer-only), run after the training blocks with this process idle"
+            return d
+        return {"infer_c5": {"error": (r.stderr or r.stdout)[-300:]}}
+    except subprocess.TimeoutExpired:
+        return {"infer_c5": {"error": f"inference child did not finish within {limit} s"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,6 +378,7 @@ def main():
     ap.add_argument("--no-b8", action="store_true", help="skip the second regime (8 images per GPU)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-in-the-loop block (the same step fed by DeviceLoader)")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference blocks (infer_c5: captured 1024^2 x 8 forward + NMS; infer_800_b64)")
+    ap.add_argument("--infer-only", action="store_true", help="internal: run only the inference blocks and print them (the child process of the default run)")
     ap.add_argument("--wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="gradient bucket format on xGMI (bf16: fp32 accumulate on receive); auto = parallel.pick_wire: bf16 for <= 16 images per GPU")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo only for plumbing tests")
@@ -382,6 +402,10 @@ def main():
     from ryolov4_amd import parallel
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    if args.infer_only:
+        torch.cuda.set_device(0)
+        print("INFERBLOCK " + json.dumps(infer_block(args, torch.device("cuda", 0))), flush=True)
+        return
     local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)                       # before the communicator is created: one process per GPU
     dev = torch.device("cuda", local)
@@ -764,10 +788,7 @@ def main():
                                      "synthetic resident-batch number; image decode is an array lookup here (no files on the GPU box)", **fed}
     # secondary metric of BASELINE.json: rotated-NMS latency at 10k boxes (device time; both sets, both thresholds, with and without the sort)
     if world == 1 and not args.no_infer and (args.ver, args.mode) == ("yolov7", "kfiou"):
-        try:
-            out.update(infer_block(args, dev))
-        except RuntimeError as e:                     # never lose the training line to the inference block
-            out["infer_c5"] = {"error": str(e)[:300]}
+        out.update(infer_child(args))
     out["nms"] = nms_block(dev)
     out["nms_ms_10k_boxes"] = out["nms"]["mask_reduce_ms"]["C_0.65"]
     out["nms_ms_10k_boxes_end_to_end_worst"] = max(out["nms"]["end_to_end_ms"].values())

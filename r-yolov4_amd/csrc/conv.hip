@@ -585,10 +585,8 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
                         // folded BatchNorm (running statistics) + activation on the fp32 accumulator (columns >= Nout are never stored)
                         const float4 sc = *reinterpret_cast<const float4*>(cscale + wn * WTN + c0);
                         const float4 sf = *reinterpret_cast<const float4*>(cshift + wn * WTN + c0);
-                        v[0] = act_fwd(v[0] * sc.x + sf.x, p.act);
-                        v[1] = act_fwd(v[1] * sc.y + sf.y, p.act);
-                        v[2] = act_fwd(v[2] * sc.z + sf.z, p.act);
-                        v[3] = act_fwd(v[3] * sc.w + sf.w, p.act);
+                        const float sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sf4[4] = {sf.x, sf.y, sf.z, sf.w};
+                        act_affine_quad(v, sc4, sf4, p.act);
                     }
                     *reinterpret_cast<uint2*>(stage + (i * 32 + (lane & 31)) * EP_LD + c0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
@@ -1674,9 +1672,7 @@ extern "C" int ryolo_conv_wgrad_plan(const WgradParams* pp, int* splitk, size_t*
     else {
         int sk8, gx8, gy8;
         int64_t kc8;
-        int sl2, wg2;
         if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) p.splitk = sk8;      // wide pointwise layers: 8-wave 256 x 256 tiles (wgrad1x1_8w.hip)
-        else if (ws2_geometry(p, &sl2, &wg2)) p.splitk = sl2;              // 3x3 stride-2 layers: parity-plane rings (conv3x3s2_wgrad8.hip)
     }
     *splitk = p.splitk;
     *workspace_bytes = (size_t)p.splitk * p.Cout * p.ntaps * p.Cin * sizeof(float);
@@ -1697,8 +1693,8 @@ static bool wgrad_taps_dma(const WgradParams& p, int bm)
 }
 
 // 0: generic split-K kernels (conv.hip: register-staged, or the LDS-DMA pointwise form), 1: 3x3 stride-1 halo-ring kernel (conv3x3.hip),
-// 2: tapped LDS-DMA kernel (conv.hip), 3: the 8-wave 256 x 256 pointwise kernel (wgrad1x1_8w.hip), 4: the 8-wave parity-plane ring kernel for
-// 3x3 stride-2 layers (conv3x3s2_wgrad8.hip) — what ryolo_conv_wgrad will launch
+// 2: tapped LDS-DMA kernel (conv.hip), 3: the 8-wave 256 x 256 pointwise kernel (wgrad1x1_8w.hip) — what ryolo_conv_wgrad will launch
+// (4 was the parity-plane ring kernel for 3x3 stride-2 layers, r05: parity-green, step-neutral, retired in r06 — git history keeps it)
 extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
 {
     if (!pp || !kernel) return RY_ERR_ARG;
@@ -1710,8 +1706,6 @@ extern "C" int ryolo_conv_wgrad_kernel(const WgradParams* pp, int* kernel)
         int sk8, gx8, gy8;
         int64_t kc8;
         if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) { *kernel = 3; return RY_OK; }
-        int sl2, wg2;
-        if (ws2_geometry(p, &sl2, &wg2)) { *kernel = 4; return RY_OK; }
     }
     int bm, gx, gy;
     if (wgrad_geometry(p, bm, gx, gy) == RY_OK && wgrad_taps_dma(p, bm)) *kernel = 2;
@@ -1738,12 +1732,6 @@ extern "C" int ryolo_conv_wgrad_grid(const WgradParams* pp, int* workgroups, int
     int64_t kc8;
     if (w1x8_geometry(p, &sk8, &kc8, &gx8, &gy8)) {
         *workgroups = gx8 * gy8 * sk8;
-        *waves = 8;
-        return RY_OK;
-    }
-    int sl2, wg2;
-    if (ws2_geometry(p, &sl2, &wg2)) {
-        *workgroups = wg2;
         *waves = 8;
         return RY_OK;
     }
@@ -1776,14 +1764,6 @@ extern "C" int ryolo_conv_wgrad(const WgradParams* pp, hipStream_t stream)
             const int rc8 = w1x8_launch(p, stream);
             if (rc8) return rc8;
             launch_wgrad_reduce(p, sk8, stream);
-            RY_CHECK_LAUNCH();
-            return RY_OK;
-        }
-        int sl2, wg2;
-        if (ws2_geometry(p, &sl2, &wg2)) {
-            const int rc2 = ws2_launch(p, stream);
-            if (rc2) return rc2;
-            launch_wgrad_reduce(p, sl2, stream);
             RY_CHECK_LAUNCH();
             return RY_OK;
         }

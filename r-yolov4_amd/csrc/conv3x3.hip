@@ -379,10 +379,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                     if constexpr (EPI == EPI_AFFINE_ACT) {
                         const float4 sc = *reinterpret_cast<const float4*>(cscale + wn * WTN + c0);     // (columns >= Nout are never stored)
                         const float4 sh = *reinterpret_cast<const float4*>(cshift + wn * WTN + c0);
-                        v[0] = act_fwd(v[0] * sc.x + sh.x, p.act);
-                        v[1] = act_fwd(v[1] * sc.y + sh.y, p.act);
-                        v[2] = act_fwd(v[2] * sc.z + sh.z, p.act);
-                        v[3] = act_fwd(v[3] * sc.w + sh.w, p.act);
+                        const float sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sf4[4] = {sh.x, sh.y, sh.z, sh.w};
+                        act_affine_quad(v, sc4, sf4, p.act);
                     }
                     const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     *reinterpret_cast<uint2*>(stage + (ii * 32 + (lane & 31)) * EP_LD + c0) = w;

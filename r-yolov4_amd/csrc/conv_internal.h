@@ -25,6 +25,34 @@ __device__ __forceinline__ float act_fwd(float u, int act)
     return u;
 }
 
+// Folded BatchNorm + activation of FOUR accumulator values (inference epilogues, EPI_AFFINE_ACT): v[q] = act(v[q] * sc[q] + sf[q]).  `act` is
+// wave-uniform; called per element through act_fwd every value paid the whole `if` chain (three scalar compare + branch pairs, and Mish's
+// `u > 20` early return as a DIVERGENT branch: 1 008 s_cbranch in the affine instantiation of the persistent pointwise kernel, r06 ISA count).  Here
+// the chain is walked once per quad and every arm is branch-free; the values are bit-identical to act_fwd's (same expressions, the Mish
+// cut-off as a select).
+template <int N> __device__ __forceinline__ void act_affine_vec(float (&v)[N], const float (&sc)[N], const float (&sf)[N], int act)
+{
+    if (act == ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < N; q++) { const float u = v[q] * sc[q] + sf[q]; v[q] = u * __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
+    } else if (act == ACT_MISH) {
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            const float u = v[q] * sc[q] + sf[q];
+            const float n = __expf(u), w = n * (n + 2.f);
+            const float r = u * w * __builtin_amdgcn_rcpf(w + 2.f);
+            v[q] = u > 20.f ? u : r;
+        }
+    } else if (act == ACT_LEAKY) {
+#pragma unroll
+        for (int q = 0; q < N; q++) { const float u = v[q] * sc[q] + sf[q]; v[q] = u > 0.f ? u : 0.1f * u; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; q++) v[q] = v[q] * sc[q] + sf[q];
+    }
+}
+__device__ __forceinline__ void act_affine_quad(float (&v)[4], const float (&sc)[4], const float (&sf)[4], int act) { act_affine_vec<4>(v, sc, sf, act); }
+
 // d act / du, same expressions as elementwise.hip's act_d (one v_exp_f32, v_rcp_f32 instead of IEEE division)
 __device__ __forceinline__ float act_bwd(float u, int act)
 {
@@ -38,6 +66,32 @@ __device__ __forceinline__ float act_bwd(float u, int act)
         return t + u * (1.f - t * t) * sg;
     }
     return 1.f;
+}
+
+// d act / du of N values with ONE walk of the (wave-uniform) activation chain and branch-free arms — bit-identical to N calls of act_bwd
+// (same expressions; Mish's `u > 20` cut-off as a select).  The fused first-layer backward (stem.hip) is instruction-rate bound: per element the
+// chain was three scalar compare + branch pairs plus a divergent early return.
+template <int N> __device__ __forceinline__ void act_bwd_vec(const float (&u)[N], float (&d)[N], int act)
+{
+    if (act == ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < N; q++) { const float s = __builtin_amdgcn_rcpf(1.f + __expf(-u[q])); d[q] = s * (1.f + u[q] * (1.f - s)); }
+    } else if (act == ACT_MISH) {
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            const float n = __expf(u[q]), w = n * (n + 2.f);
+            const float t = w * __builtin_amdgcn_rcpf(w + 2.f);
+            const float sg = n * __builtin_amdgcn_rcpf(1.f + n);
+            const float r = t + u[q] * (1.f - t * t) * sg;
+            d[q] = u[q] > 20.f ? 1.f : r;
+        }
+    } else if (act == ACT_LEAKY) {
+#pragma unroll
+        for (int q = 0; q < N; q++) d[q] = u[q] > 0.f ? 1.f : 0.1f;
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; q++) d[q] = 1.f;
+    }
 }
 
 // ---- LDS transposed reads (ds_read_b64_tr_b16) next to LDS-DMA -----------------------------------------------------------------
@@ -251,10 +305,6 @@ int w8_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
 // ---- pointwise weight gradient on 256 x 256 tiles, 8 waves (wgrad1x1_8w.hip): eligibility + split (what ryolo_conv_wgrad_plan reports), launch
 bool w1x8_geometry(const WgradParams& p, int* splitk, int64_t* kchunk, int* gx, int* gy);
 int w1x8_launch(const WgradParams& p, hipStream_t stream);
-
-// ---- 3x3 stride-2 weight gradient on parity-plane rings, 8 waves (conv3x3s2_wgrad8.hip): eligibility (+ slabs, workgroups), launch
-bool ws2_geometry(const WgradParams& p, int* slabs, int* workgroups);
-int ws2_launch(const WgradParams& p, hipStream_t stream);
 
 // ---- weight-stationary persistent 1x1 GEMM (gemm1x1.hip): Cin <= 256, identity grid, bf16 epilogues ---------------------------------
 struct Ws1Geom {

@@ -222,13 +222,23 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g4 + e];
                         if constexpr (affine) {                    // inference: folded BatchNorm + activation on the fp32 accumulator
-                            const int n = n0 + j * 32 + 8 * g4 + 4 * h;       // Nout % 8 == 0: the quad is inside or outside as a whole
-                            if (n < p.Nout) {
-                                const float4 sc = *reinterpret_cast<const float4*>(p.scale + n), sf = *reinterpret_cast<const float4*>(p.shift + n);
-                                v[0] = act_fwd(v[0] * sc.x + sf.x, p.act);
-                                v[1] = act_fwd(v[1] * sc.y + sf.y, p.act);
-                                v[2] = act_fwd(v[2] * sc.z + sf.z, p.act);
-                                v[3] = act_fwd(v[3] * sc.w + sf.w, p.act);
+                            // r06: the coefficients of the 8 channels (n8 .. n8 + 7) the two half-waves of this quad cover are WAVE-UNIFORM (n0 comes
+                            // from the workgroup id; j, g4 are unrolled): two s_load_dwordx8 through the constant address space per quad instead of
+                            // two 16-byte VMEM loads per lane — this kernel's LDS is full at K = 256 (no room for the per-tile table the generic and
+                            // halo-patch kernels got in r05), and its vmcnt counts the ring's LDS-DMA pieces: a VMEM load in the epilogue waited for them.
+                            const int n8 = n0 + j * 32 + 8 * g4;              // Nout % 8 == 0: the eight channels are inside or outside as a whole
+                            if (n8 < p.Nout) {
+                                typedef const __attribute__((address_space(4))) float cfloat_t;
+                                cfloat_t* scp = (cfloat_t*)(p.scale + n8);
+                                cfloat_t* sfp = (cfloat_t*)(p.shift + n8);
+                                float sc4[4], sf4[4];
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const float sclo = scp[e], schi = scp[4 + e], sflo = sfp[e], sfhi = sfp[4 + e];      // eight + eight uniform loads, THEN the per-half select
+                                    sc4[e] = h ? schi : sclo;
+                                    sf4[e] = h ? sfhi : sflo;
+                                }
+                                act_affine_quad(v, sc4, sf4, p.act);
                             }
                         }
                         *reinterpret_cast<uint2*>(stage + (i * 32 + l31) * 32 + ((g4 ^ wsw) << 3) + 4 * h) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));

@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const StemParams p)
                 v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
             }
             if ((p.epi == EPI_AFFINE_ACT || p.epi == EPI_AFFINE_ACT_R) && c0 < p.Cout) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = act_fwd(v[q] * p.scale[c0 + q] + p.shift[c0 + q], p.act);
+                const float sc4[4] = {p.scale[c0], p.scale[c0 + 1], p.scale[c0 + 2], p.scale[c0 + 3]};
+                const float sf4[4] = {p.shift[c0], p.shift[c0 + 1], p.shift[c0 + 2], p.shift[c0 + 3]};
+                act_affine_quad(v, sc4, sf4, p.act);
             }
             const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             if (p.out) *reinterpret_cast<uint2*>(&otile[wave][px_l][c0]) = w;  // staged: the lane's 8-byte piece of its pixel row
@@ -353,21 +354,26 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_lds_kernel(const StemParams p
         for (int e = 0; e < 16; e++) acc[e] = 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[0], f0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[1], f1, acc, 0, 0, 0);
+        // r06: BatchNorm + activation of the tile's 16 values in ONE walk of the (wave-uniform) activation chain with branch-free arms
+        // (act_affine_vec, conv_internal.h): per element the chain cost three scalar compare + branch pairs in an instruction-rate-bound kernel
+        float v16[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) v16[e] = acc[e];
+        if (EPI == EPI_AFFINE_ACT_R) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const unsigned r = pack_bf2(v16[e], v16[e + 1]);
+                v16[e] = __uint_as_float(r << 16);
+                v16[e + 1] = __uint_as_float(r & 0xffff0000u);
+            }
+        }
+        if (affine) act_affine_vec<16>(v16, sc, sh, p.act);
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
             const int c0 = 8 * g4 + 4 * h;
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = acc[4 * g4 + q];
-            if (EPI == EPI_AFFINE_ACT_R) {
-                const uint2 r = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-                v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-            }
-            if (affine) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = act_fwd(v[q] * sc[4 * g4 + q] + sh[4 * g4 + q], p.act);
-            }
+            for (int q = 0; q < 4; q++) v[q] = v16[4 * g4 + q];
             const uint2 w = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             if (p.out) *reinterpret_cast<uint2*>(&otile[wave][px_l][c0]) = w;
             if (EPI == EPI_STATS) {
@@ -665,16 +671,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         unsigned gp[8];                                              // g packed: pairs (e, e+1)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+        // (r06: the activation derivative of the tile's 16 values in ONE walk of the activation chain, branch-free arms — act_bwd_vec; per
+        // element the chain cost three scalar compare + branch pairs in a kernel that is instruction-rate bound.  Same values bit for bit.)
+        float yv[16], uv[16], dv[16];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const unsigned yr = pack_bf2(acc[4 * m + 2 * hh], acc[4 * m + 2 * hh + 1]);        // raw output as stored by the two-pass path
+                yv[4 * m + 2 * hh] = __uint_as_float(yr << 16);
+                yv[4 * m + 2 * hh + 1] = __uint_as_float(yr & 0xffff0000u);
+            }
+#pragma unroll
+        for (int e = 0; e < 16; e++) uv[e] = yv[e] * sc + sh;
+        act_bwd_vec<16>(uv, dv, p.act);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const uint2 d2 = __builtin_bit_cast(uint2, dq[m]);
             const unsigned dd[2] = {d2.x, d2.y};
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
-                const unsigned yr = pack_bf2(acc[4 * m + 2 * hh], acc[4 * m + 2 * hh + 1]);        // raw output as stored by the two-pass path
-                const float y0 = __uint_as_float(yr << 16), y1 = __uint_as_float(yr & 0xffff0000u);
+                const float y0 = yv[4 * m + 2 * hh], y1 = yv[4 * m + 2 * hh + 1];
                 const float d0 = __uint_as_float(dd[hh] << 16), d1 = __uint_as_float(dd[hh] & 0xffff0000u);
-                const float g0 = d0 * act_bwd(y0 * sc + sh, p.act), g1 = d1 * act_bwd(y1 * sc + sh, p.act);
+                const float g0 = d0 * dv[4 * m + 2 * hh], g1 = d1 * dv[4 * m + 2 * hh + 1];
                 s0 += g0 + g1;
                 s1 += g0 * y0 + g1 * y1;
                 gp[2 * m + hh] = pack_bf2(g0, g1);

@@ -291,8 +291,6 @@ class Graph:
                 return ("conv3x3_wgrad_kernel<128x9x32>", fl, by, None, cus)
             if kern.value == 3:
                 return ("wgrad1x1_8w_kernel<256x256>", fl, by, None, cus)
-            if kern.value == 4:
-                return ("conv3x3s2_wgrad8_kernel", fl, by, None, cus)
             return (f"conv_wgrad_kernel<{64 if p.Cout <= 64 else 128}>", fl, by)
         return (name, 0, 0)
 

@@ -5,7 +5,8 @@
 #   bash tools/pmc_step_mfma.sh [round tag]   ->  gpurun_out/<tag>_pmc_step_mfma_busy.json  (copy to profiles/)
 # Counter semantics (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"): SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's 1 024
 # SIMDs (= 32 x the number of 32x32x16 bf16 MFMAs); SQ_BUSY_CYCLES is summed over the 32 shader engines' SQs (4 per XCD x 8 XCDs);
-# GRBM_GUI_ACTIVE = shader-clock cycles the GPU was busy in the dispatch.  So, per dispatch:
+# GRBM_GUI_ACTIVE = shader-clock cycles the GPU was busy in the dispatch, summed over the 8 XCDs (calibrated on the first r06 pass: GUI / ns = 15.9
+# for every large dispatch = 8 x 1.99 GHz, the clock the guide quotes for profiled passes).  So, per dispatch:
 #   matrix pipe busy fraction = (MFMA_BUSY / 1024) / (SQ_BUSY / 32)        [the convention of profiles/r05_pmc_wgrad_ring/SUMMARY.txt]
 # rocprofv3 serializes dispatches while it collects counters: a kernel is counted ALONE on the chip (the 96-CU weight-gradient kernels with the
 # other 160 CUs idle).  The step-level figure therefore divides the summed matrix cycles per SIMD by the cycles of the UN-profiled two-stream step
@@ -15,9 +16,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 STEPS=3
 # the plain step time on this box (two streams, no profiler)
-python $R/bench.py --steps 10 --warmup 3 --no-kernel-timing --no-cpu-baseline --no-loader --no-b8 > $R/gpurun_out/pmc_mfma_plain.json 2> $R/gpurun_out/pmc_mfma_plain.err
+python $R/bench.py --steps 10 --warmup 3 --no-kernel-timing --no-cpu-baseline --no-loader --no-b8 --no-infer > $R/gpurun_out/pmc_mfma_plain.json 2> $R/gpurun_out/pmc_mfma_plain.err
 timeout 1200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $R/gpurun_out/pmc_step_mfma -o p -- \
-  python $R/bench.py --steps $STEPS --warmup 1 --no-kernel-timing --no-cpu-baseline --no-loader --no-b8 > $R/gpurun_out/pmc_step_mfma.log 2>&1
+  python $R/bench.py --steps $STEPS --warmup 1 --no-kernel-timing --no-cpu-baseline --no-loader --no-b8 --no-infer > $R/gpurun_out/pmc_step_mfma.log 2>&1
 TAG=$TAG python - <<'PY'
 import collections, csv, glob, json, os, re, sys
 R = os.environ["GRAFT_REPO_ROOT"]
@@ -49,8 +50,8 @@ def block(keys):
     return {"launches_per_step": round(n / max(steps, 1), 1), "ms_per_step_profiled_alone": round(sec / max(steps, 1) * 1e3, 3),
             "mfma_busy_mcycles_per_step": round(mf / max(steps, 1) / 1e6, 2), "sq_busy_mcycles_per_step": round(sq / max(steps, 1) / 1e6, 3),
             "mfma_busy_frac_of_dispatch": round((mf / 1024) / (sq / 32), 4) if sq else None,
-            "mfma_busy_frac_of_wall_clock": round((mf / 1024) / gui, 4) if gui else None,
-            "shader_clock_ghz": round(gui / sec / 1e9, 3) if sec else None,
+            "mfma_busy_frac_of_wall_clock": round((mf / 1024) / (gui / 8), 4) if gui else None,
+            "shader_clock_ghz": round(gui / 8 / sec / 1e9, 3) if sec else None,
             "bf16_mfma_tflop_per_step": round(mops * 512 / max(steps, 1) / 1e12 * 1.0, 3) if mops else None}
 
 
@@ -71,7 +72,7 @@ except Exception as e:
     print("no plain run:", e)
 out = {"_doc": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 over bench.py (batch 64, yolov7 kfiou nc=16 "
                "800^2); dispatches are serialized by the profiler (every kernel alone on the chip; the CU-exclusive weight-gradient kernels with 160 CUs idle). "
-               "mfma_busy_frac_of_dispatch = (MFMA_BUSY / 1024 SIMDs) / (SQ_BUSY / 32 SQs); mfma_busy_frac_of_wall_clock = (MFMA_BUSY / 1024) / GRBM_GUI_ACTIVE. "
+               "mfma_busy_frac_of_dispatch = (MFMA_BUSY / 1024 SIMDs) / (SQ_BUSY / 32 SQs); mfma_busy_frac_of_wall_clock = (MFMA_BUSY / 1024) / (GRBM_GUI_ACTIVE / 8 XCDs); shader clock = GRBM_GUI_ACTIVE / 8 / duration. "
                "A 32x32x16 bf16 MFMA holds its SIMD's pipe for 32 cycles at 8 passes x 4 cycles: busy 100 % = the dense peak at the running clock.",
        "steps_profiled": steps, "whole_step_profiled_alone": step, "classes": classes, "kernels": kernels}
 if plain:
