@@ -94,6 +94,8 @@ PMC_CLASSES = {        # bench class -> regex over the kernel names of the rocpr
     "gemm1x1_ws_kernel": r"gemm1x1_ws_kernel<",                                       # weight-stationary persistent 1x1 (gemm1x1.hip, RYOLO_GEMM_WS)
     "conv3x3_patch_kernel<256x128>": r"conv3x3_patch_kernel<128, 2, 2[,>]",       # (+ epilogue / BatchNorm-fold template arguments since r04)
     "conv3x3_patch_kernel<256x64>": r"conv3x3_patch_kernel<64, 4, 1[,>]",
+    "conv3x3s2_c32_dgrad_kernel": r"conv3x3s2_c32_dgrad_kernel",                      # ... and its space-to-depth data gradient
+    "conv3x3s2_c32_kernel": r"conv3x3s2_c32_kernel<",                                 # streaming 3x3 stride-2 forward of the 32-channel layer (conv3x3s2_c32.hip, r06)
     "conv3x3_ws64_kernel": r"conv3x3_ws64_kernel<",                                   # persistent weight-stationary 64 -> <= 64 channel 3x3 (conv3x3_ws.hip)
     "conv_wgrad_kernel<128>": r"conv_wgrad_kernel<128, |wgrad1x1_dma_kernel|wgrad_taps_dma_kernel",   # (register-staged + the LDS-DMA pointwise / tapped forms)
     "conv_wgrad_kernel<64>": r"conv_wgrad_kernel<64, ",

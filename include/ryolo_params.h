@@ -16,18 +16,6 @@ typedef struct TapClass {
     signed char dh[RY_MAX_TAPS], dw[RY_MAX_TAPS], widx[RY_MAX_TAPS];
 } TapClass;
 
-/* BatchNorm-backward sums in the epilogue of the launch that COMPLETES an activation gradient (ConvGemmParams.bstat): the launch's
- * output columns [n0, n0 + C) are the gradient dz of a tensor z = act(scale * y + shift) produced by a Conv block (model/utils.py:13-23);
- * after the (stored or accumulated, bf16-rounded) value is final the epilogue forms g = dz * act'(scale * y + shift) and leaves per
- * M tile the column sums S0 = sum g, S1 = sum g * y — what ryolo_bn_act_bwd's reduce pass would re-read dz and y for. */
-#define RY_MAX_BSTAT 4
-typedef struct BwdStat {
-    const bf16_t* y;                                // raw convolution output of that BatchNorm, channel 0 of the range; row = output pixel
-    const float* co;                                // its forward coefficients [4][C]: mean, invstd, scale, shift
-    float* part;                                    // out: [M tiles of this launch][2][C]  (ryolo_conv_gemm_plan's stats_rows rows)
-    int ldy, C, n0, act;
-} BwdStat;
-
 typedef struct ConvGemmParams {
     const bf16_t* A; int NB, IH, IW, Cin, ldA;      // gathered operand: [NB, IH, IW, Cin] with channel stride ldA
     const bf16_t* W; int Nout, wtaps;               // packed weights [Nout][wtaps][Cin]
@@ -55,7 +43,6 @@ typedef struct ConvGemmParams {
                                                     // grid with Nout = 4 * s2d_cin columns (output parity ph, pw, then channel) and 2x2 taps (weights from
                                                     // ryolo_pack_s2d): column n of row (img, a, b) goes to pixel (2a + ph, 2b + pw), channel n % s2d_cin —
                                                     // every store instruction writes whole 128-byte pixel pairs (oh_mul = ow_mul = 2, bf16 epilogues only)
-    int nbstat; BwdStat bstat[RY_MAX_BSTAT];        // bf16 epilogues with the identity output grid only (generic and halo-patch kernels)
     int head_attrs, head_och;                       // head_attrs > 0 (EPI_F32_BIAS, 1x1 stride 1, LDS-DMA mainloop; else RY_ERR_UNSUPPORTED): the output is a
                                                     // detection head written in its FINAL layout — column n = anchor n / head_attrs, attribute n % head_attrs
                                                     // of GEMM row (image b, cell) goes to out[b][anchor][cell][attribute] (fp32 [NB, na, OH, OW, attrs]:
@@ -130,8 +117,6 @@ typedef struct BnActParams {
     float* partial;                                   // [nblk][K][C], K = 2 (one branch) or 3
     const float* bco;                                 // backward coefficients [K][C]: mean_g, mean_gx1, mean_gx2
     int rows_per_block;
-    int pre_rows;                                     // > 0: `partial` already holds pre_rows rows [2][C] of (S0, S1) written by the epilogue of the
-                                                      // launch that completed dz (ConvGemmParams.bstat): the reduce pass is skipped
 } BnActParams;
 
 typedef struct PoolParams {

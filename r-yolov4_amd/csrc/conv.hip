@@ -595,12 +595,9 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
         constexpr int RPI = 64 / CH;                           // rows per iteration
         const int ch = lane % CH, r0 = lane / CH;
         const int n = n0 + wn * WTN + ch * 8;
-        // EP: 0 plain store loop; 1 accumulate epilogue (EPI_ACCUM); 2 the launch also completes activation gradients (ConvGemmParams.bstat).
-        // 1 and 2 use the two-phase loop below and are their own instantiations, so that its registers do not cost the plain kernels their
-        // third resident workgroup (164 -> 204 VGPRs when everything was one kernel)
-        constexpr bool BS = EP == 2;
-        BsLane bsl;
-        if constexpr (BS) bs_lane_init(p, n, bsl);
+        // EP: 0 plain store loop; 1 accumulate epilogue (EPI_ACCUM): the two-phase loop below, its own instantiation so that its registers do not
+        // cost the plain kernels their third resident workgroup (164 -> 204 VGPRs when everything was one kernel).  (EP 2 — BatchNorm-backward sums
+        // folded into this store loop, r02 — lost to the stand-alone reduce pass at every size since r04 and was retired in r06.)
         // fused MaxPool2d(2, 2) gradient: (image, row, column) of the tile's first pixel, rows inside the tile by small exact divisions
         int pl_img = 0, pl_oh = 0, pl_ow = 0;
         float pl_rOW = 0.f, pl_rOH = 0.f;
@@ -614,24 +611,22 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
             pl_rOH = 1.0f / (float)p.OH;
         }
         if constexpr (EP != 0) {
-            // Two phases: every global load of the store loop (old value of an accumulate epilogue, BatchNorm input of a bstat lane) is
+            // Two phases: every global load of the store loop (the old value of an accumulate epilogue) is
             // issued before the first one is used — inside one loop with `continue` branches each iteration paid its own round trip.
             constexpr int NIT = WTM / RPI, GRP = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);
-            const bool accum = p.epi == EPI_ACCUM, bs_on = BS && p.nbstat && bsl.y;
+            const bool accum = p.epi == EPI_ACCUM;
             const int n_s = n < p.Nout ? n : 0;
 #pragma unroll
             for (int g0 = 0; g0 < NIT; g0 += GRP) {
-                int64_t pixv[GRP];
                 bf16_t* ov[GRP];
                 bool lv[GRP];
-                uint4 oldv[GRP], yv[GRP];
+                uint4 oldv[GRP];
 #pragma unroll
                 for (int k = 0; k < GRP; k++) {
                     const int r = (g0 + k) * RPI + r0;
                     const int64_t m = m0 + wm * WTM + r;
                     lv[k] = m < M && n < p.Nout;
                     const int64_t pix = lv[k] ? out_pixel(wm * WTM + r, m) : 0;
-                    pixv[k] = pix;
                     bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + pix * p.ldC + n_s;
                     if (!ID && p.s2d_cin) {                            // depth-to-space: column block q = (ph, pw) -> pixel (+ph rows, +pw columns)
                         const int q = n_s / p.s2d_cin, ci = n_s - q * p.s2d_cin;
@@ -642,10 +637,6 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
                 if (accum) {
 #pragma unroll
                     for (int k = 0; k < GRP; k++) oldv[k] = *reinterpret_cast<const uint4*>(ov[k]);
-                }
-                if (bs_on) {
-#pragma unroll
-                    for (int k = 0; k < GRP; k++) yv[k] = bs_lane_load(bsl, pixv[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < GRP; k++) {
@@ -684,7 +675,6 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
                         v = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                     *reinterpret_cast<uint4*>(ov[k]) = v;
-                    if (bs_on) bs_lane_row(bsl, yv[k], v);
                 }
                 __builtin_amdgcn_sched_barrier(0);                     // keep the next group's loads behind this group's stores (registers)
             }
@@ -736,7 +726,6 @@ __global__ __launch_bounds__(256, NST >= 5 ? 1 : 2) void conv_gemm_kernel(const 
                 *reinterpret_cast<uint4*>(o) = v;
             }
         }
-        if constexpr (BS) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(smem), wave, r0, ch, tid, n0, mb);
 #ifdef GEMM_TIMING
         T3 = __builtin_readcyclecounter();
 #endif
@@ -1422,16 +1411,12 @@ static int launch_gemm(const ConvGemmParams& p, hipStream_t stream)
     const bool t1 = PIPE == 1 && gemm_is_t1(p);
     if constexpr (PIPE == 1) {
         if (t1) {
-            if (p.nbstat) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true, true>), grid, dim3(256), 0, stream, q);
-            else if (p.epi == EPI_ACCUM) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true, true>), grid, dim3(256), 0, stream, q);
+            if (p.epi == EPI_ACCUM) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true, true>), grid, dim3(256), 0, stream, q);
             else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 0, true, true>), grid, dim3(256), 0, stream, q);
             return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
         }
     }
-    if (p.nbstat) {                                             // (identity grid by gemm_check; the pool gradient may ride along)
-        if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, true>), grid, dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 2, false>), grid, dim3(256), 0, stream, q);
-    } else if (p.epi == EPI_ACCUM) {
+    if (p.epi == EPI_ACCUM) {
         if (ident) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, true>), grid, dim3(256), 0, stream, q);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PIPE, KB, 1, false>), grid, dim3(256), 0, stream, q);
     } else {
@@ -1457,7 +1442,7 @@ static int launch_gemm_deep(const ConvGemmParams& p, hipStream_t stream)
 static int gemm_deep_stages(const ConvGemmParams& p)
 {
     static const int mode = getenv("RYOLO_GEMM_DEEP") ? atoi(getenv("RYOLO_GEMM_DEEP")) : 1;     // 0 off; 1 by grid size; 4 / 6 force that depth on every eligible launch (tests)
-    if (!mode || (p.pipe & 0xff) != 1 || !gemm_ident(p) || p.nbstat || p.Nout <= 64 || (p.pipe & 0x800)) return 0;
+    if (!mode || (p.pipe & 0xff) != 1 || !gemm_ident(p) || p.Nout <= 64 || (p.pipe & 0x800)) return 0;
     if (mode == 4 || mode == 6) return mode;
     const int64_t tiles = ry_cdiv((int64_t)p.NB * p.OH * p.OW, 128) * ry_cdiv(p.Nout, 128);
     const int nk = p.cls[0].ntaps * (p.Cin / BK);
@@ -1524,19 +1509,8 @@ static int gemm_check(const ConvGemmParams& p)
     if (!p.A || !p.W || !p.out || p.Cin <= 0 || p.Cin % BK || p.ldA % 8 || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4)
         return RY_ERR_ARG;
     if (p.head_attrs) {
-        if (p.head_attrs < 7 || p.Nout % p.head_attrs || p.head_och < 0 || p.head_och >= p.head_attrs || p.epi != EPI_F32_BIAS || p.nbstat) return RY_ERR_ARG;
+        if (p.head_attrs < 7 || p.Nout % p.head_attrs || p.head_och < 0 || p.head_och >= p.head_attrs || p.epi != EPI_F32_BIAS) return RY_ERR_ARG;
         if (!gemm_is_t1(p)) return RY_ERR_UNSUPPORTED;        // (the caller falls back to the row-major form + ryolo_head_finish_fwd)
-    }
-    if (p.nbstat) {
-        if (p.nbstat < 0 || p.nbstat > RY_MAX_BSTAT || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.s2d_cin || p.nclasses != 1 || p.oh_mul != 1 ||
-            p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || p.cls[0].oh_add || p.cls[0].ow_add)
-            return RY_ERR_ARG;
-        for (int q = 0; q < p.nbstat; q++) {
-            const BwdStat& b = p.bstat[q];
-            if (!b.y || !b.co || !b.part || b.C <= 0 || (b.C & 7) || (b.n0 & 7) || (b.ldy & 7) || b.n0 < 0 || b.n0 + b.C > p.Nout ||
-                (reinterpret_cast<uintptr_t>(b.y) & 15))
-                return RY_ERR_ARG;
-        }
     }
     return RY_OK;
 }
@@ -1545,17 +1519,29 @@ static int gemm_check(const ConvGemmParams& p)
 // epilogue writes (= number of M tiles).  kernel: 0 generic implicit GEMM (conv.hip), 1 3x3 halo-patch kernel (conv3x3.hip,
 // selected by pipe bit 0x200 when the layer is eligible), 2 weight-stationary persistent 1x1 kernel (gemm1x1.hip; rows = waves),
 // 3 persistent weight-stationary 3x3 kernel for 64 -> <= 64 channels (conv3x3_ws.hip; rows = workgroups), 4 the 256-wide pointwise GEMM for long
-// reductions (gemm256.hip; bits 16-19 = tile columns / 32).
+// reductions (gemm256.hip; bits 16-19 = tile columns / 32), 5 the streaming 3x3 stride-2 forward for 32 input channels (conv3x3s2_c32.hip;
+// rows = workgroups), 6 the same layer's space-to-depth data gradient.
 extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, int* kernel)
 {
     if (!pp || !stats_rows) return RY_ERR_ARG;
     const ConvGemmParams& p = *pp;
     if (p.Cin <= 0 || p.Cin % BK || p.Nout <= 0 || p.nclasses < 1 || p.nclasses > 4) return RY_ERR_ARG;
     if (p.head_attrs) {                                       // detection head in its final layout: the 128 x 128 1x1 instantiation or nothing
-        if (p.head_attrs < 7 || p.Nout % p.head_attrs || p.epi != EPI_F32_BIAS || p.nbstat) return RY_ERR_ARG;
+        if (p.head_attrs < 7 || p.Nout % p.head_attrs || p.epi != EPI_F32_BIAS) return RY_ERR_ARG;
         if (!gemm_is_t1(p) || (int64_t)p.NB * p.OH * p.OW > 0x7fffffff) return RY_ERR_UNSUPPORTED;
         *stats_rows = (int)ry_cdiv((int64_t)p.NB * p.OH * p.OW, 128);
         if (kernel) *kernel = 0 | 0x100 | (2 << 12) | (4 << 16);
+        return RY_OK;
+    }
+    S2cGeom sg;
+    if (s2c_geometry(p, sg)) {                                     // streaming 3x3 stride-2 forward, 32 input channels (conv3x3s2_c32.hip): one row per workgroup
+        *stats_rows = sg.nwg;
+        if (kernel) *kernel = 5;
+        return RY_OK;
+    }
+    if (s2c_dgrad_geometry(p, sg)) {                               // ... and its data gradient in the space-to-depth form (no statistics epilogue)
+        *stats_rows = sg.nwg;
+        if (kernel) *kernel = 6;
         return RY_OK;
     }
     Ws3Geom w3;
@@ -1601,6 +1587,11 @@ extern "C" int ryolo_conv_gemm(const ConvGemmParams* pp, hipStream_t stream)
         if (p.cls[c].ntaps < 1 || p.cls[c].ntaps > RY_MAX_TAPS) return RY_ERR_ARG;
     if (p.epi == EPI_STATS && (!p.stats || p.nclasses != 1)) return RY_ERR_ARG;
     if ((int64_t)p.NB * p.OH * p.OW <= 0) return RY_OK;
+    {
+        S2cGeom sg;
+        if (s2c_geometry(p, sg)) return s2c_launch(p, sg, stream);
+        if (s2c_dgrad_geometry(p, sg)) return s2c_dgrad_launch(p, sg, stream);
+    }
     if (p.pipe & 0x200) {
         Ws3Geom w3;
         if (ws3_geometry(p, w3)) return ws3_launch(p, w3, stream);

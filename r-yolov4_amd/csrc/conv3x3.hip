@@ -44,9 +44,10 @@ template <int N> struct P3Unroll<N, N> {
     template <class F> static __device__ __forceinline__ void run(F&) {}
 };
 
-// EPI / BS (BatchNorm-backward sums folded into the store loop) are template parameters: with the epilogue selected by run-time branches the
-// one kernel body carried every variant (17 k instructions behind the loop) and the training epilogues ran 10-13 k cycles per workgroup.
-template <int BN, int WM, int WN, int EPI, bool BS>
+// EPI is a template parameter: with the epilogue selected by run-time branches the one kernel body carried every variant (17 k instructions
+// behind the loop) and the training epilogues ran 10-13 k cycles per workgroup.  (r02-r05 also carried a `BS` parameter: BatchNorm-backward sums
+// folded into the store loop — slower than the stand-alone reduce pass at every size since r04, retired in r06.)
+template <int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmParams p, const P3Geom g)
 {
     constexpr int BM = P3_BM, TM = BM / WM / 32, TN = BN / WN / 32, WTM = BM / WM, WTN = BN / WN;
@@ -333,8 +334,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
     const int ncol = n0 + wn * WTN + ch * 8;
     const int cq = lane & 15, rg = lane >> 4;                  // statistics: 4 channels x every 4th row per lane
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-    BsLane bsl;
-    if constexpr (BS) bs_lane_init(p, ncol, bsl);
     // inference: the folded BatchNorm coefficients of the tile's BN columns, once per workgroup into LDS behind the staging rows (inside the dead
     // patch buffers) instead of two 16-byte global loads per staged quad
     float* const cscale = reinterpret_cast<float*>(p3_lds + 4 * 64 * EP_LD * 2);
@@ -405,18 +404,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 #ifdef P3_TIMING
         { const unsigned long long t = __builtin_readcyclecounter(); te[2] += t - te[4]; te[4] = t; }
 #endif
-        // Store loop in two phases: every global load of the half (the old value of an accumulate epilogue, the BatchNorm input of a
-        // bstat lane) is issued before the first one is used.  With the loads inside one loop next to `continue` branches each of the
-        // 8 iterations paid its own memory round trip: +24 us on a 77 us launch for EPI_ACCUM, +40 us more with bstat (128->128 @50^2).
+        // Store loop in two phases: every global load of the half (the old value of an accumulate epilogue) is issued before the first one
+        // is used.  With the loads inside one loop next to `continue` branches each of the 8 iterations paid its own memory round trip:
+        // +24 us on a 77 us launch for EPI_ACCUM (128->128 @50^2).
         constexpr int NIT = 64 / RPI, GRP = 4;                          // 4 iterations in flight: more would cost a resident workgroup (VGPRs)
         static_assert(NIT % GRP == 0, "store loop grouping");
         constexpr bool accum = EPI == EPI_ACCUM;
-        const bool bs_on = BS && bsl.y;
 #pragma unroll
         for (int g0 = 0; g0 < NIT; g0 += GRP) {
             int64_t pixv[GRP];
             bool lv[GRP];
-            uint4 oldv[GRP], yv[GRP];
+            uint4 oldv[GRP];
 #pragma unroll
             for (int k = 0; k < GRP; k++) {
                 const int r = (g0 + k) * RPI + r0;
@@ -428,10 +426,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
             if constexpr (accum) {
 #pragma unroll
                 for (int k = 0; k < GRP; k++) oldv[k] = oldall[half][g0 + k];
-            }
-            if (bs_on) {
-#pragma unroll
-                for (int k = 0; k < GRP; k++) yv[k] = bs_lane_load(bsl, pixv[k]);
             }
 #pragma unroll
             for (int k = 0; k < GRP; k++) {
@@ -450,7 +444,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
                     v = make_uint4(w[0], w[1], w[2], w[3]);
                 }
                 *reinterpret_cast<uint4*>(o) = v;
-                if (bs_on) bs_lane_row(bsl, yv[k], v);
             }
         }
 #ifdef P3_TIMING
@@ -460,7 +453,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 #ifdef P3_TIMING
     const unsigned long long T3 = __builtin_readcyclecounter();
 #endif
-    if constexpr (BS) bs_finish<WTN, RPI, WM, WN, BN>(p, bsl, reinterpret_cast<float*>(p3_lds), wave, r0, ch, tid, n0, mb);
     if constexpr (EPI == EPI_STATS) {
         // every lane parks its 8 partial sums in LDS, one thread per column folds the 4 row groups x WM waves
         // (a shuffle tree here is 16 dependent ds_bpermute round trips, ~2 k cycles)
@@ -564,23 +556,22 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
     return true;
 }
 
-template <int BN, int WM, int WN, int EPI, bool BS> static int p3_launch_t(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
+template <int BN, int WM, int WN, int EPI> static int p3_launch_t(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 {
     static RyLdsAttr attr;
-    if (ry_max_dynamic_lds(attr, reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN, EPI, BS>), 160 * 1024)) return RY_ERR_LAUNCH;
+    if (ry_max_dynamic_lds(attr, reinterpret_cast<const void*>(&conv3x3_patch_kernel<BN, WM, WN, EPI>), 160 * 1024)) return RY_ERR_LAUNCH;
     static const unsigned ldspad = getenv("RYOLO_P3_LDSPAD") ? (unsigned)atoi(getenv("RYOLO_P3_LDSPAD")) : 0u;   // occupancy experiments
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN, EPI, BS>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes + ldspad, stream, p, g);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, WN, EPI>), dim3((unsigned)(g.gm * g.gn)), dim3(256), g.lds_bytes + ldspad, stream, p, g);
     return hipGetLastError() == hipSuccess ? RY_OK : RY_ERR_LAUNCH;
 }
 
 template <int BN, int WM, int WN> static int p3_launch_e(const ConvGemmParams& p, const P3Geom& g, hipStream_t stream)
 {
-    // BatchNorm-backward sums ride on the data-gradient epilogues only (conv.hip checks the combination)
     switch (p.epi) {
-        case EPI_RAW: return p.nbstat ? p3_launch_t<BN, WM, WN, EPI_RAW, true>(p, g, stream) : p3_launch_t<BN, WM, WN, EPI_RAW, false>(p, g, stream);
-        case EPI_ACCUM: return p.nbstat ? p3_launch_t<BN, WM, WN, EPI_ACCUM, true>(p, g, stream) : p3_launch_t<BN, WM, WN, EPI_ACCUM, false>(p, g, stream);
-        case EPI_STATS: return p.nbstat ? RY_ERR_ARG : p3_launch_t<BN, WM, WN, EPI_STATS, false>(p, g, stream);
-        case EPI_AFFINE_ACT: return p.nbstat ? RY_ERR_ARG : p3_launch_t<BN, WM, WN, EPI_AFFINE_ACT, false>(p, g, stream);
+        case EPI_RAW: return p3_launch_t<BN, WM, WN, EPI_RAW>(p, g, stream);
+        case EPI_ACCUM: return p3_launch_t<BN, WM, WN, EPI_ACCUM>(p, g, stream);
+        case EPI_STATS: return p3_launch_t<BN, WM, WN, EPI_STATS>(p, g, stream);
+        case EPI_AFFINE_ACT: return p3_launch_t<BN, WM, WN, EPI_AFFINE_ACT>(p, g, stream);
     }
     return RY_ERR_ARG;
 }

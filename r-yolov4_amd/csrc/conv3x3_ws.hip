@@ -489,7 +489,7 @@ bool ws3_geometry(const ConvGemmParams& p, Ws3Geom& g)
     if (!ws3_enabled()) return false;
     const TapClass& tc = p.cls[0];
     if (p.nclasses != 1 || tc.ntaps != 9 || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
-    if (p.pool_idx || p.s2d_cin || p.nbstat) return false;
+    if (p.pool_idx || p.s2d_cin) return false;
     if (p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || tc.oh_add || tc.ow_add) return false;
     if (p.Cin != 64 || p.Nout > 64 || p.Nout < 8 || p.Nout % 8 || p.ldA % 8 || p.ldC % 8 || !p.zeros) return false;
     if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_ACCUM) return false;

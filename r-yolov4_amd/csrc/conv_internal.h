@@ -136,86 +136,6 @@ __device__ __forceinline__ bf16x8 join_halves(ry_s16x4 lo, ry_s16x4 hi)
 template <int N> __device__ __forceinline__ void lds_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 template <int N> __device__ __forceinline__ void lds_wait2(bf16x8& f, bf16x8& g) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(g) : "n"(N)); }
 
-// ---- BatchNorm-backward sums in a GEMM epilogue (ConvGemmParams.bstat, include/ryolo_params.h) -------------------------------------
-// The store loop of both GEMM kernels gives a lane ONE 16-byte chunk (8 consecutive output columns) of a few rows.  A lane whose
-// columns fall into a registered range reads the same chunk of the BatchNorm's raw input y, forms g = dz * act'(sc * y + sh) from the
-// FINAL bf16-rounded dz it is about to store, and keeps S0 = sum g, S1 = sum g * y for its columns; bs_finish folds the lanes of the
-// workgroup through LDS in a fixed order (deterministic) and writes one partial row per M tile.
-struct BsLane {
-    const bf16_t* y;                                            // &y[0][first column of the lane]; null: no range
-    int ldy, act;
-    float sc[8], sh[8], s0[8], s1[8];
-};
-__device__ __forceinline__ void bs_lane_init(const ConvGemmParams& p, int n, BsLane& L)
-{
-    L.y = nullptr;
-    L.ldy = 0;
-    L.act = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { L.s0[k] = 0.f; L.s1[k] = 0.f; L.sc[k] = 0.f; L.sh[k] = 0.f; }
-    for (int q = 0; q < p.nbstat; q++) {
-        const BwdStat& b = p.bstat[q];
-        if (n >= b.n0 && n < b.n0 + b.C) {
-            const int col = n - b.n0;
-            L.y = b.y + col;
-            L.ldy = b.ldy;
-            L.act = b.act;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { L.sc[k] = b.co[2 * b.C + col + k]; L.sh[k] = b.co[3 * b.C + col + k]; }
-        }
-    }
-}
-__device__ __forceinline__ uint4 bs_lane_load(const BsLane& L, int64_t pix) { return *reinterpret_cast<const uint4*>(L.y + pix * L.ldy); }
-__device__ __forceinline__ void bs_lane_row(BsLane& L, const uint4& yv, const uint4& dz)
-{
-    const unsigned* a = reinterpret_cast<const unsigned*>(&dz);
-    const unsigned* b = reinterpret_cast<const unsigned*>(&yv);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float d0 = __uint_as_float(a[q] << 16), d1 = __uint_as_float(a[q] & 0xffff0000u);
-        const float y0 = __uint_as_float(b[q] << 16), y1 = __uint_as_float(b[q] & 0xffff0000u);
-        const float g0 = d0 * act_bwd(y0 * L.sc[2 * q] + L.sh[2 * q], L.act);
-        const float g1 = d1 * act_bwd(y1 * L.sc[2 * q + 1] + L.sh[2 * q + 1], L.act);
-        L.s0[2 * q] += g0;
-        L.s1[2 * q] += g0 * y0;
-        L.s0[2 * q + 1] += g1;
-        L.s1[2 * q + 1] += g1 * y1;
-    }
-}
-// part_lds: [4 waves][RPI][2][WTN] floats (the dead staging area); wave = wm * WN + wn; lane = (row lane r0, chunk ch)
-template <int WTN, int RPI, int WM, int WN, int BN>
-__device__ __forceinline__ void bs_finish(const ConvGemmParams& p, const BsLane& L, float* part_lds, int wave, int r0, int ch, int tid, int n0,
-                                          int64_t mb)
-{
-    __syncthreads();                                            // staging blocks dead
-    float* mine = part_lds + ((wave * RPI + r0) * 2) * WTN + ch * 8;
-    *reinterpret_cast<float4*>(mine) = make_float4(L.s0[0], L.s0[1], L.s0[2], L.s0[3]);
-    *reinterpret_cast<float4*>(mine + 4) = make_float4(L.s0[4], L.s0[5], L.s0[6], L.s0[7]);
-    *reinterpret_cast<float4*>(mine + WTN) = make_float4(L.s1[0], L.s1[1], L.s1[2], L.s1[3]);
-    *reinterpret_cast<float4*>(mine + WTN + 4) = make_float4(L.s1[4], L.s1[5], L.s1[6], L.s1[7]);
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.Nout) {
-        const int wn_c = tid / WTN, cc = tid % WTN;
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; w++)
-#pragma unroll
-            for (int r = 0; r < RPI; r++) {
-                const float* src = part_lds + (((w * WN + wn_c) * RPI + r) * 2) * WTN + cc;
-                a += src[0];
-                b += src[WTN];
-            }
-        const int n = n0 + tid;
-        for (int q = 0; q < p.nbstat; q++) {
-            const BwdStat& bs = p.bstat[q];
-            if (n >= bs.n0 && n < bs.n0 + bs.C) {
-                bs.part[(mb * 2 + 0) * bs.C + (n - bs.n0)] = a;
-                bs.part[(mb * 2 + 1) * bs.C + (n - bs.n0)] = b;
-            }
-        }
-    }
-}
-
 // bijective XCD remap (cdna guide T1): workgroup b runs on XCD b%8; give each XCD a contiguous tile range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {
@@ -305,6 +225,19 @@ int w8_launch(const WgradParams& p, const W3Geom& g, hipStream_t stream);
 // ---- pointwise weight gradient on 256 x 256 tiles, 8 waves (wgrad1x1_8w.hip): eligibility + split (what ryolo_conv_wgrad_plan reports), launch
 bool w1x8_geometry(const WgradParams& p, int* splitk, int64_t* kchunk, int* gx, int* gy);
 int w1x8_launch(const WgradParams& p, hipStream_t stream);
+
+// ---- streaming 3x3 stride-2 forward for 32 input channels (conv3x3s2_c32.hip; r06): weights in LDS, B fragments straight from global memory --
+struct S2cGeom {
+    int ok;
+    int cblocks;               // 32-pixel column blocks per output row
+    int64_t tiles;             // wave tiles = NB * cblocks * OH
+    int nwg;                   // persistent workgroups (= statistics rows)
+    unsigned lds_bytes;
+};
+bool s2c_geometry(const ConvGemmParams& p, S2cGeom& g);
+int s2c_launch(const ConvGemmParams& p, const S2cGeom& g, hipStream_t stream);
+bool s2c_dgrad_geometry(const ConvGemmParams& p, S2cGeom& g);      // its data gradient in the space-to-depth form (ConvGemmParams.s2d_cin == 32)
+int s2c_dgrad_launch(const ConvGemmParams& p, const S2cGeom& g, hipStream_t stream);
 
 // ---- weight-stationary persistent 1x1 GEMM (gemm1x1.hip): Cin <= 256, identity grid, bf16 epilogues ---------------------------------
 struct Ws1Geom {

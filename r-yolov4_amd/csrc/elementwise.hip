@@ -1556,13 +1556,10 @@ extern "C" int ryolo_bn_act_bwd(const BnActParams* pp, float* dgamma1, float* db
     p.rows_per_block = rpb;
     p.bco = bco;
     const int K = p.y2 ? 3 : 2;
-    const bool pre = p.pre_rows > 0;                 // (S0, S1) rows already written by the launch that completed dz (ConvGemmParams.bstat)
-    if (pre && K != 2) return RY_ERR_ARG;
-    if (pre) nblk = p.pre_rows;
 #define RY_RED(ACT)                                                                                              \
     if (p.y2) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, true>), dim3(nblk), dim3(256), 0, stream, p);        \
     else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<ACT, false>), dim3(nblk), dim3(256), 0, stream, p);
-    if (!pre) switch (p.act) {
+    switch (p.act) {
         case ACT_MISH: RY_RED(ACT_MISH) break;
         case ACT_LEAKY: RY_RED(ACT_LEAKY) break;
         case ACT_SILU: RY_RED(ACT_SILU) break;

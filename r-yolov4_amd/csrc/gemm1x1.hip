@@ -385,7 +385,7 @@ static bool ws1_s2d_eligible(const ConvGemmParams& p)
     const int nt = p.cls[0].ntaps;
     if (nt < 1 || nt > 4 || p.Cin % 32 || nt * (p.Cin / 32) > 8 || nt * (p.Cin / 32) < 2) return false;
     if (p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW || p.OHf != 2 * p.OH || p.OWf != 2 * p.OW) return false;
-    if (p.pool_idx || p.nbstat || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.ldA % 8 || p.ldC % 8) return false;
+    if (p.pool_idx || (p.epi != EPI_RAW && p.epi != EPI_ACCUM) || p.ldA % 8 || p.ldC % 8) return false;
     if ((int64_t)p.NB * p.OH * p.OW >= (1ll << 31) || (int64_t)(p.IW + 1) * p.ldA >= (1ll << 30)) return false;
     return true;
 }
@@ -423,7 +423,7 @@ static bool ws1_geometry_1x1(const ConvGemmParams& p, Ws1Geom& g)
     if (!mode || (p.pipe & 0xff) != 1 || !p.zeros) return false;
     if (p.nclasses != 1 || p.cls[0].ntaps != 1 || p.cls[0].dh[0] || p.cls[0].dw[0] || p.cls[0].widx[0] || p.cls[0].oh_add || p.cls[0].ow_add) return false;
     if (p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW || p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW) return false;
-    if (p.s2d_cin || p.nbstat) return false;
+    if (p.s2d_cin) return false;
     if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_AFFINE_ACT && p.epi != EPI_ACCUM) return false;
     if (p.Cin % 32 || p.Cin > 256 || p.Cin < 64 || p.Nout % 8 || p.ldA % 8 || p.ldC % 8) return false;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;

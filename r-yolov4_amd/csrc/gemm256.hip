@@ -315,7 +315,7 @@ bool g256_geometry(const ConvGemmParams& p, G256Geom& g)
     const TapClass& tc = p.cls[0];
     if (p.nclasses != 1 || tc.ntaps != 1 || tc.dh[0] || tc.dw[0] || tc.widx[0] || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
     if (p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || tc.oh_add || tc.ow_add) return false;
-    if (p.pool_idx || p.s2d_cin || p.nbstat || !p.zeros) return false;
+    if (p.pool_idx || p.s2d_cin || !p.zeros) return false;
     if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_ACCUM) return false;
     if (p.Cin % G256_BK || p.Nout % 8 || p.ldA % 8 || p.ldC % 8 || p.Nout < 128) return false;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;

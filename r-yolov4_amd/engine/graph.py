@@ -95,9 +95,6 @@ class TRef:
     def grad_write_mode(self):
         """Plan-time: returns 1 (accumulate) if [c0,c0+C) of the grad buffer was already written, else 0 (store)."""
         lo, hi = self.c0, self.c0 + self.C
-        g = self.buf.graph
-        if g is not None:                                  # order of the gradient writers of every buffer (who completes a gradient: _bstat_for)
-            g.gw_log.append((self.buf.k, lo, hi))
         covered = any(a <= lo and hi <= b for a, b in self.buf.g_written)
         if not covered:
             for a, b in self.buf.g_written:
@@ -123,18 +120,13 @@ def _fill_class(tc, taps, oh_add=0, ow_add=0):
 
 
 class Graph:
-    def __init__(self, rt, B, Hin, Win, training, frozen=False, dry=False, layout=None, last_writer=None):
+    def __init__(self, rt, B, Hin, Win, training, frozen=False, dry=False, layout=None):
         self.rt, self.B, self.Hin, self.Win, self.training = rt, B, Hin, Win, training
         # buffer placement (engine/arena.py): dry = liveness pass on virtual addresses; layout = its result, the buffers are slots of ONE arena
         self.dry, self.layout = dry, layout
         self._nbuf, self._virt, self._raw = 0, {}, {}
         self.arena = torch.empty(layout.total, dtype=torch.uint8, device=rt.device) if layout is not None else None
         self._done = None                      # completion events of the weight-gradient launches (bounded lag, see run())
-        # BatchNorm-backward sums in the epilogue of the launch that completes an activation gradient (ConvGemmParams.bstat)
-        self.gw_log = []                       # (buffer, lo, hi) of every TRef.grad_write_mode() call, in plan order
-        self.bn_src = {}                       # buffer index -> [(c0, C, y TRef, coefficient tensor, act code, holder dict)] of its Conv blocks
-        self.last_writer = last_writer         # {(buffer, c0, C): index into gw_log of the LAST writer touching that range} from a discovery pass
-        self.n_bstat = 0
         self.frozen = frozen                   # backward tape with eval-mode (running-statistics) BatchNorm
         self.batch_stats = training and not frozen
         self.dev = rt.device
@@ -268,6 +260,10 @@ class Graph:
                 return ("gemm1x1_ws_kernel", fl, by)
             if fam == 3:
                 return ("conv3x3_ws64_kernel", fl, by)
+            if fam == 5:
+                return ("conv3x3s2_c32_kernel", fl, by)
+            if fam == 6:
+                return ("conv3x3s2_c32_dgrad_kernel", fl, by)
             if fam == 4:
                 return (f"gemm256_kernel<256x{((kv >> 16) & 15) * 32}>", fl, by, "K<=256" if p.Cin <= 256 else "K>256")
             # the generic kernel's instantiations as rocprofv3 lists them: tile shape, and the 1x1 form (no tap table / tile decomposition)
@@ -429,7 +425,7 @@ class Graph:
 
     # ------------------------------------------------------------------ convolution
     def _gemm(self, tape, A, Aptr, W, Nout, wtaps, gemm_cin, OH, OW, stride, classes, epi, out_ptr, ldC, full=None,
-              coeffs=None, act=0, bias=None, s2d=0, pool=None, bstat=None, head=None):
+              coeffs=None, act=0, bias=None, s2d=0, pool=None, head=None):
         """Emit one ryolo_conv_gemm launch.  For epi == EPI_STATS the partial-statistics buffer is sized by the library's plan
         (one [2][Nout] row per M tile of the kernel it will run) and returned."""
         p = S.ConvGemmParams()
@@ -457,28 +453,6 @@ class Graph:
             p.head_attrs, p.head_och, p.scale, p.stats = head
         if pool is not None:
             p.pool_idx, p.pool_dz, p.pool_ldi, p.pool_ld = pool
-        if bstat:
-            rows, kern = S.I(), S.I()
-            hip.call("ryolo_conv_gemm_plan", p, rows, kern)
-            if not (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1 or A.N * OH * OW * Nout > self.rt.fuse_bn_max_elems:
-                bstat = None
-        if bstat:
-            # the plan is asked again for the launch AS IT WILL RUN: kernel selection depends on nbstat (the persistent 1x1 kernel and the
-            # deep-ring instantiations do not fold statistics), and `part` is sized by the rows of the kernel that really writes it
-            p.nbstat = len(bstat)
-            hip.call("ryolo_conv_gemm_plan", p, rows, kern)
-            if not (self.rt.fuse_bn_kernels >> (kern.value & 0xff)) & 1:
-                # the launch WITH the fold runs on another kernel family than the one asked about above, and RYOLO_FUSE_BN_KERNELS masks that one:
-                # no fold, the stand-alone reduce pass stays (p.nbstat back to 0 so that the launch is planned as it will run)
-                p.nbstat = 0
-                bstat = None
-        if bstat:
-            for i, (n0, (c0_, C_, y_, co_, act_, holder)) in enumerate(bstat):
-                part = self.f32(rows.value + 64, 2, C_)                      # +64 rows: fold scratch of ryolo_bn_act_bwd
-                b = p.bstat[i]
-                b.y, b.co, b.part, b.ldy, b.C, b.n0, b.act = y_.ptr(), co_.data_ptr(), part.data_ptr(), y_.ld, C_, n0, act_
-                holder["pre"] = (part, rows.value)
-            self.n_bstat += len(bstat)
         stats = None
         if epi == S.EPI_STATS:
             rows = S.I()
@@ -508,8 +482,7 @@ class Graph:
             if pool is not None:
                 assert k == 1 and pool["z"].C == x.C
                 pl = (pool["idx"].data_ptr(), pool["z"].gptr(), x.C, pool["z"].ld)
-            self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld, pool=pl,
-                       bstat=self._bstat_for(x))
+            self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H, x.W, 1, [(taps, 0, 0)], epi, x.gptr(), x.ld, pool=pl)
         elif (self.rt.s2d_dgrad and k == 3 and pad == 1 and cin <= self.rt.s2d_dgrad_maxc and cin % 8 == 0 and x.H % 2 == 0 and x.W % 2 == 0
               and dy_cin % 32 == 0 and dy_cin == conv.out_channels):
             # narrow stride-2 layer: ONE stride-1 GEMM over the dY grid, N = 4 parities x cin, 2x2 taps, depth-to-space store
@@ -526,39 +499,6 @@ class Graph:
                     classes.append((taps, ph, pw))
             self._gemm(self.bwd, dy, dy_ptr, pk["wd"], cin, k * k, dy_cin, x.H // 2, x.W // 2, 1, classes, epi, x.gptr(), x.ld,
                        full=(2, 2, x.H, x.W))
-
-    def _bstat_for(self, x):
-        """Called right after x.grad_write_mode() by a stride-1 data gradient: the Conv blocks whose activation lives in x's channel range
-        and whose gradient THIS launch completes (no later writer touches it) get their BatchNorm-backward sums from its epilogue."""
-        if self.last_writer is None:
-            return None
-        seq = len(self.gw_log) - 1
-        out = []
-        for ent in self.bn_src.get(x.buf.k, ()):
-            c0, Cn = ent[0], ent[1]
-            if x.c0 <= c0 and c0 + Cn <= x.c0 + x.C and self.last_writer.get((x.buf.k, c0, Cn)) == seq and len(out) < S.MAX_BSTAT:
-                out.append((c0 - x.c0, ent))
-        return out or None
-
-    def _bn_register(self, z, y, co, actc):
-        """z = act(bn(y)) of a Conv block: remembered so that the completer of z's gradient can do the reduce pass (returns the holder the
-        block's backward looks into)."""
-        holder = {}
-        if self.training and self.rt.fuse_bn_reduce:
-            self.bn_src.setdefault(z.buf.k, []).append((z.c0, z.C, y, co, actc, holder))
-        return holder
-
-    def last_writers(self):
-        """Discovery pass: {(buffer, c0, C) of every registered Conv block output: index into gw_log of the last writer overlapping it}."""
-        res = {}
-        for k, ents in self.bn_src.items():
-            for c0, Cn, *_ in ents:
-                last = -1
-                for i, (k2, lo, hi) in enumerate(self.gw_log):
-                    if k2 == k and not (hi <= c0 or c0 + Cn <= lo):
-                        last = i
-                res[(k, c0, Cn)] = last
-        return res
 
     def _wgrad(self, conv, dy, dy_ptr, cout_pad, x, x_ptr=None, dW=None):
         k, s, pad, OH, OW = self._conv_geom(conv, x)
@@ -776,18 +716,14 @@ class Graph:
             p.res, p.ldr = residual.ptr(), residual.ld
         p.z, p.ldz, p.M, p.C, p.act = z.ptr(), z.ld, y.M, cout, actc
         self._call(self.fwd, "ryolo_bn_act_fwd", p)
-        holder = self._bn_register(z, y, co, actc) if not stem else {}
         if train:
             def backward():
                 bco = self.f32(3, cout)
                 q = S.BnActParams()
                 C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
-                if "pre" in holder:                       # the sums came out of the epilogue of the launch that completed z's gradient
-                    partial, q.pre_rows = holder["pre"]
-                else:
-                    nblk, rpb = S.I(), S.I()
-                    hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
-                    partial = self.f32(nblk.value + 64, 2, cout)
+                nblk, rpb = S.I(), S.I()
+                hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
+                partial = self.f32(nblk.value + 64, 2, cout)
                 q.dz, q.lddz = z.gptr(), z.ld
                 # direct stem: the apply pass moves into the weight-gradient kernel (its only consumer); here statistics only
                 fuse_stem = stem and residual is None and getattr(conv_bwd, "can_fuse_bn", False) and rt.fuse_stem_bn
@@ -867,20 +803,17 @@ class Graph:
             p.z, p.ldz, p.M, p.C, p.act = z.ptr(), z.ld, y.M, cout, S.ACT[m.act]
             self._call(self.fwd, "ryolo_bn_act_fwd", p)
             zs.append(z)
-            parts.append((p, ys, z, bn, cout, self._bn_register(z, ys, co, S.ACT[m.act])))
+            parts.append((p, ys, z, bn, cout))
             off += cout
 
         def backward():
-            for p, ys, z, bn, cout, holder in parts:
+            for p, ys, z, bn, cout in parts:
                 bco = self.f32(3, cout)
                 q = S.BnActParams()
                 C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
-                if "pre" in holder:
-                    partial, q.pre_rows = holder["pre"]
-                else:
-                    nblk, rpb = S.I(), S.I()
-                    hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
-                    partial = self.f32(nblk.value + 64, 2, cout)
+                nblk, rpb = S.I(), S.I()
+                hip.call("ryolo_bn_act_bwd_blocks", y.M, cout, nblk, rpb)
+                partial = self.f32(nblk.value + 64, 2, cout)
                 q.dz, q.lddz = z.gptr(), z.ld
                 q.dy1, q.lddy1 = ys.gptr(), ys.ld
                 q.partial = partial.data_ptr()

@@ -65,13 +65,6 @@ class Runtime:
         self.fwd_fork = os.environ.get("RYOLO_FWD_FORK", "1") != "0"              # sibling branches of ELAN / MaxConv blocks on two streams
         self.wgrad_stream = os.environ.get("RYOLO_WGRAD_STREAM", "1") != "0"      # weight gradients on a second stream (Graph.run)
         # activations and their gradients of a plan as liveness-placed slots of one arena (engine/arena.py); 0 = one tensor per buffer
-        # BatchNorm-backward reduce pass folded into the epilogue of the data-gradient launch that completes the activation gradient
-        self.fuse_bn_reduce = os.environ.get("RYOLO_FUSE_BN_REDUCE", "1") != "0"
-        self.fuse_bn_kernels = int(os.environ.get("RYOLO_FUSE_BN_KERNELS", "3"))      # bit 0: generic GEMM launches, bit 1: 3x3 halo-patch launches
-        # only launches with M * N up to this fold the sums.  Default 0 = no launch does (r04): with the reduce pass at 5 waves per SIMD and one row
-        # of read-ahead the stand-alone pass beats the fold at every size (8-image step 513 vs 506.5 img/s at the old 32e6 gate, 3 alternating runs
-        # each on one box; 64 images equal); the fold stays parity-tested and reachable (tests/test_gpu_bnfuse.py, A/B in DESIGN.md)
-        self.fuse_bn_max_elems = int(float(os.environ.get("RYOLO_FUSE_BN_MAX_ELEMS", "0")))
         self.buffer_reuse = os.environ.get("RYOLO_BUFFER_REUSE", "1") != "0"
         self.wgrad_lanes = int(os.environ.get("RYOLO_WGRAD_LANES", "1"))          # weight gradients round-robin over this many side streams
         self.wgrad_lag = int(os.environ.get("RYOLO_WGRAD_LAG", "8"))             # weight gradients the side stream may fall behind by
@@ -236,27 +229,17 @@ class Runtime:
         if g is None:
             if not self.check_resident():
                 raise RuntimeError("ryolov4_amd: parameters were moved after the first forward; build a new Yolo/runtime")
-            last_writer = None
-            if training and self.fuse_bn_reduce:
-                # discovery pass: which launch completes the gradient of every Conv block's activation (it takes over the BatchNorm-
-                # backward reduce pass in its epilogue, ConvGemmParams.bstat)
-                disc = Graph(self, B, H, W, training, frozen, dry=True)
-                disc.begin()
-                self.model._emit(disc)
-                disc.finish()
-                last_writer = disc.last_writers()
-                del disc
             layout = None
             if self.buffer_reuse:
                 # liveness pass on virtual addresses, then the real plan on one arena (engine/arena.py)
                 from . import arena
-                dry = Graph(self, B, H, W, training, frozen, dry=True, last_writer=last_writer)
+                dry = Graph(self, B, H, W, training, frozen, dry=True)
                 dry.begin()
                 self.model._emit(dry)
                 dry.finish()
                 layout = arena.plan(dry, self.wgrad_lag if self.wgrad_stream else 0)
                 del dry
-            g = Graph(self, B, H, W, training, frozen, layout=layout, last_writer=last_writer)
+            g = Graph(self, B, H, W, training, frozen, layout=layout)
             g.begin()
             self.model._emit(g)
             g.finish()

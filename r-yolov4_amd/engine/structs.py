@@ -15,19 +15,12 @@ class TapClass(C.Structure):
                 ("widx", C.c_byte * MAX_TAPS)]
 
 
-MAX_BSTAT = 4
-
-
-class BwdStat(C.Structure):
-    _fields_ = [("y", P), ("co", P), ("part", P), ("ldy", I), ("C", I), ("n0", I), ("act", I)]
-
-
 class ConvGemmParams(C.Structure):
     _fields_ = [("A", P), ("NB", I), ("IH", I), ("IW", I), ("Cin", I), ("ldA", I),
                 ("W", P), ("Nout", I), ("wtaps", I), ("OH", I), ("OW", I), ("sh", I), ("sw", I),
                 ("oh_mul", I), ("ow_mul", I), ("OHf", I), ("OWf", I), ("nclasses", I), ("cls", TapClass * 4),
                 ("epi", I), ("out", P), ("ldC", I), ("stats", P), ("scale", P), ("shift", P), ("act", I), ("bias", P), ("zeros", P), ("pipe", I), ("a_bytes", C.c_uint), ("w_bytes", C.c_uint),
-                ("pool_idx", P), ("pool_dz", P), ("pool_ldi", I), ("pool_ld", I), ("s2d_cin", I), ("nbstat", I), ("bstat", BwdStat * MAX_BSTAT), ("head_attrs", I), ("head_och", I)]
+                ("pool_idx", P), ("pool_dz", P), ("pool_ldi", I), ("pool_ld", I), ("s2d_cin", I), ("head_attrs", I), ("head_och", I)]
 
 
 class WgradParams(C.Structure):
@@ -56,7 +49,7 @@ class BnActParams(C.Structure):
     _fields_ = [("y1", P), ("ld1", I), ("co1", P), ("y2", P), ("ld2", I), ("co2", P), ("res", P), ("ldr", I),
                 ("z", P), ("ldz", I), ("M", L), ("C", I), ("act", I),
                 ("dz", P), ("lddz", I), ("dy1", P), ("lddy1", I), ("dy2", P), ("lddy2", I),
-                ("dres", P), ("lddres", I), ("dres_accum", I), ("partial", P), ("bco", P), ("rows_per_block", I), ("pre_rows", I)]
+                ("dres", P), ("lddres", I), ("dres_accum", I), ("partial", P), ("bco", P), ("rows_per_block", I)]
 
 
 class PoolParams(C.Structure):

@@ -79,7 +79,6 @@ def test_every_conv_bn_act_node_of_the_training_plan_teacher_forced(ver, mode):
     net.to(DEV).train()
     rt = net.runtime()
     rt.record_tape = True
-    rt.fuse_bn_reduce = False          # (see the module docstring)
     rt.fuse_pool_grad = False
     g = rt.graph(B, Sz, Sz, True)
     names = {id(m): n for n, m in net.named_modules()}
