@@ -6,12 +6,15 @@
 // LDS-DMA requests, not by bytes.  ("put the 32 -> 64 @800^2 -> 400^2 layer ... on a streaming kernel like the stem's".)
 //
 // This kernel has NO LDS-DMA and no K loop over staged tiles:
-//   * K = 9 taps x 32 channels = 288 = 18 MFMA steps of 16.  The whole weight matrix (64 x 288 bf16 = 36 KiB) sits in LDS for the life of the
-//     (persistent, one per CU) workgroup in FRAGMENT-MAJOR order: fragment (step, output-channel half) is 64 lanes x 16 bytes, read with one
-//     lane-linear ds_read_b128 (conflict-free by construction).
-//   * A wave owns tiles of 32 output pixels (one output row segment) x all 64 output channels: 2 accumulator tiles, 36 MFMAs
-//     (v_mfma_f32_32x32x16_bf16, A = weights, B = pixels: a lane ends up with 4 consecutive channels of ONE pixel).
-//   * The B fragment of step (tap, channel half) for lane (pixel p, k half) is 8 consecutive channels of input pixel (2 oh + kh - 1, 2 ow + kw - 1):
+//   * K = 9 taps x 32 channels = 288.  The whole weight matrix (64 x 288 bf16 = 36 KiB) sits in LDS for the life of the (persistent, one per CU)
+//     workgroup in FRAGMENT-MAJOR order: fragment (tap, output-channel quarter) is 64 lanes x 16 bytes, read with one lane-linear ds_read_b128
+//     (conflict-free by construction).
+//   * A wave owns tiles of 32 output pixels (one output row segment) x all 64 output channels: 8 accumulator tiles of 16 x 16, 72 MFMAs
+//     (v_mfma_f32_16x16x32_bf16, A = weights, B = pixels: a lane ends up with 4 consecutive channels of ONE pixel).  K = 32 per MFMA = ALL input
+//     channels of a tap: a B fragment is 16 pixels x 64 contiguous bytes.  (The first cut used 32x32x16: 32 pixels x 32 bytes per load instruction —
+//     1 006 us, and the counters named the bound: TCP_TOTAL_CACHE_ACCESSES 395 M per launch = 0.77 tag look-ups per cycle and CU, FETCH_SIZE 1.05 x the
+//     tensor: the L1's tag rate, not HBM.  Half as many pixels per instruction = half the look-ups per byte.)
+//   * The B fragment of (tap, pixel half) for lane (pixel p, channel octet) is 8 consecutive channels of input pixel (2 oh + kh - 1, 2 ow + kw - 1):
 //     ONE 16-byte global load straight into the MFMA operand registers.  The 18 loads of tile t + 1 are issued before the MFMAs of tile t
 //     (two register sets, 144 VGPRs): 18 KiB in flight per wave, 147 KiB per CU — what a byte-bound kernel needs to cover HBM latency.
 //     The nine taps of a tile touch 3 input rows x 65 pixels; a wave walks DOWN the output rows of its 32-pixel column block, so two of the three
@@ -24,9 +27,11 @@
 #include "conv_internal.h"
 #include <stdlib.h>
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
 #define S2C_WAVES 8
-#define S2C_STEPS 18                       // 9 taps x 2 channel halves of 16
-#define S2C_WFRAG (2 * S2C_STEPS)          // weight fragments: (step, output-channel half), 1 KiB each
+#define S2C_STEPS 18                       // B fragments of a tile: 9 taps x 2 pixel halves of 16 (v_mfma_f32_16x16x32_bf16: one fragment = 16 pixels x 32 channels)
+#define S2C_WFRAG 36                       // weight fragments: (tap, output-channel quarter), 1 KiB each
 #define S2C_W_ELEMS (S2C_WFRAG * 64 * 8)   // 18 432 bf16 = 36 KiB
 #define S2C_STAGE_ELEMS (32 * 64)          // per wave: [32 px][64 ch] bf16 = 4 KiB
 
@@ -39,12 +44,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_kernel(const ConvGemmPar
     bf16_t* const stage = s2c_lds + S2C_W_ELEMS + wave * S2C_STAGE_ELEMS;      // this wave's staging tile
     float* const red = reinterpret_cast<float*>(s2c_lds + S2C_W_ELEMS + S2C_WAVES * S2C_STAGE_ELEMS);   // [8 waves][2][64] statistics fold / [2][64] coefficients
 
-    // ---- weights -> LDS, fragment-major: fragment f = 2 * step + half; lane l of it = row (half * 32 + l % 32), k = step * 16 + 8 * (l / 32) ----
+    // ---- weights -> LDS, fragment-major: fragment f = 4 * tap + quarter; lane l of it = row (16 * quarter + l % 16), channels [8 (l / 16), + 8) of the tap ----
     for (int idx = tid; idx < S2C_WFRAG * 64; idx += 512) {
         const int f = idx >> 6, l = idx & 63;
-        const int row = (f & 1) * 32 + (l & 31);
+        const int row = (f & 3) * 16 + (l & 15);
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < p.Nout) v = *reinterpret_cast<const uint4*>(p.W + (int64_t)row * (9 * 32) + (f >> 1) * 16 + (l >> 5) * 8);
+        if (row < p.Nout) v = *reinterpret_cast<const uint4*>(p.W + (int64_t)row * (9 * 32) + (f >> 2) * 32 + (l >> 4) * 8);
         *reinterpret_cast<uint4*>(wl + (int64_t)idx * 8) = v;
     }
     if constexpr (EPI == EPI_AFFINE_ACT) {
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_kernel(const ConvGemmPar
     }
     __syncthreads();
 
-    const int pl = lane & 31, hk = lane >> 5;                                  // pixel of the tile, k half (MFMA B operand) / channel-quad half (accumulator)
+    const int pn = lane & 15, kq = lane >> 4;                                  // pixel of a 16-pixel half, channel octet (B operand) / channel quad of a 16-channel quarter (accumulator)
     const int64_t gw = (int64_t)blockIdx.x * S2C_WAVES + wave, nw = (int64_t)gridDim.x * S2C_WAVES;
     // contiguous tile range per wave: consecutive tiles of a wave are consecutive OUTPUT ROWS of one (image, column block)
     const int64_t t0 = tiles * gw / nw, t1 = tiles * (gw + 1) / nw;
@@ -70,57 +75,60 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_kernel(const ConvGemmPar
 
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // the 18 B fragments of tile t: lane (pl, hk) reads channels [16 c + 8 hk, + 8) of input pixel (2 oh + kh - 1, 2 (32 cb + pl) + kw - 1)
+    // the 18 B fragments of a tile: fragment (tap, half u), lane (pn, kq) reads channels [8 kq, + 8) of input pixel
+    // (2 oh + kh - 1, 2 (32 cb + 16 u + pn) + kw - 1) — four lanes cover the pixel's 64 contiguous bytes, an instruction touches 16 pixels
+    // (the 32x32x16 form of the first cut touched 32 pixels x 32 bytes per instruction: PMC showed the L1's tag rate, not HBM, as its bound)
+    auto load_frag = [&](const Pos& q, int tap, int u) -> bf16x8 {               // (tap, u are compile-time at every call site)
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int iy = 2 * q.oh + kh - 1;
+        const int ow = q.cb * 32 + u * 16 + pn;
+        const int ix = 2 * ow + kw - 1;
+        const bool ok = (unsigned)iy < (unsigned)p.IH && ow < p.OW && (unsigned)ix < (unsigned)p.IW;
+        const bf16_t* src = ok ? p.A + (((int64_t)q.n * p.IH + iy) * p.IW + ix) * p.ldA + kq * 8 : zp;
+        return *reinterpret_cast<const bf16x8*>(src);
+    };
     auto load_tile = [&](const Pos& q, bf16x8 (&b)[S2C_STEPS]) {
-        const int n = q.n, cb = q.cb, oh = q.oh;
-        const int ow = cb * 32 + pl;
-        const bf16_t* const img = p.A + (int64_t)n * p.IH * p.IW * p.ldA + hk * 8;
 #pragma unroll
-        for (int kh = 0; kh < 3; kh++) {
-            const int iy = 2 * oh + kh - 1;
-            const bool rok = (unsigned)iy < (unsigned)p.IH && ow < p.OW;
+        for (int tap = 0; tap < 9; tap++)
 #pragma unroll
-            for (int kw = 0; kw < 3; kw++) {
-                const int ix = 2 * ow + kw - 1;
-                const bool ok = rok && (unsigned)ix < (unsigned)p.IW;
-                const bf16_t* src = ok ? img + ((int64_t)iy * p.IW + ix) * p.ldA : zp;
-                const int s = (kh * 3 + kw) * 2;
-                b[s] = *reinterpret_cast<const bf16x8*>(src);
-                b[s + 1] = *reinterpret_cast<const bf16x8*>(src + 16);
-            }
-        }
+            for (int u = 0; u < 2; u++) b[tap * 2 + u] = load_frag(q, tap, u);
     };
 
+    // (Measured and not kept: refilling every fragment with the tile after next as soon as its MFMAs are issued — two tiles of loads in flight per
+    // wave without a third register set.  Same box, three alternating runs: forward 1 058 vs 1 035 us, data gradient 1 151 vs 1 089 us — SLOWER: the
+    // launch is not short of bytes in flight.  What the counters say about the 3.8-4.0 TB/s it reaches: DESIGN.md section 3.3.)
     auto compute_tile = [&](const Pos& q, const bf16x8 (&b)[S2C_STEPS]) {
-        f32x16 acc[2];
+        f32x4 acc[2][4];                                                       // [pixel half u][output-channel quarter]: rows 4 kq + i of the quarter, column pn
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+            for (int qq = 0; qq < 4; qq++) acc[u][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < S2C_STEPS; s++) {
-            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wl + ((2 * s) * 64 + lane) * 8);
-            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + ((2 * s + 1) * 64 + lane) * 8);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[s], acc[1], 0, 0, 0);
+        for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(wl + ((tap * 4 + qq) * 64 + lane) * 8);
+                acc[0][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b[tap * 2], acc[0][qq], 0, 0, 0);
+                acc[1][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b[tap * 2 + 1], acc[1][qq], 0, 0, 0);
+            }
         }
         // ---- epilogue: stage [32 px][64 ch]; 16-byte chunk ck of pixel row r sits at chunk ck ^ (r & 7) ----
         const int n = q.n, cb = q.cb, oh = q.oh;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
+            for (int qq = 0; qq < 4; qq++) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[j][4 * g4 + e];
+                for (int e = 0; e < 4; e++) v[e] = acc[u][qq][e];
+                const int c0 = 16 * qq + 4 * kq;                                // the lane's 4 consecutive output channels of pixel row r
                 if constexpr (EPI == EPI_AFFINE_ACT) {
-                    const int c0 = j * 32 + 8 * g4 + 4 * hk;
                     const float4 sc = *reinterpret_cast<const float4*>(red + c0), sf = *reinterpret_cast<const float4*>(red + 64 + c0);
                     const float sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sf4[4] = {sf.x, sf.y, sf.z, sf.w};
                     act_affine_quad(v, sc4, sf4, p.act);
                 }
-                const int ck = j * 4 + g4;
-                *reinterpret_cast<uint2*>(stage + pl * 64 + ((ck ^ (pl & 7)) << 3) + 4 * hk) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                const int r = 16 * u + pn, ck = c0 >> 3;
+                *reinterpret_cast<uint2*>(stage + r * 64 + ((ck ^ (r & 7)) << 3) + (c0 & 4)) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             }
         // (same-wave LDS hand-off: the wave's own ds_write -> ds_read ordering)
         const int c8 = lane & 7, r8 = lane >> 3;                                // store phase: chunk c8 of rows r8 + 8 it
@@ -153,28 +161,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_kernel(const ConvGemmPar
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
-    // Two register sets: the 18 loads of the NEXT tile are in flight under the MFMAs and the epilogue of the current one.  The steady state has
-    // no conditional load (a load under a branch is a CFG join where hipcc drains vmcnt(0)): past the wave's last tile the cursor simply stays
-    // on it and the (unused) fragment set is loaded again.
+    // Two register sets: the 18 loads of the NEXT tile are in flight under the MFMAs and the epilogue of the current one.  The steady state has no
+    // load that depends on "is there a next tile" (a load under such a branch is a CFG join where hipcc drains vmcnt(0)): past the wave's last tile
+    // the head cursor simply stays on it and the (unused) fragments are loaded again.
     bf16x8 ba[S2C_STEPS], bb[S2C_STEPS];
     if (t0 < t1) {
-        Pos cur, nxt;
-        cur.n = (int)(t0 / per_img);
-        const int rem0 = (int)(t0 - (int64_t)cur.n * per_img);
-        cur.cb = rem0 / p.OH;
-        cur.oh = rem0 - cur.cb * p.OH;
-        nxt = cur;
-        load_tile(cur, ba);
+        Pos head;
+        head.n = (int)(t0 / per_img);
+        const int rem0 = (int)(t0 - (int64_t)head.n * per_img);
+        head.cb = rem0 / p.OH;
+        head.oh = rem0 - head.cb * p.OH;
+        int64_t th = t0;                                                       // tile index of `head`: the newest tile whose loads were issued
+        auto next = [&]() { if (th + 1 < t1) { advance(head); th++; } return head; };
+        Pos pa = head;
+        load_tile(pa, ba);
         for (int64_t t = t0; t < t1; t += 2) {
-            if (t + 1 < t1) advance(nxt);
-            load_tile(nxt, bb);
-            compute_tile(cur, ba);
+            const Pos pb = next();
+            load_tile(pb, bb);                                                 // tile t + 1: in flight under the MFMAs and the epilogue of tile t
+            compute_tile(pa, ba);
             if (t + 1 >= t1) break;
-            cur = nxt;
-            if (t + 2 < t1) advance(nxt);
-            load_tile(nxt, ba);
-            compute_tile(cur, bb);
-            cur = nxt;
+            pa = next();
+            load_tile(pa, ba);                                                 // tile t + 2 under tile t + 1
+            compute_tile(pb, bb);
         }
     }
 
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_kernel(const ConvGemmPar
 // (128 rows x 4 taps x 64 channels with the 7 dead blocks left out = 36 KiB) in LDS, the 16 B fragments of a tile (4 taps x 4 channel steps)
 // loaded straight into the MFMA operand registers one tile ahead, the 128 x 32 result staged as TWO contiguous 4-KiB runs (input rows 2a and
 // 2a + 1, 64 pixels x 64 bytes each) and stored 1 KiB per wave instruction.
-#define S2D_BSTEPS 16                      // 4 taps x 4 channel steps of 16
+#define S2D_BSTEPS 16                      // B fragments of a tile: 4 taps x 2 channel steps of 32 x 2 pixel halves of 16
 #define S2D_STAGE_ELEMS (2 * 64 * 32)      // per wave: [2 rows][64 px][32 ch] bf16 = 8 KiB
 
 __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_dgrad_kernel(const ConvGemmParams p, const int cblocks, const int64_t tiles)
@@ -222,20 +230,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_dgrad_kernel(const ConvG
     bf16_t* const wl = s2c_lds;
     bf16_t* const stage = s2c_lds + S2C_W_ELEMS + wave * S2D_STAGE_ELEMS;
 
-    // ---- weights -> LDS: fragment f enumerates the live (plane, tap) pairs in MFMA issue order x 4 channel steps:
+    // ---- weights -> LDS: fragment f = ((pair * 2 + channel step s2) * 2 + row half mh); `pair` enumerates the live (plane, tap) pairs in MFMA issue order:
     //   tap (0,0): planes 0 1 2 3;  tap (0,1): planes 1 3;  tap (1,0): planes 2 3;  tap (1,1): plane 3      (plane = 2 ph + pw, tap = 2 da + db)
-    // lane l of a fragment = weight-image row (plane * 32 + l % 32), tap, channels [16 s + 8 (l / 32), + 8) of pack_s2d's [128][4][64] image
+    // lane l of a fragment = weight-image row (plane * 32 + 16 mh + l % 16), tap, channels [32 s2 + 8 (l / 16), + 8) of pack_s2d's [128][4][64] image
     for (int idx = tid; idx < S2C_WFRAG * 64; idx += 512) {
         const int f = idx >> 6, l = idx & 63;
-        const int pair = f >> 2, s4 = f & 3;
+        const int pair = f >> 2, s2 = (f >> 1) & 1, mh = f & 1;
         const int tap = pair < 4 ? 0 : (pair < 6 ? 1 : (pair < 8 ? 2 : 3));
         const int plane = pair < 4 ? pair : (pair < 6 ? 1 + 2 * (pair - 4) : (pair < 8 ? 2 + (pair - 6) : 3));
-        const uint4 v = *reinterpret_cast<const uint4*>(p.W + ((int64_t)(plane * 32 + (l & 31)) * 4 + tap) * p.Cin + s4 * 16 + (l >> 5) * 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(p.W + ((int64_t)(plane * 32 + 16 * mh + (l & 15)) * 4 + tap) * p.Cin + s2 * 32 + (l >> 4) * 8);
         *reinterpret_cast<uint4*>(wl + (int64_t)idx * 8) = v;
     }
     __syncthreads();
 
-    const int pl = lane & 31, hk = lane >> 5;
+    const int pn = lane & 15, kq = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * S2C_WAVES + wave, nw = (int64_t)gridDim.x * S2C_WAVES;
     const int64_t t0 = tiles * gw / nw, t1 = tiles * (gw + 1) / nw;
     const int64_t per_img = (int64_t)cblocks * p.OH;
@@ -246,53 +254,67 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_dgrad_kernel(const ConvG
         if (q.oh == p.OH) { q.oh = 0; q.cb++; if (q.cb == cblocks) { q.cb = 0; q.n++; } }
     };
 
-    // B fragments of a tile: lane (pl, hk) reads channels [16 s + 8 hk, + 8) of dY pixel (a + da, 32 cb + pl + db)
+    // B fragments of a tile: fragment ((tap * 2 + s2) * 2 + u), lane (pn, kq) reads channels [32 s2 + 8 kq, + 8) of dY pixel (a + da, 32 cb + 16 u + pn + db):
+    // four lanes cover 64 contiguous bytes of the pixel, an instruction touches 16 pixels
+    auto load_frag = [&](const Pos& q, int tap, int s2, int u) -> bf16x8 {      // (tap, s2, u are compile-time at every call site)
+        const int da = tap >> 1, db = tap & 1;
+        const int iy = q.oh + da;
+        const int bcol = q.cb * 32 + u * 16 + pn;
+        const int ix = bcol + db;
+        const bool ok = iy < p.OH && bcol < p.OW && ix < p.OW;
+        const bf16_t* src = ok ? p.A + (((int64_t)q.n * p.OH + iy) * p.OW + ix) * p.ldA + kq * 8 + s2 * 32 : zp;
+        return *reinterpret_cast<const bf16x8*>(src);
+    };
     auto load_tile = [&](const Pos& q, bf16x8 (&b)[S2D_BSTEPS]) {
-        const int bcol = q.cb * 32 + pl;
-        const bf16_t* const img = p.A + (int64_t)q.n * p.OH * p.OW * p.ldA + hk * 8;
 #pragma unroll
-        for (int da = 0; da < 2; da++) {
-            const int iy = q.oh + da;
-            const bool rok = iy < p.OH && bcol < p.OW;
+        for (int tap = 0; tap < 4; tap++)
 #pragma unroll
-            for (int db = 0; db < 2; db++) {
-                const int ix = bcol + db;
-                const bool ok = rok && ix < p.OW;
-                const bf16_t* src = ok ? img + ((int64_t)iy * p.OW + ix) * p.ldA : zp;
-                const int t4 = (da * 2 + db) * 4;
+            for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) b[t4 + s] = *reinterpret_cast<const bf16x8*>(src + s * 16);
-            }
-        }
+                for (int u = 0; u < 2; u++) b[(tap * 2 + s2) * 2 + u] = load_frag(q, tap, s2, u);
     };
 
     auto compute_tile = [&](const Pos& q, const bf16x8 (&b)[S2D_BSTEPS]) {
-        f32x16 acc[4];
+        f32x4 acc[2][4][2];                                                    // [pixel half u][plane][row half mh]: input channels 16 mh + 4 kq + i, dY pixel pn
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
-        // fragment order = the enumeration above
-        constexpr int PAIR_TAP[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int mh = 0; mh < 2; mh++) acc[u][j][mh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // pairs (plane, tap) in weight-fragment order: tap 0 -> pairs 0..3 (planes 0 1 2 3), tap 1 -> 4, 5 (planes 1, 3), tap 2 -> 6, 7 (planes 2, 3), tap 3 -> 8 (plane 3)
+        constexpr int TAP_FIRST[5] = {0, 4, 6, 8, 9};
         constexpr int PAIR_PLANE[9] = {0, 1, 2, 3, 1, 3, 2, 3, 3};
 #pragma unroll
-        for (int pair = 0; pair < 9; pair++)
+        for (int tap = 0; tap < 4; tap++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(wl + ((pair * 4 + s) * 64 + lane) * 8);
-                acc[PAIR_PLANE[pair]] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b[PAIR_TAP[pair] * 4 + s], acc[PAIR_PLANE[pair]], 0, 0, 0);
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int bt = (tap * 2 + s2) * 2;
+#pragma unroll
+                for (int pair = TAP_FIRST[tap]; pair < TAP_FIRST[tap + 1]; pair++)
+#pragma unroll
+                    for (int mh = 0; mh < 2; mh++) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wl + (((pair * 2 + s2) * 2 + mh) * 64 + lane) * 8);
+                        const int pln = PAIR_PLANE[pair];
+                        acc[0][pln][mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b[bt], acc[0][pln][mh], 0, 0, 0);
+                        acc[1][pln][mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b[bt + 1], acc[1][pln][mh], 0, 0, 0);
+                    }
             }
-        // ---- epilogue: stage [2 input rows ph][64 input pixels 2 pl + pw][32 ch]; 16-byte chunk c of pixel x sits at chunk c ^ ((x >> 1) & 3) ----
+        // ---- epilogue: stage [2 input rows ph][64 input pixels 2 (16 u + pn) + pw][32 ch]; 16-byte chunk c of pixel x sits at chunk c ^ ((x >> 1) & 3) ----
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int ph = j >> 1, pw = j & 1;
-            const int x = 2 * pl + pw;
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const uint2 v = make_uint2(pack_bf2(acc[j][4 * g4], acc[j][4 * g4 + 1]), pack_bf2(acc[j][4 * g4 + 2], acc[j][4 * g4 + 3]));
-                *reinterpret_cast<uint2*>(stage + (ph * 64 + x) * 32 + ((g4 ^ (pl & 3)) << 3) + 4 * hk) = v;
+            for (int j = 0; j < 4; j++) {
+                const int ph = j >> 1, pw = j & 1;
+                const int x = 2 * (16 * u + pn) + pw;
+#pragma unroll
+                for (int mh = 0; mh < 2; mh++) {
+                    const f32x4 a4 = acc[u][j][mh];
+                    const int c0 = 16 * mh + 4 * kq;
+                    *reinterpret_cast<uint2*>(stage + (ph * 64 + x) * 32 + (((c0 >> 3) ^ (pn & 3)) << 3) + (c0 & 4)) =
+                        make_uint2(pack_bf2(a4[0], a4[1]), pack_bf2(a4[2], a4[3]));
+                }
             }
-        }
         // store: per input row one contiguous run of 64 pixels x 64 bytes (channel stride ldC: contiguous when the tensor is not a slice).
         // No branch around the stores of a row (a CFG join in front of in-flight loads makes hipcc drain vmcnt(0)): the row test is part of the
         // per-lane store predicate.
@@ -315,23 +337,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c32_dgrad_kernel(const ConvG
 
     bf16x8 ba[S2D_BSTEPS], bb[S2D_BSTEPS];
     if (t0 < t1) {
-        Pos cur, nxt;
-        cur.n = (int)(t0 / per_img);
-        const int rem0 = (int)(t0 - (int64_t)cur.n * per_img);
-        cur.cb = rem0 / p.OH;
-        cur.oh = rem0 - cur.cb * p.OH;
-        nxt = cur;
-        load_tile(cur, ba);
+        Pos head;
+        head.n = (int)(t0 / per_img);
+        const int rem0 = (int)(t0 - (int64_t)head.n * per_img);
+        head.cb = rem0 / p.OH;
+        head.oh = rem0 - head.cb * p.OH;
+        int64_t th = t0;
+        auto next = [&]() { if (th + 1 < t1) { advance(head); th++; } return head; };
+        Pos pa = head;
+        load_tile(pa, ba);
         for (int64_t t = t0; t < t1; t += 2) {
-            if (t + 1 < t1) advance(nxt);
-            load_tile(nxt, bb);
-            compute_tile(cur, ba);
+            const Pos pb = next();
+            load_tile(pb, bb);                                                 // tile t + 1: in flight under the MFMAs and the epilogue of tile t
+            compute_tile(pa, ba);
             if (t + 1 >= t1) break;
-            cur = nxt;
-            if (t + 2 < t1) advance(nxt);
-            load_tile(nxt, ba);
-            compute_tile(cur, bb);
-            cur = nxt;
+            pa = next();
+            load_tile(pa, ba);                                                 // tile t + 2 under tile t + 1
+            compute_tile(pb, bb);
         }
     }
 }
@@ -360,6 +382,9 @@ bool s2c_geometry(const ConvGemmParams& p, S2cGeom& g)
     g.cblocks = (p.OW + 31) / 32;
     g.tiles = (int64_t)p.NB * g.cblocks * p.OH;
     if (g.tiles <= 0 || (int64_t)p.NB * p.IH * p.IW >= (1ll << 31)) return false;
+    // a persistent workgroup pays for its 36-KiB weight tile and its two-tile prologue: below ~4 tiles per wave the generic kernel's small tiles win
+    // (one 800 x 800 image, 5 200 tiles: 22.8 vs 21.1 us).  pipe bit 0x400 (the tests' "also on small grids" bit) overrides.
+    if (g.tiles < 8192 && !(p.pipe & 0x400)) return false;
     // one persistent 8-wave workgroup per CU; small problems get as many workgroups as there are groups of 8 tiles
     const int64_t want = (g.tiles + S2C_WAVES - 1) / S2C_WAVES;
     g.nwg = (int)(want < 256 ? want : 256);
@@ -406,6 +431,7 @@ bool s2c_dgrad_geometry(const ConvGemmParams& p, S2cGeom& g)
     g.cblocks = (p.OW + 31) / 32;
     g.tiles = (int64_t)p.NB * g.cblocks * p.OH;
     if (g.tiles <= 0 || (int64_t)p.NB * p.OHf * p.OWf >= (1ll << 31)) return false;
+    if (g.tiles < 8192 && !(p.pipe & 0x400)) return false;
     const int64_t want = (g.tiles + S2C_WAVES - 1) / S2C_WAVES;
     g.nwg = (int)(want < 256 ? want : 256);
     g.lds_bytes = (unsigned)(S2C_W_ELEMS * 2 + S2C_WAVES * S2D_STAGE_ELEMS * 2);

@@ -39,7 +39,7 @@ def _run(B, H, W, Cout, epi=0, ldx_extra=0, ldc_extra=0, act=3, seed=0, expect=5
     for i in range(9):
         p.cls[0].dh[i], p.cls[0].dw[i], p.cls[0].widx[i] = i // 3 - 1, i % 3 - 1, i
     p.epi, p.out, p.ldC = epi, od.data_ptr(), ldC
-    p.zeros, p.pipe = zeros.data_ptr(), 0x301
+    p.zeros, p.pipe = zeros.data_ptr(), 0x701          # 0x400: also on grids below the size gate
     co = torch.rand(4, Cout, generator=g) + 0.5
     co[3] -= 1.0
     cod = co.to(dev)
@@ -114,6 +114,27 @@ def test_other_shapes_stay_on_the_other_kernels():
     assert kern.value & 0xff != 5
 
 
+def test_small_grids_stay_on_the_generic_kernel_by_default():
+    """Below 8 192 wave tiles (about four per wave) the persistent kernels do not pay for their weight tile: one 800 x 800 image stays generic."""
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S
+    hip.lib()
+    p = S.ConvGemmParams()
+    z = torch.zeros(4096, device="cuda:0")
+    p.A = p.W = p.out = p.zeros = z.data_ptr()
+    p.NB, p.IH, p.IW, p.Cin, p.ldA, p.Nout, p.wtaps, p.OH, p.OW, p.sh, p.sw = 1, 800, 800, 32, 32, 64, 9, 400, 400, 2, 2
+    p.oh_mul, p.ow_mul, p.OHf, p.OWf, p.nclasses, p.ldC, p.pipe = 1, 1, 400, 400, 1, 64, 0x301
+    p.cls[0].ntaps = 9
+    for i in range(9):
+        p.cls[0].dh[i], p.cls[0].dw[i], p.cls[0].widx[i] = i // 3 - 1, i % 3 - 1, i
+    rows, kern = S.I(), S.I()
+    hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+    assert kern.value & 0xff == 0
+    p.NB = 8
+    hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+    assert kern.value & 0xff == 5
+
+
 # ---- the data gradient of the same layer in its space-to-depth form (conv3x3s2_c32_dgrad_kernel; dispatch code 6) ---------------------------------
 def _run_dgrad(B, H, W, ldy_extra=0, ldx_extra=0, seed=0, expect=6):
     import torch.nn.functional as F
@@ -143,7 +164,7 @@ def _run_dgrad(B, H, W, ldy_extra=0, ldx_extra=0, seed=0, expect=6):
     for i in range(4):
         p.cls[0].dh[i], p.cls[0].dw[i], p.cls[0].widx[i] = i >> 1, i & 1, i
     p.epi, p.out, p.ldC = 0, dxd.data_ptr(), ldX
-    p.zeros, p.pipe, p.s2d_cin = zeros.data_ptr(), 0x301, Cin
+    p.zeros, p.pipe, p.s2d_cin = zeros.data_ptr(), 0x701, Cin
     rows, kern = S.I(), S.I()
     hip.call("ryolo_conv_gemm_plan", p, rows, kern)
     assert kern.value & 0xff == expect, f"dispatch picked kernel {kern.value:#x}"
