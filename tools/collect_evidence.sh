@@ -1,13 +1,17 @@
-# End-of-round evidence on ONE GPU box (run from the repo root through gpurun; round 5): PMC step traffic, default bench line, rocprofv3 kernel
-# stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/r05m/
+# End-of-round evidence on ONE GPU box (run from the repo root through gpurun): PMC step traffic + matrix-pipe occupancy, default bench line, rocprofv3
+# kernel stats (b64, b8), per-launch tables, NMS / inference timings, other configurations, batch sweep, overfit curves, DP checks -> gpurun_out/<tag>m/
+# usage: bash tools/collect_evidence.sh [round tag, default r06]
+TAG=${1:-r06}
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05m
+O=$R/gpurun_out/${TAG}m
 mkdir -p $O
 cd $R
-# 1. PMC traffic of the step (then the bench line reads it)
-timeout 1500 bash tools/pmc_step.sh r05 > $O/pmc_step.txt 2>&1
-cp gpurun_out/r05_pmc_step_traffic.json profiles/r05_pmc_step_traffic.json
+# 1. PMC traffic of the step (then the bench line reads it) and the whole-step matrix-pipe occupancy (r06)
+timeout 1500 bash tools/pmc_step.sh $TAG > $O/pmc_step.txt 2>&1
+cp gpurun_out/${TAG}_pmc_step_traffic.json profiles/${TAG}_pmc_step_traffic.json
+timeout 1500 bash tools/pmc_step_mfma.sh $TAG > $O/pmc_step_mfma.txt 2>&1
+cp gpurun_out/${TAG}_pmc_step_mfma_busy.json profiles/${TAG}_pmc_step_mfma_busy.json
 # 2. default bench line
 ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
 # 3. rocprofv3 kernel stats, serialized streams, b64 and b8
@@ -19,18 +23,17 @@ cd $R
 B=64 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b64.txt 2>&1
 B=8 TOP=400 RYOLO_WGRAD_STREAM=0 RYOLO_FWD_FORK=0 timeout 600 python tools/profile_layers.py > $O/per_launch_b8.txt 2>&1
 python tools/highres_floor_table.py $O/per_launch_b64.txt > $O/highres_layers_vs_floor.txt 2>&1
-# 4a. the 8-wave weight-gradient kernels ALONE: whole-chip grids (256 workgroups) and the shipped part-of-the-chip grids (96), old 4-wave kernels beside them
+# 4a. r06: the streaming kernels of the 32 -> 64 stride-2 layer against the kernels they replace, alternating (the 8-wave weight-gradient kernels are
+# unchanged since r05: profiles/r05_wgrad_isolated.txt and profiles/r05_pmc_wgrad_ring/ stand)
 set +x
-( for sh in "64 100 128 128 3" "64 50 256 256 3" "64 25 512 512 3" "64 100 64 64 3" "64 200 64 64 3" "64 400 64 64 3" "64 100 128 256 3" "64 200 256 256 1" "64 100 512 512 1" "64 50 1024 1024 1" "64 25 2048 512 1"; do
-    set -- $sh
-    for cfg in "RYOLO_W3_V8=0 RYOLO_WGRAD_8W=0" "RYOLO_W3_V8_BLOCKS=256 RYOLO_WGRAD_8W_BLOCKS=256" "RYOLO_W3_V8_BLOCKS=96 RYOLO_WGRAD_8W_BLOCKS=96"; do
-      echo "[$cfg] $(env $cfg CHECK=0 python tools/bench_wgrad.py $1 $2 $3 $4 $5 1 20 2>&1 | tail -1)"
-    done
-  done ) > $O/wgrad_isolated.txt 2>&1
+( for i in 1 2 3; do
+    echo "new  $(python tools/bench_s2c32.py 2>&1 | tail -1) | $(MODE=fwd python tools/bench_s2c32.py 2>&1 | tail -1)"
+    echo "old  $(RYOLO_S2C32_DGRAD=0 python tools/bench_s2c32.py 2>&1 | tail -1) | $(MODE=fwd RYOLO_S2C32=0 python tools/bench_s2c32.py 2>&1 | tail -1)"
+  done
+  echo "8 images: new $(python tools/bench_s2c32.py 8 800 50 2>&1 | tail -1) | $(MODE=fwd python tools/bench_s2c32.py 8 800 50 2>&1 | tail -1)"
+  echo "8 images: old $(RYOLO_S2C32_DGRAD=0 python tools/bench_s2c32.py 8 800 50 2>&1 | tail -1) | $(MODE=fwd RYOLO_S2C32=0 python tools/bench_s2c32.py 8 800 50 2>&1 | tail -1)"
+) > $O/s2c32_isolated.txt 2>&1
 set -x
-# 4a'. PMC groups for the ring weight-gradient kernel: 8-wave form at whole-chip sizing, 4-wave form beside it
-( RYOLO_W3_V8_BLOCKS=256 bash tools/pmc_wgrad.sh v8_128x128_100 64 100 128 128 3 1 3; RYOLO_W3_V8=0 bash tools/pmc_wgrad.sh w4_128x128_100 64 100 128 128 3 1 3;
-  RYOLO_W3_V8_BLOCKS=256 bash tools/pmc_wgrad.sh v8_64x64_200 64 200 64 64 3 1 3; RYOLO_WGRAD_8W_BLOCKS=256 bash tools/pmc_wgrad.sh p8_512x512_100 64 100 512 512 1 1 3 ) > $O/pmc_wgrad.txt 2>&1
 # 4b. BatchNorm + activation passes alone (forward, backward reduce + finalize, backward apply) and socket power / clocks while the step runs
 timeout 300 python tools/bench_bnact.py 10 > $O/bnact_passes.txt 2>&1
 set +x
@@ -58,8 +61,10 @@ BACKEND=nccl timeout 600 python tools/dp_check.py > $O/dp_check_rccl1.txt 2>&1
 # 9. loader feed rate, mAP parity (600 steps), GPU test suite
 timeout 600 python tools/bench_pipeline.py > $O/pipeline.txt 2>&1; cp gpurun_out/pipeline.json $O/pipeline.json
 timeout 300 python tools/bench_loader.py 64 800 10 > $O/loader_diag.txt 2>&1; cp gpurun_out/loader_diag.json $O/loader_diag.json
-# mAP parity where the detector detects (r05): HIP-trained weights at mAP@0.5 >= 0.5 evaluated on both paths (the CPU oracle only evaluates: ~10 s per seed)
+# mAP parity where the detector detects: HIP-trained weights at mAP@0.5 >= 0.5 evaluated on both paths + the flip analysis, the matched-candidate protocol and
+# the bf16 noise floor of the metric (r06); once at C1's image size (416^2)
 timeout 900 python tools/map_parity.py --reverse --seeds 3 > $O/map_parity_reverse.txt 2>&1
+timeout 900 python tools/map_parity.py --reverse --seeds 1 --size 416 --chunk 500 --max-steps 4000 > $O/map_parity_reverse_416.txt 2>&1
 timeout 1800 python -m pytest tests -m gpu -q --durations=10 > $O/gpu_test_suite.txt 2>&1; tail -n 3 $O/gpu_test_suite.txt
 ls -la $O
 tail -n 3 $O/pmc_step.txt; cat $O/bench_time.txt; tail -n 2 $O/dp_check_gloo2.txt; tail -n 2 $O/dp_check_rccl1.txt

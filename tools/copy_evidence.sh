@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the end-of-round evidence of tools/collect_evidence.sh (gpurun_out/<tag>m/, merged back by gpurun) into profiles/ under round names.
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/${TAG}m
 P=profiles
 last() { tail -n 1 "$1"; }
@@ -13,9 +13,11 @@ cp gpurun_out/${TAG}_pmc_step_traffic.json $P/${TAG}_pmc_step_traffic.json
 cp $O/per_launch_b64.txt $P/${TAG}_per_launch_table_b64.txt
 cp $O/per_launch_b8.txt $P/${TAG}_per_launch_table_b8.txt
 cp $O/bnact_passes.txt $P/${TAG}_bnact_passes.txt
-grep -v "^+" $O/wgrad_isolated.txt > $P/${TAG}_wgrad_isolated.txt
+[ -f $O/wgrad_isolated.txt ] && grep -v "^+" $O/wgrad_isolated.txt > $P/${TAG}_wgrad_isolated.txt
+[ -f $O/s2c32_isolated.txt ] && cp $O/s2c32_isolated.txt $P/${TAG}_s2c32_isolated.txt
+[ -f gpurun_out/${TAG}_pmc_step_mfma_busy.json ] && cp gpurun_out/${TAG}_pmc_step_mfma_busy.json $P/${TAG}_pmc_step_mfma_busy.json
 cp $O/highres_layers_vs_floor.txt $P/${TAG}_highres_layers_vs_floor.txt
-mkdir -p $P/${TAG}_pmc_wgrad_ring; grep -v "^+" $O/pmc_wgrad.txt > $P/${TAG}_pmc_wgrad_ring/raw_counters.txt
+[ -f $O/pmc_wgrad.txt ] && { mkdir -p $P/${TAG}_pmc_wgrad_ring; grep -v "^+" $O/pmc_wgrad.txt > $P/${TAG}_pmc_wgrad_ring/raw_counters.txt; }
 ( cat $O/power_clocks_bench.txt; echo; cat $O/power_clocks.txt ) > $P/${TAG}_power_clocks.txt
 cp $O/nms_times.json $P/${TAG}_nms_times.json
 cp $O/infer.json $P/${TAG}_infer_yolov7_kfiou_800.json

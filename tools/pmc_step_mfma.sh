@@ -36,6 +36,16 @@ dur, cnt = collections.defaultdict(float), collections.Counter()
 for (k, _), ns in disp.items():
     dur[k] += ns * 1e-9
     cnt[k] += 1
+# shader clock of the profiled pass: GRBM_GUI_ACTIVE / 8 XCDs / duration over the LONG dispatches only (GUI_ACTIVE also ticks through a dispatch's
+# set-up and drain: on 10-us kernels the quotient reads 2.4+ GHz, on every dispatch > 100 us it reads 1.95-2.0)
+gui_long = dur_long = 0.0
+for f in glob.glob(R + "/gpurun_out/pmc_step_mfma/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and ns > 100000:
+            gui_long += float(r["Counter_Value"])
+            dur_long += ns * 1e-9
+CLOCK_GHZ = gui_long / 8 / dur_long / 1e9 if dur_long else 2.0
 steps = cnt.get("sgd_nesterov_kernel", 0)
 skip = ("nms_", "bitonic_", "compose_kernel", "topk_", "__amd_rocclr")
 
@@ -65,6 +75,13 @@ for cls, pat in bench.PMC_CLASSES.items():
 # separate them — bench.py's roofline_3x3_all does, from the launch descriptors)
 allk = [k for k in rows if not k.startswith(skip)]
 step = block(allk)
+# every kernel that serves 3x3 convolutions, by NAME: the halo-patch / persistent / ring / streaming kernels (3x3 only) + the generic tapped kernels
+# (stride-2 3x3 forward and data gradients, small-grid 3x3; the 1x1 instantiations are separate kernels and stay out; conv_wgrad_kernel<128> also
+# serves the narrow pointwise weight gradients: included, stated)
+pat33 = r"conv3x3|" + bench._gemm_re(128, 128, "false") + "|" + bench._gemm_re(256, 64) + r"|conv_wgrad_kernel<(64|128), |wgrad_taps_dma_kernel"
+k33 = [k for k in allk if re.match(pat33, k)]
+fam33 = block(k33)
+fam33["kernels"] = sorted(k33)
 plain = None
 try:
     plain = json.loads([ln for ln in open(R + "/gpurun_out/pmc_mfma_plain.json") if ln.startswith("{")][-1])
@@ -74,10 +91,11 @@ out = {"_doc": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
                "800^2); dispatches are serialized by the profiler (every kernel alone on the chip; the CU-exclusive weight-gradient kernels with 160 CUs idle). "
                "mfma_busy_frac_of_dispatch = (MFMA_BUSY / 1024 SIMDs) / (SQ_BUSY / 32 SQs); mfma_busy_frac_of_wall_clock = (MFMA_BUSY / 1024) / (GRBM_GUI_ACTIVE / 8 XCDs); shader clock = GRBM_GUI_ACTIVE / 8 / duration. "
                "A 32x32x16 bf16 MFMA holds its SIMD's pipe for 32 cycles at 8 passes x 4 cycles: busy 100 % = the dense peak at the running clock.",
-       "steps_profiled": steps, "whole_step_profiled_alone": step, "classes": classes, "kernels": kernels}
+       "steps_profiled": steps, "shader_clock_ghz_long_dispatches": round(CLOCK_GHZ, 3), "whole_step_profiled_alone": step,
+       "all_3x3_kernels_by_name": fam33, "classes": classes, "kernels": kernels}
 if plain:
     ms = plain["ms_per_step"]
-    clk = step["shader_clock_ghz"] or 2.1
+    clk = round(CLOCK_GHZ, 3)
     mf_per_simd = step["mfma_busy_mcycles_per_step"] * 1e6 / 1024
     out["whole_step_two_streams"] = {"ms_per_step_unprofiled": ms, "img_s": plain["value"], "shader_clock_ghz_assumed": clk,
                                      "mfma_busy_frac": round(mf_per_simd / (ms * 1e-3 * clk * 1e9), 4),
@@ -85,7 +103,8 @@ if plain:
 import hashlib
 out["source_sha256"] = bench.source_sha256()
 json.dump(out, open(R + f"/gpurun_out/{TAG}_pmc_step_mfma_busy.json", "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("whole_step_profiled_alone", "whole_step_two_streams") if k in out}, indent=1))
+print(json.dumps({k: out[k] for k in ("shader_clock_ghz_long_dispatches", "whole_step_profiled_alone", "whole_step_two_streams") if k in out}, indent=1))
+print("all 3x3 kernels by name:", {k: v for k, v in fam33.items() if k != "kernels"})
 for c, v in sorted(classes.items(), key=lambda kv: -kv[1]["mfma_busy_mcycles_per_step"]):
     print(c.ljust(36), v["mfma_busy_frac_of_dispatch"], v["ms_per_step_profiled_alone"], "ms")
 PY

@@ -1,12 +1,13 @@
 # Short refresh of the evidence that depends on the sources' hash or on the inference path (after a late change): PMC step traffic, default bench
-# line, inference timings, GPU suite -> gpurun_out/r05m/ (then tools/copy_evidence.sh r05)
+# line, inference timings, GPU suite -> gpurun_out/${TAG}m/ (then tools/copy_evidence.sh <tag>)
+TAG=${1:-r06}
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05m
+O=$R/gpurun_out/${TAG}m
 mkdir -p $O
 cd $R
-timeout 1500 bash tools/pmc_step.sh r05 > $O/pmc_step.txt 2>&1
-cp gpurun_out/r05_pmc_step_traffic.json profiles/r05_pmc_step_traffic.json
+timeout 1500 bash tools/pmc_step.sh $TAG > $O/pmc_step.txt 2>&1
+cp gpurun_out/${TAG}_pmc_step_traffic.json profiles/${TAG}_pmc_step_traffic.json
 ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
 timeout 600 python tools/bench_infer.py > $O/infer.txt 2>&1; cp gpurun_out/infer.json $O/infer.json
 B=8 SZ=1024 CONF=0.0005 IOU=0.65 timeout 600 python tools/bench_infer.py > $O/infer_1024.txt 2>&1; cp gpurun_out/infer.json $O/infer_1024_b8.json
