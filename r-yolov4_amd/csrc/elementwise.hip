@@ -1425,6 +1425,36 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p
     }
 }
 
+// torch.optim.Adam defaults of train.py:154 (betas given by the caller, eps, no weight decay, no amsgrad), single pass over the flat buffers:
+//   m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// bias corrections arrive as the two host-computed scalars torch forms in double (step_size, 1 / sqrt(bias_correction2)).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n4, float step_size, float rbc2s, float b1, float b2, float eps, float gscale,
+                                                   int zero_grad)
+{
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const float w1 = 1.f - b1, w2 = 1.f - b2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 gv = g4[i];
+        float4 mv = m4[i], vv = v4[i], pv = p4[i];
+        const float ge[4] = {gv.x * gscale, gv.y * gscale, gv.z * gscale, gv.w * gscale};
+        float* me = &mv.x; float* ve = &vv.x; float* pe = &pv.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            me[k] = me[k] + w1 * (ge[k] - me[k]);                       // exp_avg.lerp_(grad, 1 - beta1)
+            ve[k] = ve[k] * b2 + w2 * (ge[k] * ge[k]);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+            pe[k] -= step_size * (me[k] / (sqrtf(ve[k]) * rbc2s + eps));
+        }
+        m4[i] = mv;
+        v4[i] = vv;
+        p4[i] = pv;
+        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // fp32 NCHW image -> is consumed directly by im2col_kernel; nothing else needed for the input side.
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -1873,6 +1903,18 @@ extern "C" int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, flo
     if (!p || !g || !buf || n < 0 || (n & 3)) return RY_ERR_ARG;
     if (n == 0) return RY_OK;
     hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, buf, n / 4, lr, mu, gscale, zero_grad);
+    RY_CHECK_LAUNCH();
+    return RY_OK;
+}
+
+extern "C" int ryolo_adam(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                          float gscale, int zero_grad, hipStream_t stream)
+{
+    if (!p || !g || !m || !v || n < 0 || (n & 3) || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return RY_ERR_ARG;
+    if (n == 0) return RY_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)),
+                       beta1, beta2, eps, gscale, zero_grad);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

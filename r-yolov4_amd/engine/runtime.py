@@ -44,6 +44,7 @@ class Runtime:
         self._graphs = {}
         self._side_streams = {}
         self.momentum_buf = None
+        self.adam_state = None            # [exp_avg, exp_avg_sq, step] of adam_step
         self.zeros = torch.zeros(256, dtype=torch.uint8, device=device)       # source of padded rows for the LDS-DMA GEMM loop
         # bits 0-7: generic mainloop (1 LDS-DMA ring [default], 0 register staged);
         # 0x200: 3x3 stride-1 layers run the halo-patch kernel (csrc/conv3x3.hip)
@@ -256,6 +257,16 @@ class Runtime:
             self.momentum_buf = torch.zeros_like(self.flat)
         hip.call("ryolo_sgd_nesterov", self.flat.data_ptr(), self.gflat.data_ptr(), self.momentum_buf.data_ptr(), self.n_flat, float(lr),
                  float(momentum), float(grad_scale), 1 if zero_grad else 0, hip.stream())
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+        """torch.optim.Adam(model.parameters(), lr).step() [+ zero_grad()] of train.py:153-154 (`--optimizer Adam`) as ONE kernel over the flat
+        parameter / gradient / moment buffers (csrc/elementwise.hip adam_kernel); the step count lives here, as torch keeps it in the optimizer state."""
+        if self.adam_state is None:
+            self.adam_state = [torch.zeros_like(self.flat), torch.zeros_like(self.flat), 0]
+        st = self.adam_state
+        st[2] += 1
+        hip.call("ryolo_adam", self.flat.data_ptr(), self.gflat.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), self.n_flat, float(lr), float(betas[0]),
+                 float(betas[1]), float(eps), st[2], float(grad_scale), 1 if zero_grad else 0, hip.stream())
 
 
 class NetFunction(torch.autograd.Function):
