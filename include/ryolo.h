@@ -245,7 +245,7 @@ int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, float lr, floa
 /* torch.optim.Adam(lr) of train.py:153-154 (betas / eps from the caller, no weight decay, no amsgrad) over flat buffers, `step` = 1, 2, ...
  * (the bias corrections 1 - beta^step are formed in double on the host, as torch does): m = m + (1 - b1)(g - m); v = b2 v + (1 - b2) g^2;
  * p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).  gscale / zero_grad as in ryolo_sgd_nesterov. */
-int ryolo_adam(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, float gscale,
+int ryolo_adam(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, float gscale,
                int zero_grad, ryolo_stream_t stream);
 /* ---- image-side augmentations of the loader on uint8 HWC (BGR) images in HBM (csrc/augment.hip; datasets/base_dataset.py:224-330,
  * lib/augmentations.py:8-74).  paste: `rects` = device array of nrect records {int64 src_off; int src_w, sx, sy, dx, dy, w, h, canvas}

@@ -125,7 +125,7 @@ __host__ __device__ constexpr int ws3_later(int v, bool first, bool stats)
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_ws64_kernel(const ConvGemmParams p, const Ws3Geom g)
 {
-    constexpr bool STATS = EPI == EPI_STATS, ACCUM = EPI == EPI_ACCUM;
+    constexpr bool STATS = EPI == EPI_STATS, ACCUM = EPI == EPI_ACCUM, AFFINE = EPI == EPI_AFFINE_ACT;
     constexpr int PF = WS3_PF, NU = WS3_NU;
 #ifdef WS3_TIMING
     const unsigned long long TT0 = __builtin_readcyclecounter();
@@ -195,6 +195,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     unsigned abase_now = 0u;                                   // what the addresses above are currently relative to (LDS address of the patch buffer in use)
+    // ---- inference (EPI_AFFINE_ACT): the folded BatchNorm coefficients of this lane's 16 output channels (accumulator element 4 g4 + q of every
+    //      pixel block = channel wn * 32 + 8 g4 + 4 h + q), in registers for the whole launch — the eval tape ran these layers on the halo-patch
+    //      kernel's 256 x 64 tile until r06 (656 against 880 TF/s on the 400^2 map) -------------------------------------------------------------------
+    float asc[AFFINE ? 4 : 1][4], asf[AFFINE ? 4 : 1][4];
+    if constexpr (AFFINE) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = wn * 32 + 8 * g4 + 4 * h + q;
+                asc[g4][q] = c < p.Nout ? p.scale[c] : 0.f;
+                asf[g4][q] = c < p.Nout ? p.shift[c] : 0.f;
+            }
+    }
     // ---- store side: lane -> 16-byte chunk ch of staged row it * 16 + r0 (chunk position ^ (row >> 1) & 3) ------------------------------------
     const int ch = lane & 3, r0 = lane >> 2;
     const int ncol = wn * 32 + ch * 8;
@@ -363,6 +377,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 float v0 = acc[b][4 * g4], v1 = acc[b][4 * g4 + 1], v2 = acc[b][4 * g4 + 2], v3 = acc[b][4 * g4 + 3];
+                if constexpr (AFFINE) {
+                    float v[4] = {v0, v1, v2, v3};
+                    act_affine_quad(v, asc[g4], asf[g4], p.act);
+                    v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3];
+                }
                 if (!live[b]) v0 = v1 = v2 = v3 = 0.f;
                 const int row = b * 32 + l31;
                 ws3_wr64(sbase + (unsigned)(row * 64 + (((g4 ^ ((row >> 1) & 3)) << 4) | (h << 3))), pack_bf2(v0, v1), pack_bf2(v2, v3));
@@ -492,7 +511,8 @@ bool ws3_geometry(const ConvGemmParams& p, Ws3Geom& g)
     if (p.pool_idx || p.s2d_cin) return false;
     if (p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || tc.oh_add || tc.ow_add) return false;
     if (p.Cin != 64 || p.Nout > 64 || p.Nout < 8 || p.Nout % 8 || p.ldA % 8 || p.ldC % 8 || !p.zeros) return false;
-    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_ACCUM) return false;
+    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_ACCUM && p.epi != EPI_AFFINE_ACT) return false;
+    if (p.epi == EPI_AFFINE_ACT && (!p.scale || !p.shift)) return false;
     unsigned seen = 0;
     for (int t = 0; t < 9; t++) {
         if (tc.dh[t] < -1 || tc.dh[t] > 1 || tc.dw[t] < -1 || tc.dw[t] > 1 || tc.widx[t] < 0 || tc.widx[t] >= p.wtaps) return false;
@@ -544,5 +564,6 @@ int ws3_launch(const ConvGemmParams& p, const Ws3Geom& g, hipStream_t stream)
 {
     if (p.epi == EPI_STATS) return ws3_launch_t<EPI_STATS>(p, g, stream);
     if (p.epi == EPI_ACCUM) return ws3_launch_t<EPI_ACCUM>(p, g, stream);
+    if (p.epi == EPI_AFFINE_ACT) return ws3_launch_t<EPI_AFFINE_ACT>(p, g, stream);
     return ws3_launch_t<EPI_RAW>(p, g, stream);
 }

@@ -1427,16 +1427,15 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p
 
 // torch.optim.Adam defaults of train.py:154 (betas given by the caller, eps, no weight decay, no amsgrad), single pass over the flat buffers:
 //   m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-// bias corrections arrive as the two host-computed scalars torch forms in double (step_size, 1 / sqrt(bias_correction2)).
+// bias corrections arrive as the two host-computed scalars torch forms in double (step_size, sqrt(bias_correction2)).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n4, float step_size, float rbc2s, float b1, float b2, float eps, float gscale,
+                                                   int64_t n4, float step_size, float bc2s, float w1, float b2, float w2, float eps, float gscale,
                                                    int zero_grad)
 {
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* g4 = reinterpret_cast<float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    const float w1 = 1.f - b1, w2 = 1.f - b2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 gv = g4[i];
         float4 mv = m4[i], vv = v4[i], pv = p4[i];
@@ -1446,7 +1445,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         for (int k = 0; k < 4; k++) {
             me[k] = me[k] + w1 * (ge[k] - me[k]);                       // exp_avg.lerp_(grad, 1 - beta1)
             ve[k] = ve[k] * b2 + w2 * (ge[k] * ge[k]);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-            pe[k] -= step_size * (me[k] / (sqrtf(ve[k]) * rbc2s + eps));
+            pe[k] -= step_size * (me[k] / (sqrtf(ve[k]) / bc2s + eps));   // denom = (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
         }
         m4[i] = mv;
         v4[i] = vv;
@@ -1907,14 +1906,15 @@ extern "C" int ryolo_sgd_nesterov(float* p, float* g, float* buf, int64_t n, flo
     return RY_OK;
 }
 
-extern "C" int ryolo_adam(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+extern "C" int ryolo_adam(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step,
                           float gscale, int zero_grad, hipStream_t stream)
 {
-    if (!p || !g || !m || !v || n < 0 || (n & 3) || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return RY_ERR_ARG;
+    if (!p || !g || !m || !v || n < 0 || (n & 3) || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return RY_ERR_ARG;
     if (n == 0) return RY_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)),
-                       beta1, beta2, eps, gscale, zero_grad);
+    // every scalar is formed in double and rounded to fp32 once, as torch does with its Python floats (1 - 0.999 in fp32 is 4.7e-5 off 0.001)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, (float)(lr / bc1), (float)sqrt(bc2),
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, gscale, zero_grad);
     RY_CHECK_LAUNCH();
     return RY_OK;
 }

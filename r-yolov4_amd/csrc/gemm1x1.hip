@@ -214,35 +214,48 @@ __global__ __launch_bounds__(512, 1) void gemm1x1_ws_kernel(const ConvGemmParams
             const int wsw = (l31 >> 1) & 3;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                // inference: folded BatchNorm + activation on the fp32 accumulators.  A lane's 16 values of a (pixel block i, quarter j) are channels
+                // n0 + 32 j + 8 g4 + 4 h + e; the coefficients of the quarter's 32 channels are WAVE-UNIFORM (n0 comes from the workgroup id, j is
+                // unrolled), so they come through the constant address space (s_load) — this kernel's LDS is full at K = 256 (no room for the per-tile
+                // table the generic and halo-patch kernels have) and its vmcnt counts the ring's LDS-DMA pieces (a VMEM load here would wait for them).
+                // r06 (second cut): the coefficients of HALF a quarter are requested in one batch, selected per half-wave into 16 VGPRs, and serve both
+                // pixel blocks; the first cut fetched 16 scalars per (i, g4) quad behind two dependent s_waitcnt lgkmcnt(0) — 64 exposed scalar-memory
+                // round trips per 64 x 128 tile, now 8, against 4 096 matrix cycles (ISA count; 256 -> 256 @200^2 x 64: 810 us against 595 for the raw store)
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+                for (int gp = 0; gp < 2; gp++) {                              // half a quarter at a time: 8 + 8 coefficient registers (16 + 16 spilled)
+                    float qsc[affine ? 8 : 1], qsf[affine ? 8 : 1];
+                    if constexpr (affine) {
+                        typedef const __attribute__((address_space(4))) float cfloat_t;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; g4++) {
-                        float v[4];
+                        for (int gg = 0; gg < 2; gg++) {
+                            const int n8 = n0 + j * 32 + 8 * (2 * gp + gg);       // Nout % 8 == 0: the eight channels are inside or outside as a whole
+                            const int n8c = n8 < p.Nout ? n8 : 0;                 // (columns >= Nout are never stored: any in-range coefficients do)
+                            // (opaque per tile: the coefficients do not depend on the tile, and hipcc would hoist all 128 + 128 selected values out of
+                            // the tile loop — 20 ... 35 VGPRs spilled to scratch in the first two cuts)
+                            unsigned long long sca = (unsigned long long)(p.scale + n8c), sfa = (unsigned long long)(p.shift + n8c);
+                            asm volatile("" : "+s"(sca), "+s"(sfa));
+                            cfloat_t* scp = (cfloat_t*)sca;
+                            cfloat_t* sfp = (cfloat_t*)sfa;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g4 + e];
-                        if constexpr (affine) {                    // inference: folded BatchNorm + activation on the fp32 accumulator
-                            // r06: the coefficients of the 8 channels (n8 .. n8 + 7) the two half-waves of this quad cover are WAVE-UNIFORM (n0 comes
-                            // from the workgroup id; j, g4 are unrolled): two s_load_dwordx8 through the constant address space per quad instead of
-                            // two 16-byte VMEM loads per lane — this kernel's LDS is full at K = 256 (no room for the per-tile table the generic and
-                            // halo-patch kernels got in r05), and its vmcnt counts the ring's LDS-DMA pieces: a VMEM load in the epilogue waited for them.
-                            const int n8 = n0 + j * 32 + 8 * g4;              // Nout % 8 == 0: the eight channels are inside or outside as a whole
-                            if (n8 < p.Nout) {
-                                typedef const __attribute__((address_space(4))) float cfloat_t;
-                                cfloat_t* scp = (cfloat_t*)(p.scale + n8);
-                                cfloat_t* sfp = (cfloat_t*)(p.shift + n8);
-                                float sc4[4], sf4[4];
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    const float sclo = scp[e], schi = scp[4 + e], sflo = sfp[e], sfhi = sfp[4 + e];      // eight + eight uniform loads, THEN the per-half select
-                                    sc4[e] = h ? schi : sclo;
-                                    sf4[e] = h ? sfhi : sflo;
-                                }
-                                act_affine_quad(v, sc4, sf4, p.act);
+                            for (int e = 0; e < 4; e++) {
+                                const float sclo = scp[e], schi = scp[4 + e], sflo = sfp[e], sfhi = sfp[4 + e];
+                                qsc[4 * gg + e] = h ? schi : sclo;
+                                qsf[4 * gg + e] = h ? sfhi : sflo;
                             }
                         }
-                        *reinterpret_cast<uint2*>(stage + (i * 32 + l31) * 32 + ((g4 ^ wsw) << 3) + 4 * h) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = acc[i][j][8 * gp + e];
+                        if constexpr (affine) act_affine_vec<8>(v, qsc, qsf, p.act);       // the activation chain is walked once per 8 values
+#pragma unroll
+                        for (int gg = 0; gg < 2; gg++)
+                            *reinterpret_cast<uint2*>(stage + (i * 32 + l31) * 32 + (((2 * gp + gg) ^ wsw) << 3) + 4 * h) =
+                                make_uint2(pack_bf2(v[4 * gg], v[4 * gg + 1]), pack_bf2(v[4 * gg + 2], v[4 * gg + 3]));
+                    }
+                }
                 // (same-wave LDS hand-off: the wave's own ds_write -> ds_read ordering)
                 const int n = S2D ? rc * 8 : n0 + j * 32 + rc * 8;       // S2D: channel inside parity block j
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (m0 + rr) * p.ldC + n;

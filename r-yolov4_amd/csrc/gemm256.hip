@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr unsigned W_OFF = 256 * 128;                      // weight rows follow the pixel rows inside a stage
     constexpr unsigned STAGE = (256 + BN) * 128;
     constexpr int NPIECE = (256 + BN) / 8 / 8;                 // 1-KiB DMA pieces per wave and stage (8 rows each): 8 / 6
-    constexpr bool STATS = EPI == EPI_STATS, ACCUM = EPI == EPI_ACCUM;
+    constexpr bool STATS = EPI == EPI_STATS, ACCUM = EPI == EPI_ACCUM, AFFINE = EPI == EPI_AFFINE_ACT;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int h = lane >> 5, l31 = lane & 31;
@@ -150,6 +150,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
+    // inference (EPI_AFFINE_ACT, r06 — the eval tape ran these layers on the generic kernel's 128 x 128 tile until then): the folded BatchNorm
+    // coefficients of the tile's BN columns go into the 2 KiB behind the two operand stages BEFORE any LDS-DMA is in flight (a plain LDS write next
+    // to DMA in flight makes hipcc drain vmcnt); the K loop's barriers publish them, the epilogue reads them back per accumulator quad
+    float* const cco = reinterpret_cast<float*>(g256_lds + 2 * STAGE);      // [2][BN]
+    if constexpr (AFFINE) {
+        if (tid < BN) {
+            const int n = n0 + tid;
+            cco[tid] = n < p.Nout ? p.scale[n] : 0.f;
+            cco[BN + tid] = n < p.Nout ? p.shift[n] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     issue_stage(0, 0u);
 #ifdef G256_TIMING
     const unsigned long long T1 = __builtin_readcyclecounter();
@@ -203,8 +215,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int g4 = 0; g4 < 4; g4++) {
                 const int row = i * 32 + l31;
                 const int chunk = j * 4 + g4;
+                float v[4] = {acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+                if constexpr (AFFINE) {
+                    const int cl = wn * WTN + j * 32 + 8 * g4 + 4 * h;    // column inside the tile (columns >= Nout hold zeros and are never stored)
+                    const float4 sc = *reinterpret_cast<const float4*>(cco + cl), sh = *reinterpret_cast<const float4*>(cco + BN + cl);
+                    const float sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sf4[4] = {sh.x, sh.y, sh.z, sh.w};
+                    act_affine_quad(v, sc4, sf4, p.act);
+                }
                 g256_wr64(sbase + (unsigned)row * ROWB + (unsigned)(((chunk ^ (row & (CHK - 1))) << 4) | (h << 3)),
-                          pack_bf2(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1]), pack_bf2(acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]));
+                          pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             }
     // (wave-local hand-off: the wave's own LDS operations are ordered)
     const int ch = lane % CHK, r0 = lane / CHK;                // store: chunk ch of staged row it * RPI + r0
@@ -316,7 +335,8 @@ bool g256_geometry(const ConvGemmParams& p, G256Geom& g)
     if (p.nclasses != 1 || tc.ntaps != 1 || tc.dh[0] || tc.dw[0] || tc.widx[0] || p.sh != 1 || p.sw != 1 || p.IH != p.OH || p.IW != p.OW) return false;
     if (p.oh_mul != 1 || p.ow_mul != 1 || p.OHf != p.OH || p.OWf != p.OW || tc.oh_add || tc.ow_add) return false;
     if (p.pool_idx || p.s2d_cin || !p.zeros) return false;
-    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_ACCUM) return false;
+    if (p.epi != EPI_RAW && p.epi != EPI_STATS && p.epi != EPI_ACCUM && p.epi != EPI_AFFINE_ACT) return false;
+    if (p.epi == EPI_AFFINE_ACT && (!p.scale || !p.shift)) return false;
     if (p.Cin % G256_BK || p.Nout % 8 || p.ldA % 8 || p.ldC % 8 || p.Nout < 128) return false;
     const int64_t M = (int64_t)p.NB * p.OH * p.OW;
     if (M <= 0) return false;
@@ -332,7 +352,7 @@ bool g256_geometry(const ConvGemmParams& p, G256Geom& g)
         static const int mink = [] { const char* e = getenv("RYOLO_GEMM_256_MINK"); return e ? atoi(e) : 512; }();      // A/B knob
         if (p.Cin < mink || g.gm * g.gn < 600 || g.BN != 256) return false;
     }
-    g.lds_bytes = 2u * (256u + (unsigned)g.BN) * 128u;
+    g.lds_bytes = 2u * (256u + (unsigned)g.BN) * 128u + (p.epi == EPI_AFFINE_ACT ? 2u * (unsigned)g.BN * 4u : 0u);
     return true;
 }
 
@@ -349,9 +369,11 @@ int g256_launch(const ConvGemmParams& p, const G256Geom& g, hipStream_t stream)
     if (g.BN == 256) {
         if (p.epi == EPI_STATS) return g256_launch_t<256, EPI_STATS>(p, g, stream);
         if (p.epi == EPI_ACCUM) return g256_launch_t<256, EPI_ACCUM>(p, g, stream);
+        if (p.epi == EPI_AFFINE_ACT) return g256_launch_t<256, EPI_AFFINE_ACT>(p, g, stream);
         return g256_launch_t<256, EPI_RAW>(p, g, stream);
     }
     if (p.epi == EPI_STATS) return g256_launch_t<128, EPI_STATS>(p, g, stream);
     if (p.epi == EPI_ACCUM) return g256_launch_t<128, EPI_ACCUM>(p, g, stream);
+    if (p.epi == EPI_AFFINE_ACT) return g256_launch_t<128, EPI_AFFINE_ACT>(p, g, stream);
     return g256_launch_t<128, EPI_RAW>(p, g, stream);
 }

@@ -113,7 +113,7 @@ for _name, _sig in {
     "ryolo_unpack_wgrad": [P, I, I, I, I, P, P],
     "ryolo_repconv_fold": [P, P, P, P, I, I, P, P, P],
     "ryolo_sgd_nesterov": [P, P, P, L, F, F, F, I, P],
-    "ryolo_adam": [P, P, P, P, L, F, F, F, F, L, F, I, P],
+    "ryolo_adam": [P, P, P, P, L, D, D, D, D, L, F, I, P],
     "ryolo_struct_sizes": [_PTR(I)],
     "ryolo_loss_workspace_bytes": [_PTR(LossParams), _PTR(Z)],
     "ryolo_loss": [_PTR(LossParams), P],

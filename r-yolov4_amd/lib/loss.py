@@ -217,8 +217,12 @@ class _ComputeLossBase:
             loss = items[4:5].clone()
         names = ("reg_loss", "conf_loss", "cls_loss", "theta_loss", "total_loss")
         self.dropped_targets = items[5]                # device scalar: rows whose image index is outside [0, batch)
-        self._check_previous_call()                    # sync_items=False: the PREVIOUS call's count, long finished by now (no stall)
-        if not sync_items:
+        # inside a stream capture (a whole training step recorded into one hipGraph: tools/bench_graph_step.py) nothing may wait on the host and
+        # the pinned read-back would be replayed without anyone looking at it: the count stays on the device (`dropped_targets`)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self._check_previous_call()                # sync_items=False: the PREVIOUS call's count, long finished by now (no stall)
+        if not sync_items and not capturing:
             if self._drop_host is None:
                 self._drop_host = torch.zeros(1, dtype=torch.float32).pin_memory()
             self._drop_host.copy_(items[5:6], non_blocking=True)

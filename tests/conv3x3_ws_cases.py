@@ -17,7 +17,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
 def test_forced_persistent_kernel(shape, epi):
     _run(*shape, epi=epi, ld_extra=24 if epi else 0, seed=epi + 3 * len(shape), expect_kernel=3)
 
@@ -25,6 +25,13 @@ def test_forced_persistent_kernel(shape, epi):
 def test_forced_persistent_kernel_mirrored():
     _run(2, 50, 50, 64, 64, mirrored=True, expect_kernel=3)
     _run(3, 100, 100, 64, 64, mirrored=True, epi=4, ld_extra=8, expect_kernel=3)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_forced_persistent_kernel_inference_activations(act):
+    """EPI_AFFINE_ACT (r06: the eval tape's 64 -> 64 layers): folded BatchNorm + every activation, narrow output (zero coefficients past Nout)."""
+    _run(2, 50, 50, 64, 64, epi=2, act=act, ld_extra=8, seed=40 + act, expect_kernel=3)
+    _run(2, 25, 50, 64, 40, epi=2, act=act, seed=50 + act, expect_kernel=3)
 
 
 def test_not_eligible_shapes_stay_on_the_patch_kernel():

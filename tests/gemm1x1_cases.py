@@ -85,7 +85,7 @@ def test_shapes_and_epilogues(shape, epi):
     _run(*shape, epi=epi, seed=epi)
 
 
-@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
 def test_channel_slices(epi):
     _run(3 * 25 * 25, 128, 200, epi=epi, ld_extra=56)
     _run(9000, 256, 128, epi=epi, ld_extra=8)

@@ -1,7 +1,7 @@
 """(cases of tests/test_gpu_gemm256.py; not collected on its own)  The 256-wide pointwise GEMM (csrc/gemm256.hip) through the C ABI against torch's
 fp32 matmul on the same bf16 inputs: ragged pixel counts (last 256-pixel tile partial), output widths that are not a multiple of the channel tile
 (zero-page weight rows, masked column chunks), both tile widths (<= 128 columns: 256 x 128), channel slices of wider buffers, K = 64 ... 2048,
-every epilogue it takes (raw, BatchNorm statistics, accumulate).  RYOLO_GEMM_256=2 puts it on every eligible launch (by default: Cin >= 512 and
+every epilogue it takes (raw, BatchNorm statistics, folded BatchNorm + activation, accumulate).  RYOLO_GEMM_256=2 puts it on every eligible launch (by default: Cin >= 512 and
 grids of >= 600 tiles), read once per process — hence the child process.  Tolerance: bf16 output rounding (2^-7 relative) on fp32-accumulated sums."""
 import os
 
@@ -21,7 +21,7 @@ SHAPES = [  # M, Cin, Cout
 ]
 
 
-def _run(M, Cin, Cout, epi, ld_extra=0, seed=0, expect=4):
+def _run(M, Cin, Cout, epi, ld_extra=0, seed=0, expect=4, act=3):
     from ryolov4_amd import hip
     from ryolov4_amd.engine import structs as S
     hip.lib()
@@ -43,6 +43,9 @@ def _run(M, Cin, Cout, epi, ld_extra=0, seed=0, expect=4):
     p.cls[0].ntaps = 1
     p.epi, p.out, p.ldC = epi, yfull.data_ptr(), ldC
     p.zeros, p.pipe = zeros.data_ptr(), 0x201
+    co = torch.rand(4, Cout, generator=g).to(dev) + 0.5           # EPI_AFFINE_ACT: folded BatchNorm scale (row 2) / shift (row 3)
+    co[3] -= 1.0
+    p.scale, p.shift, p.act = co.data_ptr() + 2 * Cout * 4, co.data_ptr() + 3 * Cout * 4, act
     rows, kern = S.I(), S.I()
     hip.call("ryolo_conv_gemm_plan", p, rows, kern)
     assert kern.value & 0xff == expect, f"routed to kernel family {kern.value & 0xff}, expected {expect} ({kern.value:#x})"
@@ -54,6 +57,9 @@ def _run(M, Cin, Cout, epi, ld_extra=0, seed=0, expect=4):
     torch.cuda.synchronize()
     ref = xfull[:, :Cin].float() @ w.float().t()
     got = yfull[:, :Cout].float()
+    if epi == S.EPI_AFFINE_ACT:
+        u = ref * co[2] + co[3]
+        ref = {3: u * torch.sigmoid(u), 2: torch.where(u > 0, u, 0.1 * u), 1: u * torch.tanh(torch.nn.functional.softplus(u)), 0: u}[act]
     if epi == S.EPI_ACCUM:
         ref = ref.to(torch.bfloat16).float() + y0[:, :Cout].float()
     err = (got - ref).abs()
@@ -71,17 +77,25 @@ def _run(M, Cin, Cout, epi, ld_extra=0, seed=0, expect=4):
 
 
 @pytest.mark.skipif(not FORCED, reason="run through tests/test_gpu_gemm256.py (RYOLO_GEMM_256=2)")
-@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_shapes_and_epilogues(shape, epi):
     _run(*shape, epi=epi, seed=epi)
 
 
 @pytest.mark.skipif(not FORCED, reason="run through tests/test_gpu_gemm256.py (RYOLO_GEMM_256=2)")
-@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
 def test_channel_slices(epi):
     _run(3 * 25 * 25, 128, 200, epi=epi, ld_extra=56)
     _run(9000, 512, 128, epi=epi, ld_extra=8)
+
+
+@pytest.mark.skipif(not FORCED, reason="run through tests/test_gpu_gemm256.py (RYOLO_GEMM_256=2)")
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_inference_epilogue_activations(act):
+    """EPI_AFFINE_ACT (r06: the eval tape's long-K pointwise layers): folded BatchNorm + every activation on both tile widths."""
+    _run(3 * 25 * 25, 512, 400, epi=2, act=act, seed=30 + act)
+    _run(300, 1024, 128, epi=2, act=act, ld_extra=8, seed=33 + act)
 
 
 @pytest.mark.skipif(not FORCED, reason="run through tests/test_gpu_gemm256.py (RYOLO_GEMM_256=2)")

@@ -103,11 +103,11 @@ def test_patch_kernel_mirrored_taps():
 
 
 # ---- the persistent weight-stationary kernel for 64 -> <= 64 channels (csrc/conv3x3_ws.hip): by default only when every workgroup gets >= 4 tiles
-@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
 def test_persistent_64_channel_kernel_multi_tile(epi):
     """8 x 200 x 200: 1280 tiles of 10 x 25 over 256 persistent workgroups — 5 tiles each, so the double-buffered patch pipeline (request two
-    tiles ahead), the per-tile barrier and the register-accumulated statistics all run in their steady state; raw / statistics / accumulate
-    epilogues, output in a channel slice of a wider buffer."""
+    tiles ahead), the per-tile barrier and the register-accumulated statistics all run in their steady state; raw / statistics / folded BatchNorm + activation
+    (r06: inference) / accumulate epilogues, output in a channel slice of a wider buffer."""
     _run(8, 200, 200, 64, 64, epi=epi, ld_extra=64, seed=10 + epi, expect_kernel=3)
 
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
 def test_default_dispatch_takes_the_long_k_layers(epi):
     from tests.gemm256_cases import _run
     _run(64 * 50 * 50, 512, 512, epi=epi, ld_extra=64 if epi else 0, seed=epi)          # 512 -> 512 @50^2, batch 64: 1250 tiles

@@ -52,8 +52,14 @@ with torch.cuda.stream(side):
 torch.cuda.current_stream().wait_stream(side)
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    loss = step()
+try:
+    with torch.cuda.graph(g):
+        loss = step()
+except Exception:
+    import traceback
+    traceback.print_exc()
+    print("capture FAILED", flush=True)
+    sys.exit(1)
 torch.cuda.synchronize()
 g.replay()
 torch.cuda.synchronize()
