@@ -1553,7 +1553,7 @@ extern "C" int ryolo_conv_gemm_plan(const ConvGemmParams* pp, int* stats_rows, i
     P3Geom g;
     if ((p.pipe & 0x200) && p3_geometry(p, g)) {
         *stats_rows = (int)g.gm;
-        if (kernel) *kernel = 1;
+        if (kernel) *kernel = 1 | ((g.BN / 32) << 16);            // bits 16-19 = tile columns / 32 (r06: 64-column tiles also for wide layers on small grids)
         return RY_OK;
     }
     G256Geom g2;

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const ConvGemmPar
 // ---------------------------------------------------------------------------------------------------------- host side
 static unsigned p3_lds_bytes(int P, int BN) { return 2u * P * 1024u + 3u * BN * 64u + 128u + (unsigned)ry_cdiv(P, 4) * 1024u + P3_BM * 4u; }
 
-bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
+static bool p3_geometry_bn(const ConvGemmParams& p, P3Geom& g, int bn_force)
 {
     g = P3Geom{};
     const TapClass& tc = p.cls[0];
@@ -509,7 +509,7 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
     const int H = p.OH, W = p.OW;
     const int64_t M = (int64_t)p.NB * H * W;
     if (M * (int64_t)p.ldA >= (1ll << 34) || (int64_t)p.Nout * p.wtaps * p.Cin >= (1ll << 31)) return false;   // 32-bit DMA source offsets
-    g.BN = p.Nout <= 64 ? 64 : 128;
+    g.BN = (p.Nout <= 64 || bn_force == 64) ? 64 : 128;
     g.gn = (int)ry_cdiv(p.Nout, g.BN);
     const unsigned budget = 80u * 1024u;                          // two workgroups per CU
     // flat runs: no tile waste; the patch carries one image row of halo on both sides
@@ -550,9 +550,29 @@ bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
     g.rTW = g.TW ? 1.0f / (float)g.TW : 0.f;
     g.lds_bytes = p3_lds_bytes(g.P, g.BN);
     if (g.gm * g.gn > 0x7fffffff || g.gm <= 0) { g.mode = 0; return false; }
-    // 256-pixel tiles need a grid that fills the chip (2 workgroups x 256 CUs); smaller problems stay on the generic kernel's
-    // 128-pixel tiles (measured: 8 x 100^2 x 128 -> 128 is 0.7x on this kernel, 64 x ... is 1.25-1.3x).  0x400 forces it (tests).
-    if (g.gm * g.gn < 512 && !(p.pipe & 0x400)) { g.mode = 0; return false; }
+    // Small grids.  Through r05 a launch with fewer than 512 workgroups (2 per CU) stayed on the generic kernel's 128-pixel tiles ("8 x 100^2 x
+    // 128 -> 128 is 0.7x on this kernel": an r02 measurement of the r02 kernel).  Re-measured in r06 (tools/bench_conv.py, 8 images, same box,
+    // statistics epilogue; generic [deep ring where it applies] vs this kernel): 100^2 128 -> 128 50.6 vs 39.0 us, 50^2 256 -> 256 55.8 vs 44.7,
+    // 50^2 128 -> 128 26.2 vs 25.3, 25^2 256 -> 256 44.1 vs 39.9, 25^2 512 -> 512 83.3 vs 74.7, 25^2 1024 -> 512 157.0 vs 139.8, 32^2 512 -> 512
+    // 86.9 vs 77.4 — it wins on every one-round grid of the 8-image step and of the batch-8 1024^2 inference tape, and by much more on 64-column
+    // tiles (p3_geometry below: 26.6 / 56.6 / 39.3 / 18.6 / 60.7 us for the 25^2 256, 25^2 512, 50^2 256, 50^2 128, 32^2 512 cases); batch 1:
+    // 25^2 256 -> 256 45.2 -> 27.4 us, 50^2 128 -> 128 27.2 -> 19.1, 25^2 512 -> 512 81.4 -> 46.6.  RYOLO_P3_MIN_WGS: A/B knob (512 ~ the r05
+    // rule).  0x400 forces the kernel (tests).
+    static const int min_wgs = getenv("RYOLO_P3_MIN_WGS") ? atoi(getenv("RYOLO_P3_MIN_WGS")) : 4;
+    if (g.gm * ry_cdiv(p.Nout, 64) < min_wgs && !(p.pipe & 0x400)) { g.mode = 0; return false; }      // (counted in 64-column tiles: what a small grid runs)
+    return true;
+}
+
+bool p3_geometry(const ConvGemmParams& p, P3Geom& g)
+{
+    if (!p3_geometry_bn(p, g, 0)) return false;
+    // fewer 128-column workgroups than CUs: 64-column tiles double the grid (RYOLO_P3_SMALL_BN64 = the grid size below which it applies; 0: off)
+    static const int small64 = getenv("RYOLO_P3_SMALL_BN64") ? atoi(getenv("RYOLO_P3_SMALL_BN64")) : 256;
+    // (0x400 = the tests' "force this kernel" bit keeps the 128-column tile; 0x2000 forces the 64-column one)
+    if (g.BN == 128 && ((g.gm * g.gn < small64 && !(p.pipe & 0x400)) || (p.pipe & 0x2000))) {
+        P3Geom g64;
+        if (p3_geometry_bn(p, g64, 64)) g = g64;
+    }
     return true;
 }
 

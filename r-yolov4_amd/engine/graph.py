@@ -251,7 +251,7 @@ class Graph:
             hip.call("ryolo_conv_gemm_plan", p, S.I(), kern)
             fam, kv = kern.value & 0xff, kern.value
             if fam == 1:
-                return (f"conv3x3_patch_kernel<256x{64 if p.Nout <= 64 else 128}>", fl, by)
+                return (f"conv3x3_patch_kernel<256x{((kv >> 16) & 15) * 32}>", fl, by)
             if fam == 2:
                 # plain pointwise launches of the persistent kernel (on by size since r04) belong to the K <= 256 / K > 256 split of bench.py
                 # like the generic kernel's 1x1 instantiation; its tapped / pool-gradient instantiations do not

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, H, W, Cin, Cout, epi=0, ld_extra=0, mirrored=False, seed=0, act=3, expect_kernel=1):
+def _run(B, H, W, Cin, Cout, epi=0, ld_extra=0, mirrored=False, seed=0, act=3, expect_kernel=1, pipe_extra=0, expect_cols=None):
     from ryolov4_amd import hip
     from ryolov4_amd.engine import structs as S
     hip.lib()
@@ -39,14 +39,16 @@ def _run(B, H, W, Cin, Cout, epi=0, ld_extra=0, mirrored=False, seed=0, act=3, e
         tc.dh[t], tc.dw[t] = r - 1, s - 1
         tc.widx[t] = (8 - k) if mirrored else k
     p.epi, p.out, p.ldC = epi, yfull.data_ptr(), ldC
-    p.zeros, p.pipe = zeros.data_ptr(), 0x1 | 0x200 | 0x400
+    p.zeros, p.pipe = zeros.data_ptr(), 0x1 | 0x200 | 0x400 | pipe_extra
     p.a_bytes, p.w_bytes = xfull.numel() * 2, w.numel() * 2
     co = torch.rand(4, Cout, device=dev) + 0.5
     co[3] -= 1.0
     p.scale, p.shift, p.act = co.data_ptr() + 2 * Cout * 4, co.data_ptr() + 3 * Cout * 4, act
     rows, kern = S.I(), S.I()
     hip.call("ryolo_conv_gemm_plan", p, rows, kern)
-    assert kern.value == expect_kernel, f"layer routed to kernel family {kern.value}, expected {expect_kernel}"
+    assert kern.value & 0xff == expect_kernel, f"layer routed to kernel family {kern.value & 0xff}, expected {expect_kernel}"
+    if expect_cols is not None:
+        assert ((kern.value >> 16) & 15) * 32 == expect_cols, f"tile columns {((kern.value >> 16) & 15) * 32}, expected {expect_cols}"
     stats = torch.zeros(rows.value, 2, Cout, device=dev)
     p.stats = stats.data_ptr()
     hip.call("ryolo_conv_gemm", p, hip.stream())
@@ -95,6 +97,39 @@ def test_patch_kernel_epilogues(epi, shape):
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_patch_kernel_activations(act):
     _run(2, 25, 25, 64, 128, epi=2, act=act)
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
+def test_patch_kernel_64_column_tiles_on_wide_layers(epi):
+    """r06: on grids of fewer 128-column workgroups than CUs the kernel runs its 256 x 64 tile also for Cout > 64 (twice the workgroups;
+    pipe bit 0x2000 forces that tile): several column tiles per pixel tile, the last one ragged, statistics rows shared by the column tiles."""
+    _run(2, 50, 50, 64, 128, epi=epi, ld_extra=40, seed=60 + epi, pipe_extra=0x2000, expect_cols=64)
+    _run(2, 13, 13, 64, 192, epi=epi, seed=64 + epi, pipe_extra=0x2000, expect_cols=64)
+    _run(3, 25, 25, 96, 136, epi=epi, seed=68 + epi, pipe_extra=0x2000, expect_cols=64)        # 3 column tiles, the last 8 columns wide
+
+
+def test_patch_kernel_takes_small_grids_by_default():
+    """r06 routing: without the force bit (0x400) a 3x3 stride-1 layer of the 8-image step's size goes to the halo-patch kernel, on 64-column
+    tiles when its 128-column grid is smaller than the chip; r02-r05 kept every grid under 512 workgroups on the generic kernel."""
+    from ryolov4_amd import hip
+    from ryolov4_amd.engine import structs as S
+    hip.lib()
+    for (B, H, Cin, Cout, cols) in [(8, 25, 256, 256, 64), (8, 50, 128, 128, 64), (8, 100, 128, 128, 128), (64, 50, 128, 128, 128)]:
+        p = S.ConvGemmParams()
+        x = torch.zeros(16, device="cuda:0")
+        p.A, p.NB, p.IH, p.IW, p.Cin, p.ldA = x.data_ptr(), B, H, H, Cin, Cin
+        p.W, p.Nout, p.wtaps = x.data_ptr(), Cout, 9
+        p.OH, p.OW, p.sh, p.sw = H, H, 1, 1
+        p.oh_mul, p.ow_mul, p.OHf, p.OWf = 1, 1, H, H
+        p.nclasses = 1
+        tc = p.cls[0]
+        tc.ntaps = 9
+        for k in range(9):
+            tc.dh[k], tc.dw[k], tc.widx[k] = k // 3 - 1, k % 3 - 1, k
+        p.epi, p.out, p.ldC, p.zeros, p.pipe = 1, x.data_ptr(), Cout, x.data_ptr(), 0x201
+        rows, kern = S.I(), S.I()
+        hip.call("ryolo_conv_gemm_plan", p, rows, kern)
+        assert kern.value & 0xff == 1 and ((kern.value >> 16) & 15) * 32 == cols, (B, H, Cin, Cout, hex(kern.value))
 
 
 def test_patch_kernel_mirrored_taps():
