@@ -615,6 +615,10 @@ def main():
                                "kernels on whole-chip grids, alone: profiles/r05_wgrad_isolated.txt (DESIGN.md section 3, round 5)")
             elif "wgrad" in k:
                 out["note"] = "side-stream kernel (RYOLO_WGRAD_BLOCKS=512: two 4-wave workgroups per CU); timed alone here"
+            elif k == "conv3x3_patch_kernel<256x128>" and out["launches_per_step"] > 44:
+                out["note"] = ("class average over EVERY launch on the halo-patch kernel's 128-column tile; since r06 the one-round grids of the 25^2 maps run "
+                               "here too (RYOLO_P3_MIN_WGS; batch 64: 15 more launches per step than in r05, 745 TF/s each where the generic kernel ran "
+                               "them at 610) and pull the average below the r05 set's (DESIGN.md 3.4, 6)")
             return out
         # dominant kernel class, BOTH ways: `roofline` = the largest share of the CHIP's time (seconds x the
         # fraction of the CUs a launch holds: a kernel that runs on 96 CUs for 10 ms costs the step what a whole-chip kernel costs in 3.75 ms;

@@ -49,6 +49,10 @@ timeout 600 python tools/bench_infer.py > $O/infer.txt 2>&1; cp gpurun_out/infer
 # C5 at its own size: 1024^2, 8 images per GPU, forward + decode + top-K + rotated NMS in one hipGraph, confidence threshold low enough
 # that >= 50 k candidates per image reach the top-K / NMS stage
 B=8 SZ=1024 CONF=0.0005 IOU=0.65 timeout 600 python tools/bench_infer.py > $O/infer_1024.txt 2>&1; cp gpurun_out/infer.json $O/infer_1024_b8.json
+# per-launch tables of the eval tape (r06): the bench block's batch-64 800^2 forward and C5's batch-8 1024^2 forward
+B=64 SZ=800 timeout 300 python tools/profile_infer_layers.py > $O/infer_layers_b64_800.txt 2>&1
+B=8 SZ=1024 timeout 300 python tools/profile_infer_layers.py > $O/infer_layers_b8_1024.txt 2>&1
+B=8 K=40 timeout 300 python tools/bench_graph_step.py > $O/graph_step_b8.txt 2>&1
 # 6. other configs + batch sweep
 for cfg in "yolov4 kfiou 608 2" "yolov7 csl 800 16" "yolov5 kfiou 800 16"; do set -- $cfg; timeout 300 python bench.py --ver $1 --mode $2 --size $3 --nc $4 --no-cpu-baseline --no-loader --no-b8 --steps 8 > $O/cfg_$1_$2.json 2> $O/cfg_$1_$2.err; done
 for b in 96 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-loader --no-b8 --no-kernel-timing --steps 8 > $O/batch$b.json 2> $O/batch$b.err; done

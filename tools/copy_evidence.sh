@@ -22,6 +22,9 @@ cp $O/highres_layers_vs_floor.txt $P/${TAG}_highres_layers_vs_floor.txt
 cp $O/nms_times.json $P/${TAG}_nms_times.json
 cp $O/infer.json $P/${TAG}_infer_yolov7_kfiou_800.json
 cp $O/infer_1024_b8.json $P/${TAG}_infer_yolov7_kfiou_1024_b8_graph.json
+[ -f $O/infer_layers_b64_800.txt ] && cp $O/infer_layers_b64_800.txt $P/${TAG}_infer_layers_b64_800.txt
+[ -f $O/infer_layers_b8_1024.txt ] && cp $O/infer_layers_b8_1024.txt $P/${TAG}_infer_layers_b8_1024.txt
+[ -f $O/graph_step_b8.txt ] && grep -E "ms/step|loss after" $O/graph_step_b8.txt > $P/${TAG}_graph_step_b8.txt
 python - <<PY
 import json
 O, P, T = "$O", "$P", "$TAG"
