@@ -10,7 +10,8 @@ dev = "cuda:0"
 hip.lib(); S.check_layouts()
 st = hip.stream()
 SHAPES = [(64 * 400 * 400, 64, 64), (64 * 400 * 400, 64, 256), (64 * 200 * 200, 128, 128), (64 * 200 * 200, 256, 256), (64 * 100 * 100, 256, 256),
-          (64 * 100 * 100, 512, 512), (64 * 50 * 50, 1024, 1024), (64 * 25 * 25, 1024, 1024), (8 * 100 * 100, 256, 256)]
+          (64 * 100 * 100, 512, 512), (64 * 50 * 50, 1024, 1024), (64 * 25 * 25, 1024, 1024), (8 * 100 * 100, 256, 256),
+          (8 * 50 * 50, 256, 256), (8 * 50 * 50, 128, 128), (8 * 25 * 25, 256, 256), (8 * 25 * 25, 512, 512), (8 * 25 * 25, 1024, 1024)]      # (the 8-image step's small maps)
 print("lib", hip.LIB_PATH)
 gen = torch.Generator(device=dev).manual_seed(0)
 for M, Cc, ld in SHAPES:
