@@ -544,3 +544,60 @@ def _last_plan(net):
     graphs = [g for k, g in net.runtime()._graphs.items() if k[3]]         # the (one) training plan
     assert len(graphs) == 1
     return graphs[0]
+
+
+@pytest.mark.gpu
+def test_whole_training_step_replays_from_one_graph():
+    """r06: forward + fused loss + two-stream backward + fused SGD step captured into ONE hipGraph (tools/bench_graph_step.py times it: 14.5 vs 14.3 ms
+    eager at 8 images — a capability, not a speed-up).  The loss's dropped-row read-back (a pinned copy behind an event the next call waits on) kept
+    the step un-capturable in r05; under capture the count stays on the device.  Two models from the same state: three eager steps on one, one
+    captured step replayed three times on the other — the replays read the static batch, so parameters and loss end equal bit for bit."""
+    import torch
+    from ryolov4_amd.lib.loss import ComputeKFIoULoss
+    from ryolov4_amd.model.yolo import Yolo
+    from ryolov4_amd.synth import CFG, HYP, fill_state, synth_targets
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(1)).cuda()
+    tg = synth_targets(2, 6, 2, False, seed=2, img_size=96).cuda()
+    finals, losses = [], []
+    for captured in (False, True):
+        m = Yolo(2, CFG, "kfiou", "yolov7")
+        m.load_state_dict(fill_state(m.state_dict()))
+        m.cuda().train()
+        crit = ComputeKFIoULoss(m, HYP)
+        rt = m.runtime()
+
+        def step():
+            loss, _ = crit(m(x, training=True), tg, sync_items=False)
+            loss.backward()
+            rt.sgd_step(0.01, 0.937, zero_grad=True)
+            return loss
+
+        if not captured:
+            for _ in range(3):
+                last = step()
+            torch.cuda.synchronize()
+        else:
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+            flat, mom = rt.flat.clone(), None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                            # warm-up outside the capture: plan build, lazy kernel attributes, allocator pools
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                last = step()
+            torch.cuda.synchronize()
+            # back to the initial state (parameters, momentum, BatchNorm running statistics), then three replays = three steps
+            rt.flat.copy_(flat)
+            rt.momentum_buf.zero_()
+            m.load_state_dict(state)
+            rt.gflat.zero_()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+        finals.append(rt.flat.clone())
+        losses.append(float(last.detach()))
+    assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
+    assert losses[0] == losses[1]
